@@ -1,0 +1,156 @@
+"""CPU: the oracle (oracle/) reproduces the golden vectors generated from the reference itself
+(tests/golden/make_golden.py).  Bit-exact for integer / fp16-bit-pattern stages."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import bca, labels, measurements, resample, sliding_window as sw
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def _json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def test_g1_tile_starts():
+    for c in _json("g1_steps.json"):
+        assert sw.compute_steps_for_sliding_window(c["size"], c["patch"], c["step"]) == c["steps"], c
+
+
+def test_g2_gaussian_bits():
+    z = _npz("g2_gaussian.npz")
+    for k in z.files:
+        ts = tuple(int(v) for v in k[2:].split("x"))
+        g = sw.compute_gaussian(ts)
+        assert g.dtype == np.float16
+        np.testing.assert_array_equal(g.view(np.uint16), z[k])
+
+
+def test_g2_gaussian_128_hash():
+    meta = _json("g2_gaussian_big.json")
+    for k, m in meta.items():
+        ts = tuple(int(v) for v in k.split("x"))
+        bits = np.ascontiguousarray(sw.compute_gaussian(ts).view(np.uint16))
+        assert hashlib.sha256(bits.tobytes()).hexdigest() == m["sha256"]
+        assert int(((bits & 0x7C00) == 0).sum()) == m["n_subnormal"]
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_g3_sliding_window_accumulation(case):
+    z = _npz("g3_sliding_window.npz")
+    tiles = z[f"{case}_tiles"]
+    it = iter(range(len(tiles)))
+    out = sw.predict_sliding_window_return_logits(
+        lambda patch: tiles[next(it)][None], z[f"{case}_x"], [int(v) for v in z[f"{case}_patch"]],
+        tiles.shape[1], float(z[f"{case}_step"]))
+    np.testing.assert_array_equal(out.view(np.uint16), z[f"{case}_logits_bits"])
+    np.testing.assert_array_equal(labels.argmax_labels(out), z[f"{case}_seg"])
+
+
+def test_g3_sliding_window_own_conv():
+    """Same, but with the tile predictions recomputed by a torch-CPU conv from the stored weights."""
+    import torch
+    z = _npz("g3_sliding_window.npz")
+    for case in "ab":
+        w, b = torch.from_numpy(z[f"{case}_w"]), torch.from_numpy(z[f"{case}_b"])
+        torch.set_num_threads(1)
+
+        def fn(p):
+            return torch.nn.functional.conv3d(torch.from_numpy(p), w, b, padding=1).numpy()
+        out = sw.predict_sliding_window_return_logits(fn, z[f"{case}_x"], [16, 16, 16], w.shape[0],
+                                                      float(z[f"{case}_step"]))
+        ref = z[f"{case}_logits_bits"].view(np.float16)
+        # conv summation order may differ between runs/threads: allow 1 fp16 ulp on < 0.1 % of voxels
+        neq = out.view(np.uint16) != z[f"{case}_logits_bits"]
+        assert neq.mean() < 1e-3
+        np.testing.assert_allclose(out.astype(np.float32), ref.astype(np.float32), rtol=2e-3, atol=1e-3)
+
+
+def test_g3_no_gaussian():
+    z = _npz("g3_sliding_window.npz")
+    tiles = z["e_tiles"]
+    it = iter(range(len(tiles)))
+    out = sw.predict_sliding_window_return_logits(lambda p: tiles[next(it)][None], z["e_x"], [16, 16, 16], 2, 0.5,
+                                                  use_gaussian=False)
+    np.testing.assert_array_equal(out.view(np.uint16), z["e_logits_bits"])
+
+
+def test_g3b_fold_ensemble():
+    z = _npz("g3b_folds.npz")
+    folds = [f.view(np.float16) for f in z["fold_logits_bits"]]
+    np.testing.assert_array_equal(sw.ensemble_folds(folds).view(np.uint16), z["ensemble_bits"])
+
+
+def test_g4_ctnorm():
+    z = _npz("g4_ctnorm.npz")
+    m, s, lo, hi = z["props"]
+    y = labels.ct_normalize(z["x"], m, s, lo, hi)
+    np.testing.assert_array_equal(y.view(np.uint32), z["y"].view(np.uint32))
+
+
+def test_g5_resample():
+    z = _npz("g5_resample.npz")
+    for k in ["half", "twothirds", "thick", "up2", "aniso"]:
+        zoom = z[f"zoom_{k}"]
+        np.testing.assert_array_equal(resample.resample_img(z["ct"].astype(np.float64), zoom, 3).astype(np.int32),
+                                      z[f"ct3_{k}"])
+        np.testing.assert_array_equal(resample.resample_img(z["lab"].astype(np.float64), zoom, 0).astype(np.uint8),
+                                      z[f"lab0_{k}"])
+
+
+def test_g6_argmax_ties():
+    z = _npz("g6_argmax.npz")
+    np.testing.assert_array_equal(labels.argmax_labels(z["logits_bits"].view(np.float16)), z["seg"])
+
+
+def test_g7_merge():
+    z = _npz("g7_merge.npz")
+    t = _json("g7_label_tables.json")
+    inv = {v: int(k) for k, v in t["total"].items()}
+    maps = [{int(k): v for k, v in t["parts"][str(tid)].items()} for tid in (291, 292, 293, 294, 295)]
+    np.testing.assert_array_equal(labels.merge_parts(list(z["segs"]), maps, inv), z["combined"])
+
+
+def _cmp(a, b, rtol, path=""):
+    if isinstance(a, dict):
+        assert set(a) == set(b), (path, set(a) ^ set(b))
+        for k in a:
+            _cmp(a[k], b[k], rtol, f"{path}/{k}")
+    elif isinstance(a, list):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _cmp(x, y, rtol, f"{path}[{i}]")
+    elif a is None or b is None or isinstance(a, (bool, str)):
+        assert a == b, (path, a, b)
+    else:
+        assert np.isclose(a, b, rtol=rtol, atol=0), (path, a, b)
+
+
+def test_g8_bca():
+    z = _npz("g8_bca.npz")
+    g = _json("g8_bca_measurements.json")
+    tis = bca.subclassify_tissues(z["ct"], z["regions"])
+    np.testing.assert_array_equal(tis, z["tissues"])
+    np.testing.assert_array_equal(bca.subclassify_tissues(z["ct"], z["regions"], True, 0), z["tissues_median"])
+    js = bca.bca_measurements_json(z["ct"], z["regions"], z["parts"], tis, tuple(z["spacing"]),
+                                   {k: tuple(v) for k, v in g["vertebrae"].items()})
+    js = json.loads(json.dumps(js, default=float))
+    _cmp(js, g["json"], 1e-12)
+
+
+def test_g9_measurements():
+    z = _npz("g9_measurements.npz")
+    g = _json("g9_measurements.json")
+    am, asd = g["auto"]
+    res = measurements.metrics_for_each_region(z["ct"], z["lab"], g["label_map"], am, asd, z["spacing"])
+    _cmp(json.loads(json.dumps(res, default=float)), g["with_ref"], 1e-12)
+    res = measurements.metrics_for_each_region(z["ct"], z["lab"], {"spleen": 1}, None, None, z["spacing"])
+    _cmp(json.loads(json.dumps(res, default=float)), g["no_ref"], 1e-12)
