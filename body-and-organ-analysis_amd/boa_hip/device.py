@@ -1,0 +1,111 @@
+"""Device context and buffers on top of the C ABI (plumbing only: memory, streams, timers)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed buffer owned by a Context; freed explicitly or when garbage collected."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(ctx.lib.boa_malloc(ctx.h, self.nbytes, C.byref(p)), f"boa_malloc({nbytes})")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr is not None and self.ctx.h is not None:
+            self.ctx.lib.boa_free(self.ctx.h, C.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def zero(self):
+        check(self.ctx.lib.boa_memset(self.ctx.h, C.c_void_p(self.ptr), 0, self.nbytes))
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes, (a.nbytes, self.nbytes)
+        check(self.ctx.lib.boa_h2d(self.ctx.h, C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return self
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes, (out.nbytes, self.nbytes)
+        check(self.ctx.lib.boa_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), out.nbytes))
+        return out
+
+    @property
+    def vp(self):
+        return C.c_void_p(self.ptr)
+
+
+class Context:
+    """One per GPU / process (`boa_init`)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = _lib.lib()
+        h = C.c_void_p()
+        check(self.lib.boa_init(int(device), C.c_void_p(stream) if stream else None, C.byref(h)), "boa_init")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h is not None:
+            self.lib.boa_destroy(self.h)
+            self.h = None
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def from_numpy(self, arr: np.ndarray) -> DeviceBuffer:
+        a = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(a.nbytes, 1)).upload(a)
+
+    def zeros(self, nbytes: int) -> DeviceBuffer:
+        b = DeviceBuffer(self, nbytes)
+        b.zero()
+        return b
+
+    def sync(self):
+        check(self.lib.boa_sync(self.h), "boa_sync")
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int()
+        tot, free = C.c_size_t(), C.c_size_t()
+        check(self.lib.boa_device_info(self.h, name, 256, C.byref(cu), C.byref(tot), C.byref(free)))
+        return {"name": name.value.decode(), "cu_count": cu.value, "total_mem": tot.value, "free_mem": free.value}
+
+    # ---- timing -----------------------------------------------------------------------------------
+    def timer_start(self, slot=0):
+        check(self.lib.boa_timer_start(self.h, slot))
+
+    def timer_stop(self, slot=0) -> float:
+        ms = C.c_float()
+        check(self.lib.boa_timer_stop(self.h, slot, C.byref(ms)))
+        return ms.value
+
+    def prof_enable(self, on=True):
+        check(self.lib.boa_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.lib.boa_prof_reset(self.h))
+
+    def prof_get(self):
+        out = {}
+        for k, name in enumerate(_lib.K_NAMES):
+            ms, n, fl, by = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+            check(self.lib.boa_prof_get(self.h, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return out

@@ -1,0 +1,221 @@
+"""HipPredictor: the device counterpart of nnUNetPredictor's inference core.
+
+Same method names and argument meaning as NN/inference/predict_from_raw_data.py for the seams the hot path
+uses:
+  predict_sliding_window_return_logits(input_image[C,X,Y,Z] fp32) -> fp16 [heads,X,Y,Z]     (:634-680)
+  predict_logits_from_preprocessed_data(data)  (fold loop + fp16 mean)                       (:471-504)
+plus the fused fast path `predict_segmentation` (normalise + fold mean + argmax + part remap on device, only the
+uint8 label volume returns) replacing export_prediction.convert_predicted_logits_to_segmentation_with_correct_shape
+(:14-71) for identity resampling.
+Errors: RuntimeError on inf logits (:622-625), ValueError/AssertionError on bad shapes, MemoryError when the
+accumulators do not fit (the reference would retry with host-side results, :663-672; with 288 GB HBM the
+14.5 GB worst case fits, so no host fallback exists here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import sliding_window as sw
+from ._lib import check, int3
+from .device import Context, DeviceBuffer
+from .plans import NetGeometry
+
+
+class HipPredictor:
+    def __init__(self, ctx: Context, geometry: NetGeometry, tile_step_size: float = 0.5, use_gaussian: bool = True,
+                 use_mirroring: bool = False, max_batch: int = 4, verbose: bool = False):
+        if use_mirroring:
+            # BOA runs every model with tta=False / *NoMirroring trainers (TS/python_api.py:753)
+            raise NotImplementedError("test-time mirroring is not used by BOA and is not implemented on device")
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.geom = geometry
+        self.tile_step_size = float(tile_step_size)
+        self.use_gaussian = use_gaussian
+        self.verbose = verbose
+        self.max_batch = int(max_batch)
+        self.list_of_parameters: List[np.ndarray] = []
+        self._desc = geometry.to_desc()
+        self._net = None
+        self._gauss_dev: Optional[DeviceBuffer] = None
+        self._loaded_fold = None
+
+    # ---- model management ---------------------------------------------------------------------------
+    def set_parameters(self, weight_blobs: Sequence[np.ndarray]):
+        """One fp32 blob per fold (plans.weight_blob_from_state_dict); mirrors `self.list_of_parameters`."""
+        need = self.lib.boa_net_weight_count(C.byref(self._desc))
+        if need == 0:
+            raise ValueError("invalid network geometry")
+        self.list_of_parameters = []
+        for b in weight_blobs:
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            if b.size != need:
+                raise ValueError(f"weight blob has {b.size} floats, geometry needs {need}")
+            self.list_of_parameters.append(b)
+        self._loaded_fold = None
+
+    def _ensure_net(self, fold: int):
+        w = self.list_of_parameters[fold]
+        if self._net is None:
+            h = C.c_void_p()
+            check(self.lib.boa_net_create(self.ctx.h, C.byref(self._desc), w.ctypes.data_as(C.c_void_p), w.size,
+                                          self.max_batch, 0, C.byref(h)), "boa_net_create")
+            self._net = h
+            self._loaded_fold = fold
+        elif self._loaded_fold != fold:
+            check(self.lib.boa_net_load_weights(self._net, w.ctypes.data_as(C.c_void_p), w.size), "boa_net_load_weights")
+            self._loaded_fold = fold
+
+    def close(self):
+        if self._net is not None:
+            self.lib.boa_net_destroy(self._net)
+            self._net = None
+        self._gauss_dev = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _gaussian(self) -> Optional[DeviceBuffer]:
+        if not self.use_gaussian:
+            return None
+        if self._gauss_dev is None:
+            g = sw.compute_gaussian(tuple(self.geom.patch_size), sigma_scale=1.0 / 8, value_scaling_factor=10)
+            self._gauss_dev = self.ctx.from_numpy(np.ascontiguousarray(g).view(np.uint16))
+        return self._gauss_dev
+
+    # ---- tile-level seam ----------------------------------------------------------------------------
+    def network_forward(self, volume: np.ndarray, origins: np.ndarray) -> np.ndarray:
+        """`self.network(x)` for tiles cut from `volume` [Cin,X,Y,Z] at `origins`: fp32 [n,heads,*patch]."""
+        self._ensure_net(0 if self._loaded_fold is None else self._loaded_fold)
+        vol = np.ascontiguousarray(volume, dtype=np.float32)
+        assert vol.ndim == 4 and vol.shape[0] == self.geom.in_channels
+        origins = np.ascontiguousarray(origins, dtype=np.int32).reshape(-1, 3)
+        n = origins.shape[0]
+        P = self.geom.patch_size
+        dvol = self.ctx.from_numpy(vol)
+        dout = self.ctx.alloc(n * self.geom.num_classes * int(np.prod(P)) * 4)
+        check(self.lib.boa_net_forward(self._net, dvol.vp, int3(vol.shape[1:]), origins.ctypes.data_as(C.POINTER(C.c_int)),
+                                       n, dout.vp), "boa_net_forward")
+        out = dout.download((n, self.geom.num_classes, *P), np.float32)
+        dvol.free()
+        dout.free()
+        return out
+
+    # ---- sliding window on a resident volume --------------------------------------------------------
+    def _run_fold(self, dvol: DeviceBuffer, V, PV, below, origins, acc: DeviceBuffer, nacc: DeviceBuffer, fold: int):
+        self._ensure_net(fold)
+        acc.zero()
+        nacc.zero()
+        g = self._gaussian()
+        check(self.lib.boa_net_predict_sliding_window(
+            self._net, dvol.vp, int3(V), int3(PV), int3(below), origins.ctypes.data_as(C.POINTER(C.c_int)),
+            origins.shape[0], g.vp if g else None, acc.vp, nacc.vp), "boa_net_predict_sliding_window")
+
+    def _setup(self, input_image: np.ndarray):
+        assert isinstance(input_image, np.ndarray) and input_image.ndim == 4, \
+            "input_image must be a 4D np.ndarray (c, x, y, z)"
+        if input_image.shape[0] != self.geom.in_channels:
+            raise ValueError(f"expected {self.geom.in_channels} channels, got {input_image.shape[0]}")
+        V = list(input_image.shape[1:])
+        PV, below = sw.pad_amounts(V, self.geom.patch_size)
+        origins = sw.get_sliding_window_origins(PV, self.geom.patch_size, self.tile_step_size)
+        return V, PV, below, origins
+
+    def predict_sliding_window_return_logits(self, input_image: np.ndarray, fold: int = 0) -> np.ndarray:
+        V, PV, below, origins = self._setup(input_image)
+        C_ = self.geom.num_classes
+        nvox = int(np.prod(PV))
+        dvol = self.ctx.from_numpy(np.ascontiguousarray(input_image, dtype=np.float32))
+        acc = self.ctx.alloc(C_ * nvox * 2)
+        nacc = self.ctx.alloc(nvox * 2)
+        flag = self.ctx.zeros(4)
+        try:
+            self._run_fold(dvol, V, PV, below, origins, acc, nacc, fold)
+            check(self.lib.boa_finalize_labels(self.ctx.h, acc.vp, nacc.vp, C_, int3(PV), None, 0, 0, 1, None, 0, None,
+                                               None, None, flag.vp), "boa_finalize_labels")
+            if int(flag.download((1,), np.int32)[0]):
+                raise RuntimeError("Encountered inf in predicted array. Aborting... If this problem persists, reduce "
+                                   "value_scaling_factor in compute_gaussian or increase the dtype of predicted_logits "
+                                   "to fp32")
+            logits = acc.download((C_, *PV), np.uint16).view(np.float16)
+        finally:
+            for b in (dvol, acc, nacc, flag):
+                b.free()
+        sl = (slice(None),) + tuple(slice(b, b + v) for b, v in zip(below, V))
+        return np.ascontiguousarray(logits[sl])
+
+    def predict_logits_from_preprocessed_data(self, data: np.ndarray) -> np.ndarray:
+        """Fold loop with the reference's fp16 `+=` and `/= n_folds` (:483-500), on the host for the logits
+        seam; `predict_segmentation` does the same on device."""
+        pred = None
+        for f in range(len(self.list_of_parameters)):
+            lg = self.predict_sliding_window_return_logits(data, fold=f)
+            if pred is None:
+                pred = lg
+            else:
+                pred = (pred.astype(np.float32) + lg.astype(np.float32)).astype(np.float16)
+        if len(self.list_of_parameters) > 1:
+            pred = (pred.astype(np.float32) / np.float32(len(self.list_of_parameters))).astype(np.float16)
+        return pred
+
+    def predict_segmentation_device(self, dvol: DeviceBuffer, V, labels_out: DeviceBuffer, lut: Optional[np.ndarray] = None,
+                                    merge: bool = False, work: Optional[dict] = None):
+        """All folds -> labels on device.  dvol: fp32 [Cin,*V] resident; labels_out: uint8 [*V] resident (updated in
+        place when merge=True).  `work` may carry preallocated acc / n / fold buffers to reuse across models."""
+        PV, below = sw.pad_amounts(V, self.geom.patch_size)
+        origins = sw.get_sliding_window_origins(PV, self.geom.patch_size, self.tile_step_size)
+        C_ = self.geom.num_classes
+        nvox = int(np.prod(PV))
+        nf = len(self.list_of_parameters)
+        own = work is None
+        work = work if work is not None else {}
+
+        def buf(name, nbytes):
+            b = work.get(name)
+            if b is None or b.nbytes < nbytes:
+                if b is not None:
+                    b.free()
+                b = self.ctx.alloc(nbytes)
+                work[name] = b
+            return b
+
+        acc = buf("acc", C_ * nvox * 2)
+        nacc = buf("n", nvox * 2)
+        fold = buf("fold", C_ * nvox * 2) if nf > 1 else None
+        flag = buf("flag", 4)
+        flag.zero()
+        lut_arr = None
+        if lut is not None:
+            lut_arr = np.zeros(256, dtype=np.uint8)
+            lut_arr[:len(lut)] = lut
+        crop = any(b != 0 for b in below) or list(PV) != list(V)
+        for f in range(nf):
+            self._run_fold(dvol, V, PV, below, origins, acc, nacc, f)
+            last = f == nf - 1
+            check(self.lib.boa_finalize_labels(
+                self.ctx.h, acc.vp, nacc.vp, C_, int3(PV), fold.vp if fold else None, 0 if f == 0 else 1,
+                nf if (last and fold) else 0, 0, lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None,
+                1 if merge else 0, labels_out.vp if last else None, int3(below) if crop else None,
+                int3(V) if crop else None, flag.vp), "boa_finalize_labels")
+        if int(flag.download((1,), np.int32)[0]):
+            raise RuntimeError("Encountered inf in predicted array. Aborting...")
+        if own:
+            for b in work.values():
+                b.free()
+
+    def predict_segmentation(self, input_image: np.ndarray, lut: Optional[np.ndarray] = None) -> np.ndarray:
+        V = list(input_image.shape[1:])
+        dvol = self.ctx.from_numpy(np.ascontiguousarray(input_image, dtype=np.float32))
+        lab = self.ctx.zeros(int(np.prod(V)))
+        try:
+            self.predict_segmentation_device(dvol, V, lab, lut=lut, merge=False)
+            return lab.download(tuple(V), np.uint8)
+        finally:
+            dvol.free()
+            lab.free()

@@ -1,0 +1,474 @@
+// HBM-bound voxel aggregations of the BOA body-composition / measurement path (integer arithmetic only):
+// tissue subclassification + slice-wise counts and HU sums, per-label HU histograms, label/HU masks,
+// separable binary erosion, 26-connected component labelling by atomic union-find.
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------
+// BCA/tissue/subclassification.py:38-53 with the rules of BCA/tissue/definition.py:22-30 applied in enum order
+// (later rules overwrite): MUSCLE(-29..150 in MUSCLE=2), BONE(-1000..3000 in BONE=5), SAT/VAT/IMAT/PAT/EAT
+// (-190..-30 in SUBCUTANEOUS=1 / ABDOMINAL=3 / MUSCLE=2 / MEDIASTINUM=9 / PERICARDIUM=7).
+__device__ __forceinline__ int tissue_of(int hu, int region) {
+    const bool adip = hu >= -190 && hu <= -30;
+    int t = 0;
+    if (region == 2 && hu >= -29 && hu <= 150) t = 1;
+    if (region == 5 && hu >= -1000 && hu <= 3000) t = 2;
+    if (adip) {
+        if (region == 1) t = 3;
+        if (region == 3) t = 4;
+        if (region == 2) t = 5;
+        if (region == 9) t = 6;
+        if (region == 7) t = 7;
+    }
+    return t;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_tissue_aggregate(const short* __restrict__ ct,
+                                                          const unsigned char* __restrict__ regions,
+                                                          const unsigned char* __restrict__ parts,
+                                                          unsigned char* __restrict__ tissues, int slice_vox,
+                                                          unsigned int* __restrict__ counts,
+                                                          long long* __restrict__ sums) {
+    __shared__ unsigned int s_cnt[16];
+    __shared__ long long s_sum[16];
+    const int z = blockIdx.y;
+    if (threadIdx.x < 16) {
+        s_cnt[threadIdx.x] = 0;
+        s_sum[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    int cnt[2][8];
+    int sum[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cnt[a][t] = sum[a][t] = 0;
+    const size_t base = (size_t)z * slice_vox;
+    const int nvec = slice_vox / VEC;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+        short hu[VEC] __attribute__((aligned(16)));
+        unsigned char rg[VEC] __attribute__((aligned(8)));
+        unsigned char pt[VEC] __attribute__((aligned(8)));
+        unsigned char ts[VEC] __attribute__((aligned(8)));
+        const size_t o = base + (size_t)i * VEC;
+        if (VEC == 8) {
+            *(uint4*)hu = *(const uint4*)(ct + o);
+            *(uint2*)rg = *(const uint2*)(regions + o);
+            if (parts) *(uint2*)pt = *(const uint2*)(parts + o);
+        } else {
+            hu[0] = ct[o];
+            rg[0] = regions[o];
+            if (parts) pt[0] = parts[o];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int t = tissue_of(hu[j], rg[j]);
+            ts[j] = (unsigned char)t;
+            const bool torso = parts && pt[j] == 1;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                const bool m = (t == k);
+                cnt[0][k] += m ? 1 : 0;
+                sum[0][k] += m ? hu[j] : 0;
+                cnt[1][k] += (m && torso) ? 1 : 0;
+                sum[1][k] += (m && torso) ? hu[j] : 0;
+            }
+        }
+        if (tissues) {
+            if (VEC == 8)
+                *(uint2*)(tissues + o) = *(const uint2*)ts;
+            else
+                tissues[o] = ts[0];
+        }
+    }
+    // wave reduce, then one LDS atomic per wave and counter, then one global atomic per block and counter
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            int c = cnt[a][k];
+            long long s = sum[a][k];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                c += __shfl_xor(c, m);
+                s += __shfl_xor(s, m);
+            }
+            if ((threadIdx.x & 63) == 0 && c) {
+                atomicAdd(&s_cnt[a * 8 + k], (unsigned int)c);
+                atomicAdd((unsigned long long*)&s_sum[a * 8 + k], (unsigned long long)s);
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x < 16 && s_cnt[threadIdx.x]) {
+        atomicAdd(&counts[(size_t)z * 16 + threadIdx.x], s_cnt[threadIdx.x]);
+        atomicAdd((unsigned long long*)&sums[(size_t)z * 16 + threadIdx.x], (unsigned long long)s_sum[threadIdx.x]);
+    }
+}
+
+extern "C" int boa_tissue_aggregate(boa_ctx* c, const int16_t* dev_ct, const uint8_t* dev_regions,
+                                    const uint8_t* dev_parts, uint8_t* dev_tissues_out, int Z, int Y, int X,
+                                    uint32_t* dev_counts, int64_t* dev_hu_sums) {
+    BOA_REQUIRE(c && dev_ct && dev_regions && dev_counts && dev_hu_sums, "boa_tissue_aggregate: NULL argument");
+    BOA_REQUIRE(Z > 0 && Y > 0 && X > 0 && (long long)Y * X < (1ll << 30), "boa_tissue_aggregate: bad dims");
+    BOA_HIP_TRY(hipMemsetAsync(dev_counts, 0, (size_t)Z * 16 * sizeof(uint32_t), c->stream));
+    BOA_HIP_TRY(hipMemsetAsync(dev_hu_sums, 0, (size_t)Z * 16 * sizeof(int64_t), c->stream));
+    const int sv = Y * X;
+    const bool vec8 = (sv % 8 == 0) && (((uintptr_t)dev_ct) % 16 == 0) && (((uintptr_t)dev_regions) % 8 == 0) &&
+                      (((uintptr_t)dev_parts) % 8 == 0) && (((uintptr_t)dev_tissues_out) % 8 == 0);
+    const int nvec = vec8 ? sv / 8 : sv;
+    int gx = std::min(ceil_div(nvec, 256), 64);
+    const double vox = (double)Z * sv;
+    KernelTimer t(c, BOA_K_OTHER, 0, vox * (3.0 + (dev_parts ? 1 : 0) + (dev_tissues_out ? 1 : 0)));
+    if (vec8)
+        hipLaunchKernelGGL(k_tissue_aggregate<8>, dim3(gx, Z), dim3(256), 0, c->stream, dev_ct, dev_regions, dev_parts,
+                           dev_tissues_out, sv, dev_counts, (long long*)dev_hu_sums);
+    else
+        hipLaunchKernelGGL(k_tissue_aggregate<1>, dim3(gx, Z), dim3(256), 0, c->stream, dev_ct, dev_regions, dev_parts,
+                           dev_tissues_out, sv, dev_counts, (long long*)dev_hu_sums);
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_slice_presence(const unsigned char* __restrict__ labels, int slice_vox,
+                                                        unsigned char* __restrict__ present) {
+    __shared__ unsigned int flags[256];
+    const int z = blockIdx.y;
+    flags[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned char* p = labels + (size_t)z * slice_vox;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < slice_vox; i += gridDim.x * 256) flags[p[i]] = 1;
+    __syncthreads();
+    if (flags[threadIdx.x]) present[(size_t)z * 256 + threadIdx.x] = 1;
+}
+
+extern "C" int boa_slice_label_presence(boa_ctx* c, const uint8_t* dev_labels, int Z, int Y, int X,
+                                        uint8_t* dev_present) {
+    BOA_REQUIRE(c && dev_labels && dev_present && Z > 0 && Y > 0 && X > 0, "boa_slice_label_presence: bad argument");
+    BOA_HIP_TRY(hipMemsetAsync(dev_present, 0, (size_t)Z * 256, c->stream));
+    const int sv = Y * X;
+    int gx = std::min(ceil_div(sv, 256 * 8), 32);
+    KernelTimer t(c, BOA_K_OTHER, 0, (double)Z * sv);
+    hipLaunchKernelGGL(k_slice_presence, dim3(gx, Z), dim3(256), 0, c->stream, dev_labels, sv, dev_present);
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per-label HU histogram (label 0 = background is never measured by the reference and is skipped)
+__global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
+                                                    const unsigned char* __restrict__ mask, size_t n, int hu_min,
+                                                    int nbins, unsigned int* __restrict__ hist) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const int l = labels[i];
+        if (l == 0) continue;
+        if (mask && !mask[i]) continue;
+        int b = (int)ct[i] - hu_min;
+        b = b < 0 ? 0 : (b >= nbins ? nbins - 1 : b);
+        atomicAdd(&hist[(size_t)l * nbins + b], 1u);
+    }
+}
+
+extern "C" int boa_label_hu_histogram(boa_ctx* c, const int16_t* dev_ct, const uint8_t* dev_labels,
+                                      const uint8_t* dev_mask, size_t n, int hu_min, int nbins, uint32_t* dev_hist) {
+    BOA_REQUIRE(c && dev_ct && dev_labels && dev_hist && nbins > 0, "boa_label_hu_histogram: bad argument");
+    BOA_HIP_TRY(hipMemsetAsync(dev_hist, 0, (size_t)256 * nbins * sizeof(uint32_t), c->stream));
+    if (n == 0) return BOA_OK;
+    int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 32);
+    KernelTimer t(c, BOA_K_OTHER, 0, (double)n * (3.0 + (dev_mask ? 1 : 0)));
+    hipLaunchKernelGGL(k_label_hist, dim3(grid), dim3(256), 0, c->stream, dev_ct, dev_labels, dev_mask, n, hu_min,
+                       nbins, dev_hist);
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+struct Lut256 {
+    unsigned char v[256];
+};
+
+__global__ __launch_bounds__(256) void k_label_hu_mask(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
+                                                       Lut256 lut, int mode, int lo, int hi, size_t n,
+                                                       unsigned char* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        bool m = lut.v[labels[i]] != 0;
+        if (mode != 0) {
+            const int hu = ct[i];
+            const bool inside = hu >= lo && hu <= hi;
+            m = m && (mode == 1 ? inside : !inside);
+        }
+        out[i] = m ? 1 : 0;
+    }
+}
+
+extern "C" int boa_label_hu_mask(boa_ctx* c, const int16_t* dev_ct, const uint8_t* dev_labels, const uint8_t* host_lut,
+                                 int mode, int hu_lo, int hu_hi, size_t n, uint8_t* dev_mask_out) {
+    BOA_REQUIRE(c && dev_labels && host_lut && dev_mask_out && (mode == 0 || dev_ct), "boa_label_hu_mask: bad argument");
+    BOA_REQUIRE(mode >= 0 && mode <= 2, "boa_label_hu_mask: mode %d", mode);
+    if (n == 0) return BOA_OK;
+    Lut256 lut;
+    memcpy(lut.v, host_lut, 256);
+    int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 32);
+    KernelTimer t(c, BOA_K_OTHER, 0, (double)n * 4.0);
+    hipLaunchKernelGGL(k_label_hu_mask, dim3(grid), dim3(256), 0, c->stream, dev_ct, dev_labels, lut, mode, hu_lo, hu_hi,
+                       n, dev_mask_out);
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+__global__ __launch_bounds__(256) void k_label_select(const unsigned char* __restrict__ labels, size_t n, int mode,
+                                                      int a, int b, int cc, unsigned char* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const int l = labels[i];
+        bool m;
+        if (mode == 0)
+            m = l == a;
+        else if (mode == 1)
+            m = l > 0;
+        else
+            m = (l == a) || (l == b) || (l == cc);
+        out[i] = m ? 1 : 0;
+    }
+}
+
+extern "C" int boa_label_select(boa_ctx* c, const uint8_t* dev_labels, size_t n, int mode, const int vals[3],
+                                uint8_t* dev_mask_out) {
+    BOA_REQUIRE(c && dev_labels && dev_mask_out && mode >= 0 && mode <= 2, "boa_label_select: bad argument");
+    BOA_REQUIRE(mode == 1 || vals, "boa_label_select: vals is NULL");
+    if (n == 0) return BOA_OK;
+    int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 32);
+    hipLaunchKernelGGL(k_label_select, dim3(grid), dim3(256), 0, c->stream, dev_labels, n, mode, vals ? vals[0] : 0,
+                       vals ? vals[1] : 0, vals ? vals[2] : 0, dev_mask_out);
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// erode_region: AND over offsets [-(k/2) .. k - 1 - k/2] for even k (footprint padded at the end), symmetric for
+// odd k; outside the volume counts as set.  One pass per axis.
+__global__ __launch_bounds__(256) void k_erode_axis(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                                    int Z, int Y, int X, int axis, int lo, int hi) {
+    const size_t n = (size_t)Z * Y * X;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % X);
+    const int y = (int)((i / X) % Y);
+    const int z = (int)(i / ((size_t)X * Y));
+    const int pos = axis == 0 ? z : (axis == 1 ? y : x);
+    const int len = axis == 0 ? Z : (axis == 1 ? Y : X);
+    const size_t st = axis == 0 ? (size_t)Y * X : (axis == 1 ? (size_t)X : 1);
+    unsigned char r = 1;
+    for (int d = lo; d <= hi; ++d) {
+        const int q = pos + d;
+        if (q < 0 || q >= len) continue;
+        r &= (in[i + (long long)d * (long long)st] != 0) ? 1 : 0;
+    }
+    out[i] = r;
+}
+
+extern "C" int boa_binary_erode(boa_ctx* c, const uint8_t* dev_mask, uint8_t* dev_out, uint8_t* dev_tmp, int Z, int Y,
+                                int X, int kernel_value) {
+    BOA_REQUIRE(c && dev_mask && dev_out && dev_tmp && kernel_value >= 1, "boa_binary_erode: bad argument");
+    BOA_REQUIRE(dev_out != dev_mask && dev_tmp != dev_mask && dev_tmp != dev_out, "boa_binary_erode: buffers must differ");
+    const int k = kernel_value;
+    const int center = (k % 2 == 0) ? (k + 1) / 2 : k / 2;  // centre of the (padded) footprint
+    const int lo = -center, hi = k - 1 - center;
+    const size_t n = (size_t)Z * Y * X;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    KernelTimer t(c, BOA_K_OTHER, 0, (double)n * 6.0);
+    hipLaunchKernelGGL(k_erode_axis, dim3(grid), dim3(256), 0, c->stream, dev_mask, dev_out, Z, Y, X, 2, lo, hi);
+    hipLaunchKernelGGL(k_erode_axis, dim3(grid), dim3(256), 0, c->stream, dev_out, dev_tmp, Z, Y, X, 1, lo, hi);
+    hipLaunchKernelGGL(k_erode_axis, dim3(grid), dim3(256), 0, c->stream, dev_tmp, dev_out, Z, Y, X, 0, lo, hi);
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 26-connected components by atomic union-find (roots = smallest linear index of each component)
+#define AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+__device__ __forceinline__ int uf_find(int* L, int i) {
+    int p = AGENT_LOAD(&L[i]);
+    while (p != i) {
+        i = p;
+        p = AGENT_LOAD(&L[i]);
+    }
+    return i;
+}
+
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+    while (true) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) {
+            int t = a;
+            a = b;
+            b = t;
+        }
+        int old = atomicMin(&L[a], b);  // link the larger root under the smaller
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_init(const unsigned char* __restrict__ mask, size_t n, int* __restrict__ L) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) L[i] = mask[i] ? (int)i : -1;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_merge(const unsigned char* __restrict__ mask, int Z, int Y, int X, int* L) {
+    const size_t n = (size_t)Z * Y * X;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !mask[i]) return;
+    const int x = (int)(i % X);
+    const int y = (int)((i / X) % Y);
+    const int z = (int)(i / ((size_t)X * Y));
+    // the 13 neighbours with larger linear index
+#pragma unroll
+    for (int dz = 0; dz <= 1; ++dz)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (dz == 0 && (dy < 0 || (dy == 0 && dx <= 0))) continue;
+                const int zz = z + dz, yy = y + dy, xx = x + dx;
+                if (zz >= Z || yy < 0 || yy >= Y || xx < 0 || xx >= X) continue;
+                const size_t j = ((size_t)zz * Y + yy) * X + xx;
+                if (mask[j]) uf_union(L, (int)i, (int)j);
+            }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_compress(size_t n, int* L, unsigned int* sizes, int* n_comp) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int root = -1;
+    if (i < n && L[i] >= 0) {
+        root = (int)i;
+        int p = L[root];
+        while (p != root) {
+            root = p;
+            p = L[root];
+        }
+    }
+    // wave-aggregated size counting: one atomic per distinct root per wave
+    unsigned long long active = __ballot(root >= 0);
+    const int lane = threadIdx.x & 63;
+    bool mine = root >= 0;
+    while (active) {
+        const int leader = __ffsll((long long)active) - 1;
+        const int r = __shfl(root, leader);
+        const unsigned long long same = __ballot(mine && root == r);
+        if (lane == leader) {
+            atomicAdd(&sizes[r], (unsigned int)__popcll(same));
+        }
+        if (mine && root == r) mine = false;
+        active &= ~same;
+    }
+    if (i < n && root >= 0 && root == (int)i) atomicAdd(n_comp, 1);
+    __syncthreads();
+    if (i < n) L[i] = root;  // safe: every thread of the grid only reads parents towards smaller indices ... see note
+}
+
+// note on k_ccl_compress: path compression writes L[i] = root while other threads may still walk through i.
+// A walker that reads the new value simply jumps to the root sooner: values only ever move towards the root.
+
+extern "C" int boa_ccl26(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int X, int32_t* dev_roots,
+                         uint32_t* dev_sizes, int* host_n_components) {
+    BOA_REQUIRE(c && dev_mask && dev_roots && dev_sizes && Z > 0 && Y > 0 && X > 0, "boa_ccl26: bad argument");
+    const size_t n = (size_t)Z * Y * X;
+    BOA_REQUIRE(n < (1ull << 31), "boa_ccl26: volume too large for int32 indices");
+    int* d_count = nullptr;
+    BOA_HIP_TRY(hipMalloc(&d_count, sizeof(int)));
+    BOA_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
+    BOA_HIP_TRY(hipMemsetAsync(dev_sizes, 0, n * sizeof(uint32_t), c->stream));
+    unsigned grid = (unsigned)((n + 255) / 256);
+    KernelTimer t(c, BOA_K_OTHER, 0, (double)n * 14.0);
+    hipLaunchKernelGGL(k_ccl_init, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, dev_roots);
+    hipLaunchKernelGGL(k_ccl_merge, dim3(grid), dim3(256), 0, c->stream, dev_mask, Z, Y, X, dev_roots);
+    hipLaunchKernelGGL(k_ccl_compress, dim3(grid), dim3(256), 0, c->stream, n, dev_roots, dev_sizes, d_count);
+    t.stop();
+    int cnt = 0;
+    hipError_t e = hipMemcpyAsync(&cnt, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_count);
+    BOA_HIP_TRY(e);
+    BOA_HIP_TRY(hipGetLastError());
+    if (host_n_components) *host_n_components = cnt;
+    return BOA_OK;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_best(const unsigned int* __restrict__ sizes, size_t n,
+                                                  unsigned long long* best) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long key = 0;
+    if (i < n && sizes[i]) key = ((unsigned long long)sizes[i] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        unsigned long long o = __shfl_xor(key, m);
+        key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key) atomicMax(best, key);
+}
+
+__global__ __launch_bounds__(256) void k_ccl_apply_largest(const int* __restrict__ roots, size_t n,
+                                                           const unsigned long long* best, unsigned char* seg, int fill) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long b = *best;
+    if (!b) return;
+    const int best_root = (int)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull));
+    const int r = roots[i];
+    if (r >= 0 && r != best_root) seg[i] = (unsigned char)fill;
+}
+
+extern "C" int boa_ccl_filter_largest(boa_ctx* c, const int32_t* dev_roots, const uint32_t* dev_sizes, size_t n,
+                                      uint8_t* dev_seg, int fill_value) {
+    BOA_REQUIRE(c && dev_roots && dev_sizes && dev_seg, "boa_ccl_filter_largest: NULL argument");
+    if (n == 0) return BOA_OK;
+    unsigned long long* d_best = nullptr;
+    BOA_HIP_TRY(hipMalloc(&d_best, sizeof(unsigned long long)));
+    BOA_HIP_TRY(hipMemsetAsync(d_best, 0, sizeof(unsigned long long), c->stream));
+    unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_ccl_best, dim3(grid), dim3(256), 0, c->stream, dev_sizes, n, d_best);
+    hipLaunchKernelGGL(k_ccl_apply_largest, dim3(grid), dim3(256), 0, c->stream, dev_roots, n, d_best, dev_seg,
+                       fill_value);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d_best);
+    BOA_HIP_TRY(e);
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_remove_small(const int* __restrict__ roots, const unsigned int* __restrict__ sizes,
+                                                          size_t n, unsigned int max_size, unsigned char* mask) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = roots[i];
+    if (r >= 0 && sizes[r] <= max_size) mask[i] = 0;
+}
+
+extern "C" int boa_ccl_remove_small(boa_ctx* c, const int32_t* dev_roots, const uint32_t* dev_sizes, size_t n,
+                                    uint32_t max_size, uint8_t* dev_mask_inout) {
+    BOA_REQUIRE(c && dev_roots && dev_sizes && dev_mask_inout, "boa_ccl_remove_small: NULL argument");
+    if (n == 0) return BOA_OK;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_ccl_remove_small, dim3(grid), dim3(256), 0, c->stream, dev_roots, dev_sizes, n, max_size,
+                       dev_mask_inout);
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}

@@ -1,0 +1,210 @@
+// Context, memory, timing and error plumbing of libboa_hip.so.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void boa_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* boa_last_error(void) { return g_err; }
+extern "C" int boa_version(void) { return 100; }
+
+extern "C" int boa_init(int device, void* stream, boa_ctx** out) {
+    BOA_REQUIRE(out != nullptr, "boa_init: out is NULL");
+    int n = 0;
+    BOA_HIP_TRY(hipGetDeviceCount(&n));
+    BOA_REQUIRE(device >= 0 && device < n, "boa_init: device %d not available (%d visible)", device, n);
+    BOA_HIP_TRY(hipSetDevice(device));
+    boa_ctx* c = new boa_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        BOA_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    hipDeviceProp_t p;
+    BOA_HIP_TRY(hipGetDeviceProperties(&p, device));
+    c->cu_count = p.multiProcessorCount;
+    for (int i = 0; i < 8; ++i) {
+        BOA_HIP_TRY(hipEventCreate(&c->t0[i]));
+        BOA_HIP_TRY(hipEventCreate(&c->t1[i]));
+    }
+    *out = c;
+    return BOA_OK;
+}
+
+extern "C" void boa_destroy(boa_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 8; ++i) {
+        hipEventDestroy(c->t0[i]);
+        hipEventDestroy(c->t1[i]);
+    }
+    for (auto& r : c->prof_pending) {
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int boa_device_info(boa_ctx* c, char* name, int name_len, int* cu_count, size_t* total_mem,
+                               size_t* free_mem) {
+    BOA_REQUIRE(c, "ctx is NULL");
+    hipDeviceProp_t p;
+    BOA_HIP_TRY(hipGetDeviceProperties(&p, c->device));
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    size_t f = 0, t = 0;
+    BOA_HIP_TRY(hipMemGetInfo(&f, &t));
+    if (total_mem) *total_mem = t;
+    if (free_mem) *free_mem = f;
+    return BOA_OK;
+}
+
+extern "C" int boa_malloc(boa_ctx* c, size_t bytes, void** dev_out) {
+    BOA_REQUIRE(c && dev_out, "boa_malloc: NULL argument");
+    BOA_HIP_TRY(hipSetDevice(c->device));
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        boa_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return BOA_ENOMEM;
+    }
+    *dev_out = p;
+    return BOA_OK;
+}
+
+extern "C" int boa_free(boa_ctx* c, void* dev) {
+    BOA_REQUIRE(c, "ctx is NULL");
+    if (dev) {
+        BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+        BOA_HIP_TRY(hipFree(dev));
+    }
+    return BOA_OK;
+}
+
+extern "C" int boa_memset(boa_ctx* c, void* dev, int value, size_t bytes) {
+    BOA_REQUIRE(c && dev, "boa_memset: NULL argument");
+    BOA_HIP_TRY(hipMemsetAsync(dev, value, bytes, c->stream));
+    return BOA_OK;
+}
+
+extern "C" int boa_h2d(boa_ctx* c, void* dev_dst, const void* host_src, size_t bytes) {
+    BOA_REQUIRE(c && dev_dst && host_src, "boa_h2d: NULL argument");
+    BOA_HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+    BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+    return BOA_OK;
+}
+
+extern "C" int boa_d2h(boa_ctx* c, void* host_dst, const void* dev_src, size_t bytes) {
+    BOA_REQUIRE(c && host_dst && dev_src, "boa_d2h: NULL argument");
+    BOA_HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+    return BOA_OK;
+}
+
+extern "C" int boa_sync(boa_ctx* c) {
+    BOA_REQUIRE(c, "ctx is NULL");
+    BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+extern "C" int boa_timer_start(boa_ctx* c, int slot) {
+    BOA_REQUIRE(c && slot >= 0 && slot < 8, "boa_timer_start: bad slot");
+    BOA_HIP_TRY(hipEventRecord(c->t0[slot], c->stream));
+    return BOA_OK;
+}
+
+extern "C" int boa_timer_stop(boa_ctx* c, int slot, float* ms_out) {
+    BOA_REQUIRE(c && slot >= 0 && slot < 8 && ms_out, "boa_timer_stop: bad argument");
+    BOA_HIP_TRY(hipEventRecord(c->t1[slot], c->stream));
+    BOA_HIP_TRY(hipEventSynchronize(c->t1[slot]));
+    BOA_HIP_TRY(hipEventElapsedTime(ms_out, c->t0[slot], c->t1[slot]));
+    return BOA_OK;
+}
+
+// ---- per-kernel-class profiling with HIP events on the launch stream --------------------------------
+static hipEvent_t take_event(boa_ctx* c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+KernelTimer::KernelTimer(boa_ctx* c, int kclass, double flops, double bytes) : ctx(c), k(kclass) {
+    if (!c->prof) return;
+    if (c->prof_pending.size() >= 32768) boa_prof_flush(c);
+    e0 = take_event(c);
+    e1 = take_event(c);
+    c->prof_flops[k] += flops;
+    c->prof_bytes[k] += bytes;
+    c->prof_launches[k] += 1;
+    hipEventRecord(e0, c->stream);
+}
+
+void KernelTimer::stop() {
+    if (!e0) return;
+    hipEventRecord(e1, ctx->stream);
+    ctx->prof_pending.push_back({k, e0, e1});
+}
+
+int boa_prof_flush(boa_ctx* c) {
+    for (auto& r : c->prof_pending) {
+        float ms = 0.f;
+        hipEventSynchronize(r.e1);
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) c->prof_ms[r.kclass] += ms;
+        c->ev_pool.push_back(r.e0);
+        c->ev_pool.push_back(r.e1);
+    }
+    c->prof_pending.clear();
+    return BOA_OK;
+}
+
+extern "C" int boa_prof_enable(boa_ctx* c, int on) {
+    BOA_REQUIRE(c, "ctx is NULL");
+    if (!on) boa_prof_flush(c);
+    c->prof = on != 0;
+    return BOA_OK;
+}
+
+extern "C" int boa_prof_reset(boa_ctx* c) {
+    BOA_REQUIRE(c, "ctx is NULL");
+    boa_prof_flush(c);
+    for (int i = 0; i < BOA_K_COUNT; ++i) {
+        c->prof_ms[i] = 0;
+        c->prof_launches[i] = 0;
+        c->prof_flops[i] = 0;
+        c->prof_bytes[i] = 0;
+    }
+    return BOA_OK;
+}
+
+extern "C" int boa_prof_get(boa_ctx* c, int kclass, double* total_ms, long long* launches, double* flops,
+                            double* bytes) {
+    BOA_REQUIRE(c && kclass >= 0 && kclass < BOA_K_COUNT, "boa_prof_get: bad class");
+    boa_prof_flush(c);
+    if (total_ms) *total_ms = c->prof_ms[kclass];
+    if (launches) *launches = c->prof_launches[kclass];
+    if (flops) *flops = c->prof_flops[kclass];
+    if (bytes) *bytes = c->prof_bytes[kclass];
+    return BOA_OK;
+}

@@ -1,0 +1,73 @@
+// Internal helpers shared by the HIP translation units of libboa_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+
+#include "boa_hip.h"
+
+void boa_set_error(const char* fmt, ...);
+
+#define BOA_HIP_TRY(expr)                                                                       \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            boa_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (_e == hipErrorOutOfMemory) ? BOA_ENOMEM : BOA_EHIP;                         \
+        }                                                                                       \
+    } while (0)
+
+#define BOA_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            boa_set_error(__VA_ARGS__);       \
+            return BOA_EINVAL;                \
+        }                                     \
+    } while (0)
+
+#define BOA_TRY(expr)               \
+    do {                            \
+        int _r = (expr);            \
+        if (_r != BOA_OK) return _r; \
+    } while (0)
+
+struct ProfRec {
+    int kclass;
+    hipEvent_t e0, e1;
+};
+
+struct boa_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cu_count = 256;
+    hipEvent_t t0[8] = {}, t1[8] = {};
+    // per-kernel-class event profiling
+    bool prof = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[BOA_K_COUNT] = {};
+    long long prof_launches[BOA_K_COUNT] = {};
+    double prof_flops[BOA_K_COUNT] = {};
+    double prof_bytes[BOA_K_COUNT] = {};
+};
+
+// RAII-less explicit bracket: KernelTimer t(ctx, klass, flops, bytes); <launch>; t.stop();
+struct KernelTimer {
+    boa_ctx* ctx;
+    int k;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    KernelTimer(boa_ctx* c, int kclass, double flops, double bytes);
+    void stop();
+};
+int boa_prof_flush(boa_ctx* ctx);
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------------------------------
+__device__ __forceinline__ float h2f(__half h) { return __half2float(h); }
+__device__ __forceinline__ __half f2h(float f) { return __float2half_rn(f); }
+__device__ __forceinline__ float us2f(unsigned short u) { return __half2float(__ushort_as_half(u)); }
+__device__ __forceinline__ unsigned short f2us(float f) { return __half_as_ushort(__float2half_rn(f)); }

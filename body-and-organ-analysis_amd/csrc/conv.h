@@ -1,0 +1,68 @@
+// Conv-stack kernels of the PlainConvUNet engine (gfx950): launch wrappers shared by net.hip and the test seams.
+#pragma once
+#include "common.h"
+
+// Activation tensors are channels-last fp16: [N][D][H][W][C] (D,H,W = nnU-Net array axes X,Y,Z; W contiguous
+// in space, C contiguous in memory).  A "source" is an activation plus the deferred InstanceNorm+LeakyReLU of
+// its producer: y = lrelu(x * scale[n][c] + shift[n][c]); ss == nullptr means identity (raw tensor).
+struct ActSrc {
+    const __half* data = nullptr;
+    const float* ss = nullptr;  // [N][C][2] (scale, shift)
+    int C = 0;
+};
+
+struct ConvGeom {
+    int N, Di, Hi, Wi, Do, Ho, Wo;
+    int Cout;
+    int k[3], s[3];
+};
+
+// tile configuration chosen on the host (see choose_conv_tile)
+struct ConvTile {
+    int R;           // M-tiles (32 output voxels each) per wave; block = 4 waves = 4R M-tiles
+    int w[3];        // wave M-tile shape, product 32
+    int b[3];        // M-tiles per block along each axis, product 4R
+    int h[3];        // input halo extents
+    int tiles[3];    // block tiles per axis
+    size_t lds_bytes;
+};
+
+bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out);
+
+// packed weight sizes / packers (host side)
+size_t conv_wpk_halves(int Cin_total, int Cout, const int k[3]);
+void pack_conv_weights(const float* w /*[Cout][Cin][k0][k1][k2]*/, int Cin, int Cout, const int k[3], __half* dst);
+size_t convt_wpk_halves(int Cin, int Cout, const int s[3]);
+void pack_convt_weights(const float* w /*[Cin][Cout][s0][s1][s2]*/, int Cin, int Cout, const int s[3], __half* dst);
+
+// Conv3d(k, stride, pad (k-1)/2) + bias over cat(src0, src1) -> out fp16 (pre-norm) and per-block partial
+// sums of (x, x^2) per (n, cout) into partials[N][Cout][2][nblk]; returns nblk through *nblk_out.
+int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const ConvGeom& g, const ConvTile& t,
+                     const __half* wpk, const float* bias, float slope, __half* out, float* partials);
+int conv_nblk(const ConvTile& t);
+
+// First conv: reads tiles straight out of the resident fp32 volume [Cin][V0][V1][V2] (zero outside the volume
+// and outside the tile), fp32 VALU, stride 1.  w: dev fp32 [Cin][taps][Cout].
+int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins,
+                      int N, int Cin, const int P[3], const int k[3], int Cout, const float* w, const float* bias,
+                      __half* out, float* partials, int* nblk_out);
+int conv_first_nblk(const int P[3]);
+
+// InstanceNorm statistics -> (scale, shift) per (n, c):  scale = gamma * rsqrt(var + eps), shift = beta - mean * scale
+int launch_norm_finalize(boa_ctx* ctx, const float* partials, int nblk, int N, int C, double count,
+                         const float* gamma, const float* beta, float eps, float* ss_out);
+
+// ConvTranspose3d with kernel == stride, + bias; input source with deferred norm; out fp16 raw.
+int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], const int s[3], int Cout,
+                      const __half* wpk, const float* bias, float slope, __half* out);
+
+// 1x1x1 head on the last decoder activation.  mode 0: write fp32 logits [C][P0][P1][P2];
+// mode 1: pred * gauss accumulated into fp16 acc/n at `start` (NN/inference/predict_from_raw_data.py:611-614).
+int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const int P[3], int C, const float* w,
+                const float* bias, float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc,
+                uint16_t* nacc, const int PV[3], const int start[3]);
+
+// layout helpers (tests / debug)
+int launch_nchw_to_ndhwc_f16(boa_ctx* ctx, const float* in, int N, int C, size_t vox, __half* out);
+int launch_ndhwc_to_nchw_f32(boa_ctx* ctx, const __half* in, const float* ss, float slope, int N, int C, size_t vox,
+                             float* out);

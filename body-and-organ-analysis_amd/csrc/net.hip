@@ -1,0 +1,463 @@
+// PlainConvUNet on device + the sliding-window tile loop
+// (NN/inference/predict_from_raw_data.py:543,560-631; architecture per NN/utilities/plans_handling/plans_handler.py:59-92).
+#include <string.h>
+
+#include <vector>
+
+#include "conv.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ConvLayer {
+    ConvGeom g{};
+    ConvTile t{};
+    int Cin0 = 0, Cin1 = 0;  // channels of the two concatenated sources (Cin1 = 0: single source)
+    bool first = false;      // stage-0 conv-0: fp32 VALU kernel reading the volume
+    __half* wpk = nullptr;   // MFMA layers
+    float* wfirst = nullptr; // first layer [Cin][taps][Cout]
+    float *bias = nullptr, *gamma = nullptr, *beta = nullptr;
+    __half* out = nullptr;
+    float* partials = nullptr;
+    float* ss = nullptr;
+    int nblk = 0;
+    size_t w_elems = 0;  // fp32 elements of W in the blob
+};
+
+struct UpLayer {
+    int Cin = 0, Cout = 0;
+    int s[3] = {1, 1, 1};
+    int din[3] = {0, 0, 0};
+    __half* wpk = nullptr;
+    float* bias = nullptr;
+    __half* out = nullptr;
+};
+
+}  // namespace
+
+struct boa_net {
+    boa_ctx* ctx = nullptr;
+    boa_net_desc d{};
+    int maxN = 1;
+    std::vector<std::vector<ConvLayer>> enc;  // [stage][conv]
+    std::vector<UpLayer> up;                  // decoder order (deepest first)
+    std::vector<std::vector<ConvLayer>> dec;  // [d][conv]
+    float *head_w = nullptr, *head_b = nullptr;
+    int* dev_origins = nullptr;
+    float* ident_ss = nullptr;
+    std::vector<void*> allocs;
+    int dims[BOA_MAX_STAGES][3];
+};
+
+static int net_alloc(boa_net* net, size_t bytes, void** out) {
+    BOA_TRY(boa_malloc(net->ctx, bytes, out));
+    net->allocs.push_back(*out);
+    return BOA_OK;
+}
+
+static bool desc_ok(const boa_net_desc* d) {
+    if (!d || d->n_stages < 2 || d->n_stages > BOA_MAX_STAGES || d->in_channels < 1 || d->num_classes < 1) return false;
+    for (int s = 0; s < d->n_stages; ++s) {
+        if (d->features[s] <= 0 || d->n_conv_enc[s] < 1) return false;
+        for (int a = 0; a < 3; ++a)
+            if ((d->kernel[s][a] != 1 && d->kernel[s][a] != 3) || d->stride[s][a] < 1 || d->stride[s][a] > 2) return false;
+    }
+    for (int s = 0; s < d->n_stages - 1; ++s)
+        if (d->n_conv_dec[s] < 1) return false;
+    return true;
+}
+
+extern "C" size_t boa_net_weight_count(const boa_net_desc* d) {
+    if (!desc_ok(d)) return 0;
+    size_t n = 0;
+    int cin = d->in_channels;
+    for (int s = 0; s < d->n_stages; ++s) {
+        int taps = d->kernel[s][0] * d->kernel[s][1] * d->kernel[s][2];
+        for (int i = 0; i < d->n_conv_enc[s]; ++i) {
+            n += (size_t)d->features[s] * cin * taps + 3 * (size_t)d->features[s];
+            cin = d->features[s];
+        }
+    }
+    for (int k = 0; k < d->n_stages - 1; ++k) {
+        int sb = d->n_stages - 1 - k;  // stage below
+        int below = d->features[sb], skip = d->features[sb - 1];
+        int st = d->stride[sb][0] * d->stride[sb][1] * d->stride[sb][2];
+        n += (size_t)below * skip * st + skip;
+        int taps = d->kernel[sb - 1][0] * d->kernel[sb - 1][1] * d->kernel[sb - 1][2];
+        int ci = 2 * skip;
+        for (int i = 0; i < d->n_conv_dec[k]; ++i) {
+            n += (size_t)skip * ci * taps + 3 * (size_t)skip;
+            ci = skip;
+        }
+    }
+    n += (size_t)d->num_classes * d->features[0] + d->num_classes;
+    return n;
+}
+
+static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int cin0, int cin1, int cout, const int k[3],
+                      const int s[3], bool first) {
+    L.first = first;
+    L.Cin0 = cin0;
+    L.Cin1 = cin1;
+    L.g.N = N;
+    L.g.Di = din[0]; L.g.Hi = din[1]; L.g.Wi = din[2];
+    L.g.Cout = cout;
+    int dout[3];
+    for (int a = 0; a < 3; ++a) {
+        L.g.k[a] = k[a];
+        L.g.s[a] = s[a];
+        int p = (k[a] - 1) / 2;
+        dout[a] = (din[a] + 2 * p - k[a]) / s[a] + 1;
+    }
+    L.g.Do = dout[0]; L.g.Ho = dout[1]; L.g.Wo = dout[2];
+    const int taps = k[0] * k[1] * k[2];
+    L.w_elems = (size_t)cout * (cin0 + cin1) * taps;
+    if (first) {
+        BOA_REQUIRE(s[0] == 1 && s[1] == 1 && s[2] == 1, "first conv must have stride 1");
+        L.nblk = conv_first_nblk(dout);
+        BOA_TRY(net_alloc(net, L.w_elems * sizeof(float), (void**)&L.wfirst));
+    } else {
+        BOA_REQUIRE((cin0 % 16) == 0 && (cin1 % 16) == 0 && (cout % 32) == 0,
+                    "conv %d+%d -> %d: channel counts must be multiples of 16 (in) / 32 (out)", cin0, cin1, cout);
+        BOA_REQUIRE(choose_conv_tile(L.g, net->ctx->cu_count, &L.t), "no tile configuration fits conv %dx%dx%d", din[0],
+                    din[1], din[2]);
+        L.nblk = conv_nblk(L.t);
+        BOA_TRY(net_alloc(net, conv_wpk_halves(cin0 + cin1, cout, k) * sizeof(__half), (void**)&L.wpk));
+    }
+    BOA_TRY(net_alloc(net, cout * sizeof(float), (void**)&L.bias));
+    BOA_TRY(net_alloc(net, cout * sizeof(float), (void**)&L.gamma));
+    BOA_TRY(net_alloc(net, cout * sizeof(float), (void**)&L.beta));
+    size_t vox = (size_t)dout[0] * dout[1] * dout[2];
+    BOA_TRY(net_alloc(net, (size_t)N * vox * cout * sizeof(__half), (void**)&L.out));
+    BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * L.nblk * sizeof(float), (void**)&L.partials));
+    BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * sizeof(float), (void**)&L.ss));
+    return BOA_OK;
+}
+
+extern "C" int boa_net_load_weights(boa_net* net, const float* w, size_t n_floats) {
+    BOA_REQUIRE(net && w, "boa_net_load_weights: NULL argument");
+    size_t expect = boa_net_weight_count(&net->d);
+    BOA_REQUIRE(n_floats == expect, "weight blob has %zu floats, geometry needs %zu", n_floats, expect);
+    boa_ctx* c = net->ctx;
+    BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+    const float* p = w;
+    std::vector<__half> tmp;
+    auto load_conv = [&](ConvLayer& L) -> int {
+        const int cin = L.Cin0 + L.Cin1, cout = L.g.Cout;
+        const int taps = L.g.k[0] * L.g.k[1] * L.g.k[2];
+        if (L.first) {
+            std::vector<float> wf((size_t)cin * taps * cout);
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < taps; ++t) wf[((size_t)ci * taps + t) * cout + co] = p[((size_t)co * cin + ci) * taps + t];
+            BOA_HIP_TRY(hipMemcpy(L.wfirst, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+            tmp.assign(conv_wpk_halves(cin, cout, L.g.k), __float2half_rn(0.f));
+            pack_conv_weights(p, cin, cout, L.g.k, tmp.data());
+            BOA_HIP_TRY(hipMemcpy(L.wpk, tmp.data(), tmp.size() * sizeof(__half), hipMemcpyHostToDevice));
+        }
+        p += L.w_elems;
+        BOA_HIP_TRY(hipMemcpy(L.bias, p, cout * sizeof(float), hipMemcpyHostToDevice));
+        p += cout;
+        BOA_HIP_TRY(hipMemcpy(L.gamma, p, cout * sizeof(float), hipMemcpyHostToDevice));
+        p += cout;
+        BOA_HIP_TRY(hipMemcpy(L.beta, p, cout * sizeof(float), hipMemcpyHostToDevice));
+        p += cout;
+        return BOA_OK;
+    };
+    for (auto& st : net->enc)
+        for (auto& L : st) BOA_TRY(load_conv(L));
+    for (size_t k = 0; k < net->up.size(); ++k) {
+        UpLayer& U = net->up[k];
+        tmp.assign(convt_wpk_halves(U.Cin, U.Cout, U.s), __float2half_rn(0.f));
+        pack_convt_weights(p, U.Cin, U.Cout, U.s, tmp.data());
+        BOA_HIP_TRY(hipMemcpy(U.wpk, tmp.data(), tmp.size() * sizeof(__half), hipMemcpyHostToDevice));
+        p += (size_t)U.Cin * U.Cout * U.s[0] * U.s[1] * U.s[2];
+        BOA_HIP_TRY(hipMemcpy(U.bias, p, U.Cout * sizeof(float), hipMemcpyHostToDevice));
+        p += U.Cout;
+        for (auto& L : net->dec[k]) BOA_TRY(load_conv(L));
+    }
+    size_t hw = (size_t)net->d.num_classes * net->d.features[0];
+    BOA_HIP_TRY(hipMemcpy(net->head_w, p, hw * sizeof(float), hipMemcpyHostToDevice));
+    p += hw;
+    BOA_HIP_TRY(hipMemcpy(net->head_b, p, net->d.num_classes * sizeof(float), hipMemcpyHostToDevice));
+    p += net->d.num_classes;
+    BOA_REQUIRE((size_t)(p - w) == expect, "internal: weight cursor mismatch");
+    return BOA_OK;
+}
+
+extern "C" void boa_net_destroy(boa_net* net) {
+    if (!net) return;
+    hipStreamSynchronize(net->ctx->stream);
+    for (void* a : net->allocs) hipFree(a);
+    delete net;
+}
+
+extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const float* host_weights, size_t n_floats,
+                              int max_batch, int precision, boa_net** out) {
+    BOA_REQUIRE(ctx && desc && out, "boa_net_create: NULL argument");
+    BOA_REQUIRE(desc_ok(desc), "boa_net_create: invalid network geometry");
+    BOA_REQUIRE(precision == 0, "boa_net_create: precision %d not supported (0 = f16 MFMA / fp32 accumulate)", precision);
+    BOA_REQUIRE(max_batch >= 1 && max_batch <= 64, "boa_net_create: max_batch %d out of range", max_batch);
+    BOA_HIP_TRY(hipSetDevice(ctx->device));
+    boa_net* net = new boa_net();
+    net->ctx = ctx;
+    net->d = *desc;
+    if (net->d.norm_eps <= 0.f) net->d.norm_eps = 1e-5f;
+    if (net->d.lrelu_slope == 0.f) net->d.lrelu_slope = 0.01f;
+    net->maxN = max_batch;
+    const boa_net_desc& d = net->d;
+    int rc = BOA_OK;
+    auto fail = [&](int r) {
+        boa_net_destroy(net);
+        return r;
+    };
+    // encoder
+    int din[3] = {d.patch[0], d.patch[1], d.patch[2]};
+    int cin = d.in_channels;
+    net->enc.resize(d.n_stages);
+    for (int s = 0; s < d.n_stages; ++s) {
+        net->enc[s].resize(d.n_conv_enc[s]);
+        for (int i = 0; i < d.n_conv_enc[s]; ++i) {
+            int one[3] = {1, 1, 1};
+            const int* st = (i == 0) ? d.stride[s] : one;
+            bool first = (s == 0 && i == 0);
+            rc = setup_conv(net, net->enc[s][i], max_batch, din, cin, 0, d.features[s], d.kernel[s], st, first);
+            if (rc) return fail(rc);
+            const ConvGeom& g = net->enc[s][i].g;
+            din[0] = g.Do; din[1] = g.Ho; din[2] = g.Wo;
+            cin = d.features[s];
+        }
+        net->dims[s][0] = din[0]; net->dims[s][1] = din[1]; net->dims[s][2] = din[2];
+    }
+    // decoder
+    net->up.resize(d.n_stages - 1);
+    net->dec.resize(d.n_stages - 1);
+    for (int k = 0; k < d.n_stages - 1; ++k) {
+        int sb = d.n_stages - 1 - k;
+        UpLayer& U = net->up[k];
+        U.Cin = d.features[sb];
+        U.Cout = d.features[sb - 1];
+        for (int a = 0; a < 3; ++a) {
+            U.s[a] = d.stride[sb][a];
+            U.din[a] = net->dims[sb][a];
+        }
+        int dup[3] = {U.din[0] * U.s[0], U.din[1] * U.s[1], U.din[2] * U.s[2]};
+        for (int a = 0; a < 3; ++a)
+            if (dup[a] != net->dims[sb - 1][a]) {
+                boa_set_error("decoder %d: upsampled dim %d (%d) != skip dim (%d); patch not divisible by strides", k, a,
+                              dup[a], net->dims[sb - 1][a]);
+                return fail(BOA_EINVAL);
+            }
+        if (U.Cin % 16 || U.Cout % 32) {
+            boa_set_error("transposed conv %d -> %d: unsupported channel counts", U.Cin, U.Cout);
+            return fail(BOA_EINVAL);
+        }
+        if ((rc = net_alloc(net, convt_wpk_halves(U.Cin, U.Cout, U.s) * sizeof(__half), (void**)&U.wpk))) return fail(rc);
+        if ((rc = net_alloc(net, U.Cout * sizeof(float), (void**)&U.bias))) return fail(rc);
+        size_t vox = (size_t)dup[0] * dup[1] * dup[2];
+        if ((rc = net_alloc(net, (size_t)max_batch * vox * U.Cout * sizeof(__half), (void**)&U.out))) return fail(rc);
+        net->dec[k].resize(d.n_conv_dec[k]);
+        int one[3] = {1, 1, 1};
+        for (int i = 0; i < d.n_conv_dec[k]; ++i) {
+            int c0 = U.Cout, c1 = (i == 0) ? U.Cout : 0;
+            rc = setup_conv(net, net->dec[k][i], max_batch, dup, c0, c1, U.Cout, d.kernel[sb - 1], one, false);
+            if (rc) return fail(rc);
+        }
+    }
+    if ((rc = net_alloc(net, (size_t)d.num_classes * d.features[0] * sizeof(float), (void**)&net->head_w))) return fail(rc);
+    if ((rc = net_alloc(net, d.num_classes * sizeof(float), (void**)&net->head_b))) return fail(rc);
+    if ((rc = net_alloc(net, (size_t)max_batch * 3 * sizeof(int), (void**)&net->dev_origins))) return fail(rc);
+    if (host_weights) {
+        rc = boa_net_load_weights(net, host_weights, n_floats);
+        if (rc) return fail(rc);
+    }
+    *out = net;
+    return BOA_OK;
+}
+
+// run the conv stack for N tiles; leaves the last decoder activation (+ its ss) in net->dec.back().back()
+static int net_forward_stack(boa_net* net, const float* volume, const int V[3], const int vol_off[3],
+                             const int* host_origins, int N) {
+    boa_ctx* c = net->ctx;
+    const boa_net_desc& d = net->d;
+    BOA_REQUIRE(N >= 1 && N <= net->maxN, "forward: batch %d exceeds max_batch %d", N, net->maxN);
+    BOA_HIP_TRY(hipMemcpyAsync(net->dev_origins, host_origins, (size_t)N * 3 * sizeof(int), hipMemcpyHostToDevice,
+                               c->stream));
+    auto run_conv = [&](ConvLayer& L, const ActSrc& a, const ActSrc& b) -> int {
+        ConvGeom g = L.g;
+        g.N = N;
+        if (L.first) {
+            int nblk = 0;
+            BOA_TRY(launch_conv_first(c, volume, V, vol_off, net->dev_origins, N, d.in_channels, d.patch, L.g.k, L.g.Cout,
+                                      L.wfirst, L.bias, L.out, L.partials, &nblk));
+        } else {
+            BOA_TRY(launch_conv_mfma(c, a, b, g, L.t, L.wpk, L.bias, d.lrelu_slope, L.out, L.partials));
+        }
+        double count = (double)g.Do * g.Ho * g.Wo;
+        BOA_TRY(launch_norm_finalize(c, L.partials, L.nblk, N, g.Cout, count, L.gamma, L.beta, d.norm_eps, L.ss));
+        return BOA_OK;
+    };
+    ActSrc cur, none;
+    for (int s = 0; s < d.n_stages; ++s)
+        for (size_t i = 0; i < net->enc[s].size(); ++i) {
+            ConvLayer& L = net->enc[s][i];
+            BOA_TRY(run_conv(L, cur, none));
+            cur.data = L.out;
+            cur.ss = L.ss;
+            cur.C = L.g.Cout;
+        }
+    for (int k = 0; k < d.n_stages - 1; ++k) {
+        int sb = d.n_stages - 1 - k;
+        UpLayer& U = net->up[k];
+        BOA_TRY(launch_convt_mfma(c, cur, N, U.din, U.s, U.Cout, U.wpk, U.bias, d.lrelu_slope, U.out));
+        ConvLayer& SK = net->enc[sb - 1].back();
+        ActSrc upsrc, skip;
+        upsrc.data = U.out; upsrc.ss = nullptr; upsrc.C = U.Cout;
+        skip.data = SK.out; skip.ss = SK.ss; skip.C = SK.g.Cout;
+        for (size_t i = 0; i < net->dec[k].size(); ++i) {
+            ConvLayer& L = net->dec[k][i];
+            if (i == 0)
+                BOA_TRY(run_conv(L, upsrc, skip));
+            else
+                BOA_TRY(run_conv(L, cur, none));
+            cur.data = L.out;
+            cur.ss = L.ss;
+            cur.C = L.g.Cout;
+        }
+    }
+    return BOA_OK;
+}
+
+extern "C" int boa_net_forward(boa_net* net, const float* dev_volume, const int V[3], const int* host_origins,
+                               int n_tiles, float* dev_logits_out) {
+    BOA_REQUIRE(net && dev_volume && V && host_origins && dev_logits_out, "boa_net_forward: NULL argument");
+    const boa_net_desc& d = net->d;
+    const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2];
+    const int zero[3] = {0, 0, 0};
+    for (int t0 = 0; t0 < n_tiles; t0 += net->maxN) {
+        int nb = std::min(net->maxN, n_tiles - t0);
+        BOA_TRY(net_forward_stack(net, dev_volume, V, zero, host_origins + (size_t)t0 * 3, nb));
+        ConvLayer& last = net->dec.back().back();
+        for (int i = 0; i < nb; ++i) {
+            BOA_TRY(launch_head(net->ctx, last.out + (size_t)i * pv * d.features[0], last.ss + (size_t)i * d.features[0] * 2,
+                                d.features[0], d.patch, d.num_classes, net->head_w, net->head_b, d.lrelu_slope,
+                                dev_logits_out + (size_t)(t0 + i) * d.num_classes * pv, nullptr, nullptr, nullptr,
+                                nullptr, nullptr));
+        }
+    }
+    return BOA_OK;
+}
+
+extern "C" int boa_net_predict_sliding_window(boa_net* net, const float* dev_volume, const int V[3], const int PV[3],
+                                              const int* vol_off, const int* host_origins, int n_tiles,
+                                              const uint16_t* dev_gauss, uint16_t* dev_acc, uint16_t* dev_n) {
+    BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_acc && dev_n,
+                "boa_net_predict_sliding_window: NULL argument");
+    const boa_net_desc& d = net->d;
+    const int zero[3] = {0, 0, 0};
+    const int* off = vol_off ? vol_off : zero;
+    for (int a = 0; a < 3; ++a)
+        BOA_REQUIRE(PV[a] >= d.patch[a] && off[a] >= 0 && off[a] + V[a] <= PV[a],
+                    "sliding window: padded dim %d (%d) must cover patch (%d) and volume (%d at %d)", a, PV[a],
+                    d.patch[a], V[a], off[a]);
+    const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2];
+    for (int t0 = 0; t0 < n_tiles; t0 += net->maxN) {
+        int nb = std::min(net->maxN, n_tiles - t0);
+        BOA_TRY(net_forward_stack(net, dev_volume, V, off, host_origins + (size_t)t0 * 3, nb));
+        ConvLayer& last = net->dec.back().back();
+        for (int i = 0; i < nb; ++i) {  // canonical order: one launch per tile, serialised on the stream
+            const int* st = host_origins + (size_t)(t0 + i) * 3;
+            BOA_TRY(launch_head(net->ctx, last.out + (size_t)i * pv * d.features[0], last.ss + (size_t)i * d.features[0] * 2,
+                                d.features[0], d.patch, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr,
+                                dev_gauss, dev_acc, dev_n, PV, st));
+        }
+    }
+    return BOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// unit-test seams
+extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, const int dims[3],
+                                   const float* host_w, const float* host_b, const float* host_gamma,
+                                   const float* host_beta, int Cout, const int kernel[3], const int stride[3],
+                                   int with_norm_act, int impl, float* dev_out) {
+    BOA_REQUIRE(ctx && dev_in && dims && host_w && host_b && kernel && stride && dev_out, "conv test: NULL argument");
+    BOA_REQUIRE(impl == 0, "conv test: impl %d not available", impl);
+    ConvGeom g;
+    g.N = N; g.Di = dims[0]; g.Hi = dims[1]; g.Wi = dims[2]; g.Cout = Cout;
+    int dout[3];
+    for (int a = 0; a < 3; ++a) {
+        g.k[a] = kernel[a];
+        g.s[a] = stride[a];
+        dout[a] = (dims[a] + 2 * ((kernel[a] - 1) / 2) - kernel[a]) / stride[a] + 1;
+    }
+    g.Do = dout[0]; g.Ho = dout[1]; g.Wo = dout[2];
+    ConvTile t;
+    BOA_REQUIRE(choose_conv_tile(g, ctx->cu_count, &t), "conv test: no tile configuration");
+    size_t vin = (size_t)dims[0] * dims[1] * dims[2], vout = (size_t)dout[0] * dout[1] * dout[2];
+    __half *in16 = nullptr, *out16 = nullptr, *wpk = nullptr;
+    float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *partials = nullptr, *ss = nullptr;
+    int nblk = conv_nblk(t);
+    std::vector<__half> tmp(conv_wpk_halves(Cin, Cout, kernel));
+    pack_conv_weights(host_w, Cin, Cout, kernel, tmp.data());
+    std::vector<float> ones(Cout, 1.f), zeros(Cout, 0.f);
+    int rc = BOA_OK;
+#define T_(x) do { if (rc == BOA_OK) rc = (x); } while (0)
+    T_(boa_malloc(ctx, (size_t)N * vin * Cin * 2, (void**)&in16));
+    T_(boa_malloc(ctx, (size_t)N * vout * Cout * 2, (void**)&out16));
+    T_(boa_malloc(ctx, tmp.size() * 2, (void**)&wpk));
+    T_(boa_malloc(ctx, Cout * 4, (void**)&bias));
+    T_(boa_malloc(ctx, Cout * 4, (void**)&gamma));
+    T_(boa_malloc(ctx, Cout * 4, (void**)&beta));
+    T_(boa_malloc(ctx, (size_t)N * Cout * 2 * nblk * 4, (void**)&partials));
+    T_(boa_malloc(ctx, (size_t)N * Cout * 2 * 4, (void**)&ss));
+    T_(boa_h2d(ctx, wpk, tmp.data(), tmp.size() * 2));
+    T_(boa_h2d(ctx, bias, host_b, Cout * 4));
+    T_(boa_h2d(ctx, gamma, host_gamma ? host_gamma : ones.data(), Cout * 4));
+    T_(boa_h2d(ctx, beta, host_beta ? host_beta : zeros.data(), Cout * 4));
+    T_(launch_nchw_to_ndhwc_f16(ctx, dev_in, N, Cin, vin, in16));
+    ActSrc a, none;
+    a.data = in16; a.ss = nullptr; a.C = Cin;
+    T_(launch_conv_mfma(ctx, a, none, g, t, wpk, bias, 0.01f, out16, partials));
+    T_(launch_norm_finalize(ctx, partials, nblk, N, Cout, (double)vout, gamma, beta, 1e-5f, ss));
+    T_(launch_ndhwc_to_nchw_f32(ctx, out16, with_norm_act ? ss : nullptr, 0.01f, N, Cout, vout, dev_out));
+    if (rc == BOA_OK) rc = boa_sync(ctx);
+#undef T_
+    boa_free(ctx, in16); boa_free(ctx, out16); boa_free(ctx, wpk); boa_free(ctx, bias); boa_free(ctx, gamma);
+    boa_free(ctx, beta); boa_free(ctx, partials); boa_free(ctx, ss);
+    return rc;
+}
+
+extern "C" int boa_convtranspose_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, const int dims[3],
+                                      const float* host_w, const float* host_b, int Cout, const int stride[3],
+                                      float* dev_out) {
+    BOA_REQUIRE(ctx && dev_in && dims && host_w && host_b && stride && dev_out, "convT test: NULL argument");
+    size_t vin = (size_t)dims[0] * dims[1] * dims[2];
+    size_t vout = vin * stride[0] * stride[1] * stride[2];
+    __half *in16 = nullptr, *out16 = nullptr, *wpk = nullptr;
+    float* bias = nullptr;
+    std::vector<__half> tmp(convt_wpk_halves(Cin, Cout, stride));
+    pack_convt_weights(host_w, Cin, Cout, stride, tmp.data());
+    int rc = BOA_OK;
+#define T_(x) do { if (rc == BOA_OK) rc = (x); } while (0)
+    T_(boa_malloc(ctx, (size_t)N * vin * Cin * 2, (void**)&in16));
+    T_(boa_malloc(ctx, (size_t)N * vout * Cout * 2, (void**)&out16));
+    T_(boa_malloc(ctx, tmp.size() * 2, (void**)&wpk));
+    T_(boa_malloc(ctx, Cout * 4, (void**)&bias));
+    T_(boa_h2d(ctx, wpk, tmp.data(), tmp.size() * 2));
+    T_(boa_h2d(ctx, bias, host_b, Cout * 4));
+    T_(launch_nchw_to_ndhwc_f16(ctx, dev_in, N, Cin, vin, in16));
+    ActSrc a;
+    a.data = in16; a.ss = nullptr; a.C = Cin;
+    T_(launch_convt_mfma(ctx, a, N, dims, stride, Cout, wpk, bias, 0.01f, out16));
+    T_(launch_ndhwc_to_nchw_f32(ctx, out16, nullptr, 0.01f, N, Cout, vout, dev_out));
+    if (rc == BOA_OK) rc = boa_sync(ctx);
+#undef T_
+    boa_free(ctx, in16); boa_free(ctx, out16); boa_free(ctx, wpk); boa_free(ctx, bias);
+    return rc;
+}

@@ -1,0 +1,229 @@
+/*
+ * boa_hip.h -- C ABI of libboa_hip.so: the MI355X (gfx950) engine for the BOA hot path.
+ *
+ * The reference (UMEssen/Body-and-Organ-Analysis v1.0.1) is 100 % Python and has NO FFI / plugin interface
+ * for this path: the boundary it exposes is the Python function surface of
+ * body_organ_analysis/compute/ and of the vendored nnU-Net / TotalSegmentator / body_composition_analysis
+ * packages.  This header is therefore the binding a maintainer would add underneath those functions (ctypes
+ * stubs are shown in INTEGRATION.md).  Every entry point cites the reference code it replaces
+ * (paths relative to the reference root; NN = body_organ_analysis/_external/nnunetv2,
+ * TS = .../totalsegmentator, BCA = .../body_composition_analysis, BOA = body_organ_analysis).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, ints; no torch / C++ types.  All functions return 0 on success, a negative
+ *     BOA_E* code otherwise; boa_last_error() returns a thread-local message for the last failure.
+ *   - "dev" pointers are HIP device pointers (from boa_malloc, or any hipMalloc / torch data_ptr() in the
+ *     same process); "host" pointers are caller-owned and only borrowed for the duration of the call.
+ *   - volumes use the nnU-Net array order [X][Y][Z] with Z contiguous (NN/imageio/nibabel_reader_writer.py:51-56)
+ *     for the inference path and SimpleITK order [z][y][x] with x contiguous for the measurement path
+ *     (BOA/compute/measurements.py:257-258); both are "3 dims, last contiguous" for the kernels.
+ *   - all launches go to the context's stream; calls are asynchronous unless documented otherwise.
+ *   - fp16 values are IEEE binary16 bit patterns carried as uint16_t.
+ */
+#ifndef BOA_HIP_H
+#define BOA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BOA_OK 0
+#define BOA_EINVAL (-1)   /* bad argument / unsupported geometry  (reference: ValueError / AssertionError) */
+#define BOA_EHIP (-2)     /* HIP runtime error                     (reference: RuntimeError)              */
+#define BOA_ENOMEM (-3)   /* device allocation failed              (reference: OOM -> CPU retry, predict_from_raw_data.py:663-672) */
+#define BOA_EINF (-4)     /* inf in normalised logits              (reference: RuntimeError, predict_from_raw_data.py:622-625)     */
+
+typedef struct boa_ctx boa_ctx;
+typedef struct boa_net boa_net;
+
+/* ------------------------------------------------------------------ context / memory / timing ------- */
+const char* boa_last_error(void);
+int boa_version(void);
+/* One context per GPU (one process per GPU).  stream == NULL -> the context creates its own stream,
+ * otherwise it borrows the given hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int boa_init(int device, void* stream, boa_ctx** out);
+void boa_destroy(boa_ctx* ctx);
+int boa_device_info(boa_ctx* ctx, char* name, int name_len, int* cu_count, size_t* total_mem, size_t* free_mem);
+int boa_malloc(boa_ctx* ctx, size_t bytes, void** dev_out);
+int boa_free(boa_ctx* ctx, void* dev);
+int boa_memset(boa_ctx* ctx, void* dev, int value, size_t bytes);
+int boa_h2d(boa_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);   /* synchronous */
+int boa_d2h(boa_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);   /* synchronous */
+int boa_sync(boa_ctx* ctx);
+/* HIP-event timing on the context stream: ms between the two marks (boa_timer_stop synchronises). */
+int boa_timer_start(boa_ctx* ctx, int slot);
+int boa_timer_stop(boa_ctx* ctx, int slot, float* ms_out);
+/* Per-kernel-class accumulated time, measured with HIP events around every launch of that class while
+ * profiling is enabled (bench.py uses this for `roofline.achieved`).  Classes: see BOA_K_*. */
+#define BOA_K_CONV_MFMA 0
+#define BOA_K_CONV_FIRST 1
+#define BOA_K_CONVT 2
+#define BOA_K_NORM_FINALIZE 3
+#define BOA_K_HEAD_ACCUM 4
+#define BOA_K_ARGMAX 5
+#define BOA_K_OTHER 6
+#define BOA_K_COUNT 7
+int boa_prof_enable(boa_ctx* ctx, int on);
+int boa_prof_reset(boa_ctx* ctx);
+int boa_prof_get(boa_ctx* ctx, int kclass, double* total_ms, long long* launches, double* flops, double* bytes);
+
+/* ------------------------------------------------------------------ sliding-window arithmetic seams -- */
+/* CTNormalization.run (NN/preprocessing/normalization/default_normalization_schemes.py:53-67):
+ * out = ((float)clip(in, lo, hi) - mean) / max(std, 1e-8) in fp32.  in_dtype: 0 = int16, 1 = float32. */
+int boa_ct_normalize(boa_ctx* ctx, const void* dev_in, int in_dtype, float* dev_out, size_t n,
+                     float mean, float std, float lo, float hi);
+
+/* One iteration of the tile loop, NN/inference/predict_from_raw_data.py:611-614, given the tile's logits:
+ *   pred *= gauss (fp32*fp16->fp32); acc[:, sl] += pred (fp16 RTNE); n[sl] += gauss (fp16 RTNE).
+ * pred:  dev fp32 [C][P0][P1][P2]; gauss: dev fp16 [P0][P1][P2] or NULL (use_gaussian=False: weight 1);
+ * acc:   dev fp16 [C][V0][V1][V2]; n: dev fp16 [V0][V1][V2]; start: tile origin in the volume. */
+int boa_accumulate_tile(boa_ctx* ctx, const float* dev_pred, const uint16_t* dev_gauss, uint16_t* dev_acc,
+                        uint16_t* dev_n, int C, const int P[3], const int V[3], const int start[3]);
+
+/* torch.div(logits, n, out=logits) + inf check (predict_from_raw_data.py:620-625), fold accumulation
+ * (`prediction += ...`, :494-500), `/= n_folds`, numpy argmax(0) on fp16 with first-max / NaN-is-max semantics
+ * (NN/utilities/label_handling/label_handling.py:175-178) and the TotalSegmentator part->global remap
+ * `seg_combined[seg == jdx] = class_map_inv[name]` (TS/nnunet.py:553-556), fused in one pass over the volume.
+ *
+ *   acc, n      dev fp16 accumulators of THIS fold/model (acc is overwritten with acc/n when write_logits != 0)
+ *   fold_sum    dev fp16 [C][V] running fold sum, or NULL.  When non-NULL: fold_mode 0 = store (first fold),
+ *               1 = add (fp16 + fp16 -> fp16), and when n_folds_final > 0 the sum is divided by n_folds_final
+ *               (fp16) before the argmax; the argmax is skipped when n_folds_final == 0 (more folds to come).
+ *   lut         host uint8[256] mapping local argmax index -> output label (NULL = identity)
+ *   merge       0: labels_out[v] = lut[argmax];  1: labels_out[v] = lut[argmax] only where argmax != 0
+ *               (later parts overwrite earlier ones, background never overwrites)
+ *   crop_off/crop_dims: revert pad_nd_image (predict_from_raw_data.py:657,679): labels_out is
+ *               [crop_dims] and voxel (i,j,k) comes from padded voxel (i+off0, j+off1, k+off2); NULL = no crop.
+ *   inf_flag    dev int32, set to 1 if any normalised logit is +-inf (caller raises, BOA_EINF semantics).
+ */
+int boa_finalize_labels(boa_ctx* ctx, uint16_t* dev_acc, const uint16_t* dev_n, int C, const int V[3],
+                        uint16_t* dev_fold_sum, int fold_mode, int n_folds_final, int write_logits,
+                        const uint8_t* host_lut, int merge, uint8_t* dev_labels_out,
+                        const int* crop_off, const int* crop_dims, int* dev_inf_flag);
+
+/* ------------------------------------------------------------------ network (PlainConvUNet) ---------- */
+/* Geometry of dynamic_network_architectures PlainConvUNet as the reference instantiates it from plans.json
+ * (NN/utilities/plans_handling/plans_handler.py:59-92; NN/utilities/get_network_from_plans.py:34-38):
+ * encoder stages of n_conv x [Conv3d(k, stride on first conv, pad (k-1)/2, bias) -> InstanceNorm3d(eps 1e-5,
+ * affine) -> LeakyReLU(0.01)], decoder stages of ConvTranspose3d(k = s = stride, bias) -> cat(up, skip) ->
+ * n_conv blocks, final 1x1x1 Conv3d head (deep supervision off, predict_from_raw_data.py:110). */
+#define BOA_MAX_STAGES 8
+typedef struct {
+    int n_stages;
+    int in_channels;
+    int num_classes;
+    int features[BOA_MAX_STAGES];
+    int kernel[BOA_MAX_STAGES][3];
+    int stride[BOA_MAX_STAGES][3];
+    int n_conv_enc[BOA_MAX_STAGES];
+    int n_conv_dec[BOA_MAX_STAGES]; /* n_stages - 1 entries, decoder order (deepest first) */
+    int patch[3];
+    float norm_eps;
+    float lrelu_slope;
+} boa_net_desc;
+
+/* weights: host fp32 blob, tensors concatenated in this order, PyTorch memory layout:
+ *   for each encoder stage s, conv i:  W[Cout][Cin][k0][k1][k2], b[Cout], gamma[Cout], beta[Cout]
+ *   for each decoder stage d (deepest first): Wt[Cin][Cout][s0][s1][s2], bt[Cout], then for conv i: W, b, gamma, beta
+ *   head: W[num_classes][features[0]], b[num_classes]
+ * (state-dict keys encoder.stages.S.0.convs.I.{conv,norm}.*, decoder.transpconvs.D.*, decoder.stages.D.convs.I.*,
+ *  decoder.seg_layers.<last>.*).  precision: 0 = fp16 storage + f16 MFMA / fp32 accumulate. */
+int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const float* host_weights, size_t n_floats,
+                   int max_batch, int precision, boa_net** out);
+void boa_net_destroy(boa_net* net);
+size_t boa_net_weight_count(const boa_net_desc* desc); /* expected n_floats, 0 on invalid desc */
+/* swap weights (next fold), NN/inference/predict_from_raw_data.py:486-489 `load_state_dict(params)` */
+int boa_net_load_weights(boa_net* net, const float* host_weights, size_t n_floats);
+
+/* network(x) for a batch of tiles gathered from a resident volume
+ * (replaces `self.network(workon)` predict_from_raw_data.py:543 + producer thread :568-571):
+ *   volume   dev fp32 [Cin][V0][V1][V2] (already normalised); tile voxels outside the volume read as 0
+ *            (pad_nd_image) -- origins may be negative / overhang for volumes smaller than the patch.
+ *   origins  host int[n_tiles][3]
+ *   logits   dev fp32 [n_tiles][num_classes][P0][P1][P2]  (PyTorch NCDHW)  */
+int boa_net_forward(boa_net* net, const float* dev_volume, const int V[3], const int* host_origins,
+                    int n_tiles, float* dev_logits_out);
+
+/* Whole `_internal_predict_sliding_window_return_logits` loop (predict_from_raw_data.py:560-631) for one
+ * fold: for every tile in the given (canonical x->y->z) order: forward, head, *gauss, fp16 accumulate.
+ * acc/n must be zeroed by the caller (boa_memset).  vol_off: position of the real volume inside the padded
+ * accumulator grid (pad_nd_image `below`), NULL = {0,0,0}.  Tiles are processed in batches of <= max_batch
+ * through the conv stack; accumulation is applied strictly in the given order.
+ *   PV  padded accumulator dims (>= patch), V real volume dims. */
+int boa_net_predict_sliding_window(boa_net* net, const float* dev_volume, const int V[3], const int PV[3],
+                                   const int* vol_off, const int* host_origins, int n_tiles,
+                                   const uint16_t* dev_gauss, uint16_t* dev_acc, uint16_t* dev_n);
+
+/* Debug / unit-test seam: run ONE conv block on device tensors in PyTorch layout.
+ *   in  dev fp32 [N][Cin][D][H][W], w/b/gamma/beta host fp32; out dev fp32 [N][Cout][Do][Ho][Wo] =
+ *   LeakyReLU(InstanceNorm(Conv3d(in))) when with_norm_act != 0, else the raw convolution (+bias).
+ * impl: 0 = MFMA implicit-GEMM kernel, 1 = naive direct kernel (on-device cross-check). */
+int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, const int dims[3],
+                        const float* host_w, const float* host_b, const float* host_gamma, const float* host_beta,
+                        int Cout, const int kernel[3], const int stride[3], int with_norm_act, int impl,
+                        float* dev_out); /* impl must be 0 */
+int boa_convtranspose_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, const int dims[3],
+                           const float* host_w, const float* host_b, int Cout, const int stride[3], float* dev_out);
+
+/* ------------------------------------------------------------------ body-composition / HU aggregation - */
+/* subclassify_tissues (BCA/tissue/subclassification.py:38-53, rules BCA/tissue/definition.py:6-30) fused with
+ * the slice-wise voxel counts of Builder.prepare (BCA/report/builder.py:403-444) and the per-slice HU sums that
+ * `np.mean(image[tissue_mask])` (builder.py:284-305) needs.
+ *   ct int16 [Z][Y][X], regions uint8, parts uint8 (may be NULL -> no torso counts), tissues_out uint8 (may be NULL)
+ *   counts  dev uint32 [Z][2][8]   (index 0 unused; [0] = all voxels, [1] = body_parts == TORSO(1))
+ *   hu_sums dev int64  [Z][2][8]
+ * counts/hu_sums are overwritten. */
+int boa_tissue_aggregate(boa_ctx* ctx, const int16_t* dev_ct, const uint8_t* dev_regions, const uint8_t* dev_parts,
+                         uint8_t* dev_tissues_out, int Z, int Y, int X, uint32_t* dev_counts, int64_t* dev_hu_sums);
+
+/* Per-slice presence of each label value (np.where(mask.any(axis=(1,2))) in builder.py:56-100,170-199 and
+ * BCA/commands.py:24-45): present[z][label] = 1 if any voxel of slice z has that label. dev uint8 [Z][256]. */
+int boa_slice_label_presence(boa_ctx* ctx, const uint8_t* dev_labels, int Z, int Y, int X, uint8_t* dev_present);
+
+/* One pass replacing the ~125 full-volume passes of metrics_for_each_region (BOA/compute/measurements.py:74-123,
+ * 203-241): histogram of HU per label.  hist dev uint32 [256][nbins], bin = clamp(hu - hu_min, 0, nbins-1);
+ * mask (optional dev uint8, same shape): only voxels with mask != 0 are counted (eroded / fat-window masks).
+ * hist is overwritten.  Exact order statistics (median, percentiles), mean, std, min, max follow on the host
+ * from integer counts. */
+int boa_label_hu_histogram(boa_ctx* ctx, const int16_t* dev_ct, const uint8_t* dev_labels, const uint8_t* dev_mask,
+                           size_t n_voxels, int hu_min, int nbins, uint32_t* dev_hist);
+
+/* mask_out = (lut[labels] != 0) && (hu_lo <= ct <= hu_hi  [in_range] | ct < hu_lo || ct > hu_hi [!in_range]);
+ * get_region_minus_fat / compute_lung_measurement fat masks (BOA/compute/measurements.py:29-39,126-148).
+ * lut: host uint8[256]; mode 0 = label only, 1 = inside [lo,hi], 2 = outside [lo,hi]. */
+int boa_label_hu_mask(boa_ctx* ctx, const int16_t* dev_ct, const uint8_t* dev_labels, const uint8_t* host_lut,
+                      int mode, int hu_lo, int hu_hi, size_t n_voxels, uint8_t* dev_mask_out);
+
+/* erode_region (BOA/compute/measurements.py:61-71): binary erosion with a k^3 ones footprint whose anchor is
+ * the centre of the end-padded (k+1)^3 footprint for even k; voxels outside the volume count as set.
+ * Separable min filter, three passes. tmp: dev uint8 scratch of the same size. */
+int boa_binary_erode(boa_ctx* ctx, const uint8_t* dev_mask, uint8_t* dev_out, uint8_t* dev_tmp, int Z, int Y, int X,
+                     int kernel_value);
+
+/* Connected components, 26-connectivity (skimage.measure.label default for 3-D inputs,
+ * BCA/body_regions/postprocess.py:9; remove_small_objects(connectivity=3), BCA/body_parts/postprocess.py:43-48)
+ * of `mask != 0` by atomic union-find on the device.
+ *   roots dev int32 [n]: linear index of the component's first voxel in raster order (= the order in which
+ *         skimage numbers components), -1 for background;
+ *   sizes dev uint32 [n]: component size stored at the root's index, 0 elsewhere;
+ *   host_n_components (optional): number of components. */
+int boa_ccl26(boa_ctx* ctx, const uint8_t* dev_mask, int Z, int Y, int X, int32_t* dev_roots, uint32_t* dev_sizes,
+              int* host_n_components);
+/* _filter_largest_unique_segment (BCA/body_regions/postprocess.py:8-15): every component except the largest
+ * (ties: the one numbered first, i.e. smallest root) gets seg = fill_value (255). No-op for <= 1 component. */
+int boa_ccl_filter_largest(boa_ctx* ctx, const int32_t* dev_roots, const uint32_t* dev_sizes, size_t n,
+                           uint8_t* dev_seg, int fill_value);
+/* remove_small_objects(mask, max_size): clear mask where the component has <= max_size voxels. */
+int boa_ccl_remove_small(boa_ctx* ctx, const int32_t* dev_roots, const uint32_t* dev_sizes, size_t n,
+                         uint32_t max_size, uint8_t* dev_mask_inout);
+/* mask_out = (labels == value) [mode 0] | (lut-free) labels > 0 [mode 1] | labels in {a,b,c} [mode 2, vals[3]] */
+int boa_label_select(boa_ctx* ctx, const uint8_t* dev_labels, size_t n, int mode, const int vals[3],
+                     uint8_t* dev_mask_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOA_HIP_H */

@@ -1,0 +1,304 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI (libboa_hip.so).
+
+Integer / fp16-bit-pattern stages are compared bit-exactly against the golden vectors generated from the
+reference and against the oracle; the fp16-MFMA conv stack is compared against torch-CPU fp32 with the
+tolerances stated in each test.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from boa_hip.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def _i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def _finalize(ctx, acc, n, Cn, V, fold=None, fold_mode=0, nff=0, write=1, lut=None, merge=0, labels=None, crop=None):
+    from boa_hip._lib import check
+    flag = ctx.zeros(4)
+    lut_p = None
+    if lut is not None:
+        la = np.zeros(256, np.uint8)
+        la[:len(lut)] = lut
+        lut_p = la.ctypes.data_as(C.c_void_p)
+    check(ctx.lib.boa_finalize_labels(ctx.h, acc.vp, n.vp, Cn, _i3(V), fold.vp if fold else None, fold_mode, nff, write,
+                                      lut_p, merge, labels.vp if labels else None,
+                                      _i3(crop[0]) if crop else None, _i3(crop[1]) if crop else None, flag.vp))
+    return int(flag.download((1,), np.int32)[0])
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d", "e"])
+def test_accumulate_finalize_bit_exact(ctx, case):
+    """G3: tile loop arithmetic given identical per-tile logits -> fp16 logits bit patterns + labels."""
+    from boa_hip import sliding_window as sw
+    from boa_hip._lib import check
+    z = _npz("g3_sliding_window.npz")
+    tiles = z[f"{case}_tiles"]
+    x = z[f"{case}_x"]
+    patch = [int(v) for v in z[f"{case}_patch"]]
+    step = float(z[f"{case}_step"])
+    Cn = tiles.shape[1]
+    V = list(x.shape[1:])
+    PV, below = sw.pad_amounts(V, patch)
+    origins = sw.get_sliding_window_origins(PV, patch, step)
+    assert len(origins) == len(tiles)
+    use_g = case != "e"
+    g = ctx.from_numpy(np.ascontiguousarray(sw.compute_gaussian(tuple(patch), 1. / 8, 10)).view(np.uint16)) if use_g else None
+    nv = int(np.prod(PV))
+    acc = ctx.zeros(Cn * nv * 2)
+    n = ctx.zeros(nv * 2)
+    for t, o in zip(tiles, origins):
+        d = ctx.from_numpy(t.astype(np.float32))
+        check(ctx.lib.boa_accumulate_tile(ctx.h, d.vp, g.vp if g else None, acc.vp, n.vp, Cn, _i3(patch), _i3(PV), _i3(o)))
+        ctx.sync()
+        d.free()
+    lab = ctx.zeros(int(np.prod(V)))
+    crop = (below, V) if PV != V else None
+    inf = _finalize(ctx, acc, n, Cn, PV, write=1, labels=lab, crop=crop)
+    assert inf == 0
+    logits = acc.download((Cn, *PV), np.uint16)
+    sl = (slice(None),) + tuple(slice(b, b + v) for b, v in zip(below, V))
+    np.testing.assert_array_equal(logits[sl], z[f"{case}_logits_bits"])
+    if f"{case}_seg" in z.files:
+        np.testing.assert_array_equal(lab.download(tuple(V), np.uint8), z[f"{case}_seg"])
+
+
+def test_argmax_ties_nan_inf(ctx):
+    """G6: numpy argmax semantics on fp16 (first max, -0 == 0, NaN wins) and the inf flag."""
+    z = _npz("g6_argmax.npz")
+    bits = z["logits_bits"]
+    Cn, V = bits.shape[0], list(bits.shape[1:])
+    acc = ctx.from_numpy(bits)
+    n = ctx.from_numpy(np.full(V, 0x3C00, np.uint16))  # fp16 1.0
+    lab = ctx.zeros(int(np.prod(V)))
+    inf = _finalize(ctx, acc, n, Cn, V, write=0, labels=lab)
+    assert inf == 1  # the fixture contains +inf logits: the reference raises RuntimeError for those
+    np.testing.assert_array_equal(lab.download(tuple(V), np.uint8), z["seg"])
+
+
+def test_fold_ensemble_bit_exact(ctx):
+    """G3b: prediction += fold (fp16), /= n_folds (fp16), then argmax."""
+    from oracle import labels as olab
+    z = _npz("g3b_folds.npz")
+    folds = z["fold_logits_bits"]
+    nf, Cn = folds.shape[0], folds.shape[1]
+    V = list(folds.shape[2:])
+    nv = int(np.prod(V))
+    one = ctx.from_numpy(np.full(V, 0x3C00, np.uint16))
+    fsum = ctx.zeros(Cn * nv * 2)
+    lab = ctx.zeros(nv)
+    for f in range(nf):
+        acc = ctx.from_numpy(folds[f])
+        last = f == nf - 1
+        _finalize(ctx, acc, one, Cn, V, fold=fsum, fold_mode=0 if f == 0 else 1, nff=nf if last else 0, write=0,
+                  labels=lab if last else None)
+        acc.free()
+    np.testing.assert_array_equal(fsum.download((Cn, *V), np.uint16), z["ensemble_bits"])
+    np.testing.assert_array_equal(lab.download(tuple(V), np.uint8), olab.argmax_labels(z["ensemble_bits"].view(np.float16)))
+
+
+def test_merge_parts_lut(ctx):
+    """G7: part -> global label remap with later-part-overwrites order, fused in the argmax epilogue."""
+    z = _npz("g7_merge.npz")
+    with open(os.path.join(GOLDEN, "g7_label_tables.json")) as f:
+        t = json.load(f)
+    inv = {v: int(k) for k, v in t["total"].items()}
+    segs = z["segs"]
+    V = list(segs.shape[1:])
+    nv = int(np.prod(V))
+    out = ctx.zeros(nv)
+    one = ctx.from_numpy(np.full(V, 0x3C00, np.uint16))
+    for tid, seg in zip((291, 292, 293, 294, 295), segs):
+        pm = {int(k): v for k, v in t["parts"][str(tid)].items()}
+        Cn = max(pm) + 1
+        lut = np.zeros(Cn, np.uint8)
+        for j, name in pm.items():
+            lut[j] = inv[name]
+        onehot = (np.arange(Cn)[:, None, None, None] == seg[None]).astype(np.float16)
+        acc = ctx.from_numpy(onehot.view(np.uint16))
+        _finalize(ctx, acc, one, Cn, V, write=0, lut=lut, merge=1, labels=out)
+        acc.free()
+    np.testing.assert_array_equal(out.download(tuple(V), np.uint8), z["combined"])
+
+
+def test_ct_normalize_bit_exact(ctx):
+    from boa_hip._lib import check
+    z = _npz("g4_ctnorm.npz")
+    m, s, lo, hi = [float(v) for v in z["props"]]
+    x = np.ascontiguousarray(z["x"])
+    d = ctx.from_numpy(x)
+    o = ctx.alloc(x.size * 4)
+    check(ctx.lib.boa_ct_normalize(ctx.h, d.vp, 0, o.vp, x.size, m, s, lo, hi))
+    y = o.download(x.shape, np.float32)
+    np.testing.assert_array_equal(y.view(np.uint32), z["y"].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _conv_case(ctx, N, Cin, dims, Cout, k, s, norm, seed):
+    import torch
+    from boa_hip._lib import check
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, Cin, *dims)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, *k)) / np.sqrt(Cin * np.prod(k))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32) * 0.1
+    gam = (1 + 0.2 * rng.standard_normal(Cout)).astype(np.float32)
+    bet = (0.2 * rng.standard_normal(Cout)).astype(np.float32)
+    dout = [(d + 2 * ((kk - 1) // 2) - kk) // ss + 1 for d, kk, ss in zip(dims, k, s)]
+    dx = ctx.from_numpy(x)
+    do = ctx.alloc(N * Cout * int(np.prod(dout)) * 4)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(ctx.lib.boa_conv_block_test(ctx.h, dx.vp, N, Cin, _i3(dims), vp(w), vp(b), vp(gam), vp(bet), Cout, _i3(k), _i3(s),
+                                      1 if norm else 0, 0, do.vp), "boa_conv_block_test")
+    got = do.download((N, Cout, *dout), np.float32)
+    torch.set_num_threads(8)
+    xt = torch.from_numpy(x).half().float()
+    wt = torch.from_numpy(w).half().float()
+    ref = torch.nn.functional.conv3d(xt, wt, torch.from_numpy(b), stride=tuple(s), padding=tuple((kk - 1) // 2 for kk in k))
+    if norm:
+        ref = torch.nn.functional.instance_norm(ref, weight=torch.from_numpy(gam), bias=torch.from_numpy(bet), eps=1e-5)
+        ref = torch.nn.functional.leaky_relu(ref, 0.01)
+    return got, ref.numpy()
+
+
+@pytest.mark.parametrize("N,Cin,dims,Cout,k,s", [
+    (1, 32, (8, 16, 32), 32, (3, 3, 3), (1, 1, 1)),
+    (2, 32, (10, 12, 40), 64, (3, 3, 3), (1, 1, 1)),       # ragged dims, Cout 64 (two cout blocks)
+    (1, 32, (16, 16, 32), 64, (3, 3, 3), (2, 2, 2)),       # strided
+    (1, 64, (8, 8, 16), 32, (3, 3, 3), (1, 1, 1)),
+    (2, 16, (6, 20, 20), 32, (1, 3, 3), (1, 2, 2)),        # anisotropic kernel / stride (BCA-style stages)
+    (1, 320, (4, 4, 4), 320, (3, 3, 3), (1, 1, 1)),        # bottleneck
+    (1, 256, (8, 8, 8), 320, (3, 3, 3), (2, 2, 2)),
+    (1, 32, (5, 7, 9), 32, (3, 3, 3), (1, 1, 1)),          # odd sizes
+])
+def test_conv_mfma_raw(ctx, N, Cin, dims, Cout, k, s):
+    """Raw conv (+bias) on f16 MFMA vs torch-CPU fp32 on the same fp16-rounded operands.
+    Tolerance: output is stored in fp16 (rel 2^-11) + fp32 accumulation-order noise."""
+    got, ref = _conv_case(ctx, N, Cin, dims, Cout, k, s, norm=False, seed=1)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("N,Cin,dims,Cout,k,s", [
+    (2, 32, (8, 16, 32), 32, (3, 3, 3), (1, 1, 1)),
+    (1, 64, (12, 12, 24), 64, (3, 3, 3), (2, 2, 2)),
+])
+def test_conv_block_norm_act(ctx, N, Cin, dims, Cout, k, s):
+    """Conv -> InstanceNorm(affine) -> LeakyReLU with deferred normalisation vs torch-CPU fp32.  atol 6e-3 on
+    O(1) normalised activations (fp16 storage of the pre-norm tensor)."""
+    got, ref = _conv_case(ctx, N, Cin, dims, Cout, k, s, norm=True, seed=2)
+    np.testing.assert_allclose(got, ref, rtol=5e-3, atol=6e-3)
+
+
+@pytest.mark.parametrize("N,Cin,dims,Cout,s", [
+    (1, 64, (8, 8, 16), 32, (2, 2, 2)),
+    (2, 320, (4, 4, 4), 320, (2, 2, 2)),
+    (1, 128, (5, 6, 7), 64, (1, 2, 2)),
+])
+def test_convtranspose(ctx, N, Cin, dims, Cout, s):
+    import torch
+    from boa_hip._lib import check
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((N, Cin, *dims)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, *s)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32) * 0.1
+    dout = [d * ss for d, ss in zip(dims, s)]
+    dx = ctx.from_numpy(x)
+    do = ctx.alloc(N * Cout * int(np.prod(dout)) * 4)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(ctx.lib.boa_convtranspose_test(ctx.h, dx.vp, N, Cin, _i3(dims), vp(w), vp(b), Cout, _i3(s), do.vp))
+    got = do.download((N, Cout, *dout), np.float32)
+    ref = torch.nn.functional.conv_transpose3d(torch.from_numpy(x).half().float(), torch.from_numpy(w).half().float(),
+                                               torch.from_numpy(b), stride=tuple(s)).numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _small_net(patch=(32, 32, 32), features=(32, 64, 128), classes=5, seed=0, kernels=None, strides=None):
+    import torch
+    from boa_hip import plans
+    from oracle.network import build_from_arch
+    pj, dj = plans.synthetic_plans(patch=patch, features=features, num_classes=classes, kernels=kernels, strides=strides)
+    cfg = plans.model_config_from_plans(pj, dj)
+    sd = plans.synthetic_state_dict(cfg.geometry, seed)
+    blob = plans.weight_blob_from_state_dict(cfg.geometry, sd)
+    net = build_from_arch(pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"], 1, classes)
+    missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not missing.missing_keys, missing
+    return cfg.geometry, blob, net
+
+
+@pytest.mark.parametrize("patch,features,kernels,strides", [
+    ((32, 32, 32), (32, 64, 128), None, None),
+    ((16, 48, 40), (32, 64, 128, 256), [[1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+     [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2]]),
+])
+def test_network_forward_vs_oracle(ctx, patch, features, kernels, strides):
+    """Whole PlainConvUNet tile forward (fp16 MFMA) vs the torch-CPU fp32 oracle.  Tolerance: max abs logit error
+    <= 3 % of the logit range and argmax agreement >= 98 % (random weights make near-ties common)."""
+    from boa_hip.predictor import HipPredictor
+    from oracle.network import network_fn_from_module
+    geom, blob, net = _small_net(patch, features, 5, 0, kernels, strides)
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal((1, patch[0] + 9, patch[1] + 5, patch[2] + 11)).astype(np.float32)
+    origins = np.array([[0, 0, 0], [9, 5, 11], [3, 2, 7]], dtype=np.int32)
+    p = HipPredictor(ctx, geom, max_batch=2)
+    p.set_parameters([blob])
+    got = p.network_forward(vol, origins)
+    fn = network_fn_from_module(net, threads=8)
+    for i, o in enumerate(origins):
+        patch_in = vol[:, o[0]:o[0] + patch[0], o[1]:o[1] + patch[1], o[2]:o[2] + patch[2]][None]
+        ref = fn(patch_in)[0]
+        rng_ = float(ref.max() - ref.min())
+        err = float(np.abs(got[i] - ref).max())
+        agree = float((got[i].argmax(0) == ref.argmax(0)).mean())
+        print(f"tile {i}: max|err|={err:.4g} range={rng_:.4g} argmax agreement={agree:.5f}")
+        assert err <= 0.03 * rng_, (err, rng_)
+        assert agree >= 0.98
+    p.close()
+
+
+def test_sliding_window_end_to_end(ctx):
+    """predict_sliding_window_return_logits on device vs the oracle running the fp32 torch-CPU network through
+    the reference's tile loop; includes a volume smaller than the patch on one axis (pad_nd_image path)."""
+    from boa_hip.predictor import HipPredictor
+    from oracle import sliding_window as osw
+    from oracle.network import network_fn_from_module
+    geom, blob, net = _small_net((32, 32, 32), (32, 64), 4, 1)
+    rng = np.random.default_rng(6)
+    for shape, step in [((40, 50, 45), 0.5), ((24, 40, 33), 0.8)]:
+        vol = rng.standard_normal((1, *shape)).astype(np.float32)
+        p = HipPredictor(ctx, geom, tile_step_size=step, max_batch=3)
+        p.set_parameters([blob])
+        got = p.predict_sliding_window_return_logits(vol)
+        seg = p.predict_segmentation(vol)
+        ref = osw.predict_sliding_window_return_logits(network_fn_from_module(net, 8), vol, list(geom.patch_size),
+                                                       geom.num_classes, step)
+        assert got.shape == ref.shape and got.dtype == np.float16
+        g32, r32 = got.astype(np.float32), ref.astype(np.float32)
+        rng_ = float(r32.max() - r32.min())
+        err = float(np.abs(g32 - r32).max())
+        agree = float((seg == ref.argmax(0)).mean())
+        print(f"{shape} step {step}: max|err|={err:.4g} range={rng_:.4g} label agreement={agree:.5f}")
+        assert err <= 0.03 * rng_
+        assert agree >= 0.98
+        # on-device argmax is exactly the argmax of the on-device fp16 logits
+        np.testing.assert_array_equal(seg, got.argmax(0).astype(np.uint8))
+        p.close()

@@ -1,0 +1,99 @@
+"""CPU: host logic of the product package + the C ABI library loads and exports what include/boa_hip.h declares."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+
+from conftest import GOLDEN, ROOT
+
+
+def _json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def test_library_exports_every_declared_symbol():
+    from boa_hip import _lib
+    hdr = open(os.path.join(ROOT, "include", "boa_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(boa_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    assert os.path.exists(_lib.LIB_PATH), "build libboa_hip.so first (python -c 'import __graft_entry__ as g; g.build()')"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in boa_hip.h but not exported"
+    # and every symbol is bound with a prototype on the Python side
+    assert sorted(_lib.EXPORTS) == declared
+    assert _lib.lib().boa_version() >= 100
+
+
+def test_tile_starts_match_reference():
+    from boa_hip import sliding_window as sw
+    for c in _json("g1_steps.json"):
+        assert sw.compute_steps_for_sliding_window(c["size"], c["patch"], c["step"]) == c["steps"]
+    o = sw.get_sliding_window_origins((512, 512, 512), (128, 128, 128), 0.8)
+    assert o.shape == (125, 3) and o[1].tolist() == [0, 0, 96] and o[-1].tolist() == [384, 384, 384]
+
+
+def test_gaussian_matches_reference_bits():
+    from boa_hip import sliding_window as sw
+    z = np.load(os.path.join(GOLDEN, "g2_gaussian.npz"))
+    for k in z.files:
+        ts = tuple(int(v) for v in k[2:].split("x"))
+        np.testing.assert_array_equal(sw.compute_gaussian(ts, 1. / 8, 10).view(np.uint16), z[k])
+    for k, m in _json("g2_gaussian_big.json").items():
+        ts = tuple(int(v) for v in k.split("x"))
+        bits = np.ascontiguousarray(sw.compute_gaussian(ts, 1. / 8, 10).view(np.uint16))
+        assert hashlib.sha256(bits.tobytes()).hexdigest() == m["sha256"]
+
+
+def test_pad_amounts():
+    from boa_hip import sliding_window as sw
+    assert sw.pad_amounts((12, 40, 20), (16, 16, 16)) == ([16, 40, 20], [2, 0, 0])
+    assert sw.pad_amounts((13, 40, 9), (16, 16, 16)) == ([16, 40, 16], [1, 0, 3])
+
+
+def test_plans_roundtrip_and_weight_blob():
+    from boa_hip import _lib, plans
+    pj, dj = plans.synthetic_plans()
+    cfg = plans.model_config_from_plans(pj, dj)
+    g = cfg.geometry
+    assert g.features == [32, 64, 128, 256, 320, 320] and g.num_classes == 25 and g.patch_size == [128, 128, 128]
+    # 478.8 GMAC, 2.074 GB
+    assert abs(g.flops_per_tile() / 2 / 1e9 - 478.8) < 0.5
+    assert abs(g.activation_bytes_per_tile() / 1e6 - 2073.7) < 2.0
+    sd = plans.synthetic_state_dict(g, 0)
+    blob = plans.weight_blob_from_state_dict(g, sd)
+    d = g.to_desc()
+    assert _lib.lib().boa_net_weight_count(ctypes.byref(d)) == blob.size
+    assert abs(blob.size - 31.19e6) < 0.3e6  # 31.19 M parameters
+    # old-format plans are reconstructed like plans_handler.py:36-97
+    old = {"configurations": {"3d_fullres": {
+        "UNet_class_name": "PlainConvUNet", "UNet_base_num_features": 32, "unet_max_num_features": 320,
+        "n_conv_per_stage_encoder": [2] * 6, "n_conv_per_stage_decoder": [2] * 5, "num_pool_per_axis": [5, 5, 5],
+        "pool_op_kernel_sizes": [[1, 1, 1]] + [[2, 2, 2]] * 5, "conv_kernel_sizes": [[3, 3, 3]] * 6,
+        "patch_size": [128, 128, 128], "spacing": [1.5, 1.5, 1.5], "normalization_schemes": ["CTNormalization"]}},
+        "foreground_intensity_properties_per_channel": {"0": {"mean": 1.0, "std": 2.0, "percentile_00_5": 0, "percentile_99_5": 3}}}
+    g2 = plans.model_config_from_plans(old, dj).geometry
+    assert g2.features == g.features and g2.strides == g.strides and g2.kernels == g.kernels
+    import pytest
+    bad = dict(sd)
+    bad.pop("decoder.transpconvs.0.bias")
+    with pytest.raises(KeyError):
+        plans.weight_blob_from_state_dict(g, bad)
+
+
+def test_oracle_network_accepts_upstream_key_names():
+    import torch
+    from boa_hip import plans
+    from oracle.network import build_from_arch
+    pj, dj = plans.synthetic_plans(patch=(16, 16, 16), features=(32, 64), num_classes=3)
+    g = plans.model_config_from_plans(pj, dj).geometry
+    sd = plans.synthetic_state_dict(g, 1)
+    net = build_from_arch(pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"], 1, 3)
+    res = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    y = net(torch.zeros(1, 1, 16, 16, 16))
+    assert tuple(y.shape) == (1, 3, 16, 16, 16)
