@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- CT volumes/sec of the BOA hot path on MI355X (BASELINE.json metric).
+
+Workload (configs[1] of BASELINE.json): one 512x512x512 @1.5 mm synthetic CT per GPU, `total` task = the five
+part models Dataset291-295 (PlainConvUNet 3d_fullres, patch 128^3, step 0.8 -> 125 tiles each = 625 tile
+forwards), Gaussian-weighted fp16 accumulation, normalise + argmax + part->global merge; the int16 CT is
+resident in HBM when the timed region starts and the uint8 label volume stays in HBM (PCIe-inclusive rate: see
+DESIGN.md).  One "step" = one whole volume.  Multi-GPU: one process per GPU, every rank segments its own volume
+(volume-level sharding, no data-path collective) -> weak scaling; value = all volumes / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--batch 4] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "body-and-organ-analysis_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+
+
+def cpu_baseline(geom_tuple, n_tiles_sample, tiles_per_volume, log):
+    """Oracle (torch-CPU fp32 PlainConvUNet + numpy fp16 accumulation = the reference's CPU path restated) timed
+    on the host on a bounded sample: `n_tiles_sample` tile forwards of part model 291, extrapolated by tile count."""
+    import torch
+    from oracle import sliding_window as osw
+    from oracle.network import build_from_arch
+    pj, dj, sd = geom_tuple
+    threads = min(8, os.cpu_count() or 1)  # the reference caps torch at min(8, n) (predict_from_raw_data.py:479-480)
+    torch.set_num_threads(threads)
+    arch = pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"]
+    nc = len(dj["labels"])
+    net = build_from_arch(arch, 1, nc).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    patch = pj["configurations"]["3d_fullres"]["patch_size"]
+    g = osw.compute_gaussian(tuple(patch), 1. / 8, 10)
+    x = torch.randn(1, 1, *patch)
+    acc = np.zeros((nc, *patch), np.float16)
+    n = np.zeros(patch, np.float16)
+    with torch.inference_mode():
+        net(x)  # warm-up (allocator, mkldnn primitives)
+        t0 = time.perf_counter()
+        for _ in range(n_tiles_sample):
+            y = net(x)[0].numpy()
+            osw.accumulate_tile(acc, n, y, g, (0, 0, 0))
+        dt = (time.perf_counter() - t0) / n_tiles_sample
+    log(f"cpu_baseline: {dt:.3f} s per tile forward+accumulate on {threads} threads")
+    return {"value": 1.0 / (dt * tiles_per_volume), "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"{n_tiles_sample} x 128^3 tile forward (torch-CPU fp32 PlainConvUNet, 31M params) + fp16 Gaussian "
+                      f"accumulation, extrapolated to {tiles_per_volume} tile forwards per volume; argmax/merge not included",
+            "s_per_tile": dt, "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, nargs="+", default=[512])
+    ap.add_argument("--batch", type=int, default=4, help="tiles per conv-stack launch")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=4)
+    ap.add_argument("--dump", type=str, default=None, help="write per-kernel-class timings to this JSON file")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    n_gpus = args.gpus
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_
+    log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
+
+    from boa_hip import label_maps, synthetic
+    from boa_hip._lib import check
+    from boa_hip.device import Context
+    from boa_hip.predictor import HipPredictor
+
+    shape = args.size * 3 if len(args.size) == 1 else args.size
+    ctx = Context(local_rank)
+    log("device:", ctx.info())
+    t0 = time.perf_counter()
+    models = synthetic.total_part_models()
+    predictors = []
+    for tid, cfg, blob, _ in models:
+        p = HipPredictor(ctx, cfg.geometry, tile_step_size=0.8, max_batch=args.batch)  # TS/nnunet.py:507-514
+        p.set_parameters([blob])
+        p._ensure_net(0)
+        predictors.append((tid, cfg, p))
+    ct = synthetic.ct_phantom(shape, seed=20260928 + rank)
+    log(f"setup (synthetic weights + phantom {shape}) {time.perf_counter() - t0:.1f}s")
+    nvox = int(np.prod(shape))
+    d_ct = ctx.from_numpy(ct)
+    d_vol = ctx.alloc(nvox * 4)
+    d_lab = ctx.alloc(nvox)
+    work = {}
+    ip = models[0][1].intensity_properties["0"]
+    tiles_per_volume = 0
+    flops_per_volume = 0.0
+    from boa_hip import sliding_window as sw
+    for tid, cfg, p in predictors:
+        PV, _ = sw.pad_amounts(shape, cfg.geometry.patch_size)
+        nt = len(sw.get_sliding_window_origins(PV, cfg.geometry.patch_size, 0.8))
+        tiles_per_volume += nt
+        flops_per_volume += nt * cfg.geometry.flops_per_tile()
+
+    def step():
+        # CTNormalization -> 5 part models (sliding window, fp16 accumulate) -> argmax + merge into `total` labels
+        check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, 0, d_vol.vp, nvox, ip["mean"], ip["std"], ip["percentile_00_5"],
+                                       ip["percentile_99_5"]))
+        d_lab.zero()
+        for tid, cfg, p in predictors:
+            p.predict_segmentation_device(d_vol, shape, d_lab, lut=label_maps.part_lut(tid), merge=True, work=work)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    ctx.prof_enable(False)
+    prof = ctx.prof_get()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    labels_sum = int(d_lab.download((nvox,), np.uint8).astype(np.int64).sum()) if rank == 0 else 0
+    if rank == 0:
+        conv = prof["conv_mfma"]
+        conv_ms = conv["ms"]
+        achieved = conv["flops"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        total_ms = sum(v["ms"] for v in prof.values())
+        for k, v in prof.items():
+            if v["launches"]:
+                log(f"  {k:16s} {v['ms']:10.1f} ms  {v['launches']:8d} launches  "
+                    f"{v['flops'] / max(v['ms'], 1e-9) / 1e9:9.1f} TFLOP/s  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:9.1f} GB/s")
+        log(f"  sum of kernel times {total_ms:.1f} ms of {elapsed * 1e3:.1f} ms wall; label checksum {labels_sum}")
+        res = {
+            "metric": "CT volumes/sec (512^3 @1.5 mm, total) on MI355X",
+            "value": n_gpus * args.steps / elapsed, "unit": "volumes/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: single {shape[0]}x{shape[1]}x{shape[2]} @1.5 mm volume, `total` "
+                                   f"(5 part models, {tiles_per_volume} tile forwards of 128^3, step 0.8), 1 volume per GPU",
+                       "tiles_per_volume": tiles_per_volume, "tile_batch": args.batch,
+                       "tflop_per_volume": flops_per_volume / 1e12,
+                       "precision": "fp16 activations/weights, fp32 MFMA accumulate, fp16 logit accumulators (reference semantics)"},
+            "roofline": {"bound": "mfma", "kernel": "k_conv_mfma (implicit-GEMM 3x3x3 conv, v_mfma_f32_32x32x16_f16)",
+                         "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
+                         "launches": conv["launches"], "avg_launch_ms": conv_ms / max(conv["launches"], 1),
+                         "flops_per_launch": conv["flops"] / max(conv["launches"], 1),
+                         "share_of_kernel_time": conv_ms / max(total_ms, 1e-9)},
+            "end_to_end_tflops": flops_per_volume * args.steps / elapsed / 1e12,
+        }
+        if not args.no_cpu and n_gpus == 1:
+            res["cpu_baseline"] = cpu_baseline(models[0][3], args.cpu_tiles, tiles_per_volume, log)
+        else:
+            res["cpu_baseline"] = None
+        if args.dump:
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump)), exist_ok=True)
+            with open(args.dump, "w") as f:
+                json.dump({"prof": prof, "elapsed_s": elapsed, "result": res}, f, indent=1)
+        print(json.dumps(res), flush=True)
+    for _, _, p in predictors:
+        p.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

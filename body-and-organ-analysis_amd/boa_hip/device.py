@@ -1,12 +1,26 @@
 """Device context and buffers on top of the C ABI (plumbing only: memory, streams, timers)."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
 from . import _lib
 from ._lib import check
+
+
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    for c in list(_LIVE):
+        try:
+            c.close()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:
@@ -59,9 +73,19 @@ class Context:
         check(self.lib.boa_init(int(device), C.c_void_p(stream) if stream else None, C.byref(h)), "boa_init")
         self.h = h
         self.device = device
+        self._children = weakref.WeakSet()  # objects holding device state (predictors) closed before the context
+        _LIVE.add(self)
+
+    def register(self, obj):
+        self._children.add(obj)
 
     def close(self):
         if self.h is not None:
+            for ch in list(self._children):
+                try:
+                    ch.close()
+                except Exception:
+                    pass
             self.lib.boa_destroy(self.h)
             self.h = None
 

@@ -1,0 +1,75 @@
+"""Label tables of the TotalSegmentator `total` task as data (structure names, whitespace separated, in label
+order starting at 1).  Same content as TS/map_to_binary.py `class_map["total"]` (:116-234), `class_map_5_parts`
+(:808-959) and `map_taskid_to_partname_ct` (:1054-1062); pinned by tests/golden/g7_label_tables.json, which is
+generated from the reference tables."""
+
+_TOTAL = """
+    spleen kidney_right kidney_left gallbladder liver stomach pancreas adrenal_gland_right adrenal_gland_left
+    lung_upper_lobe_left lung_lower_lobe_left lung_upper_lobe_right lung_middle_lobe_right
+    lung_lower_lobe_right esophagus trachea thyroid_gland small_bowel duodenum colon urinary_bladder prostate
+    kidney_cyst_left kidney_cyst_right sacrum vertebrae_S1 vertebrae_L5 vertebrae_L4 vertebrae_L3 vertebrae_L2
+    vertebrae_L1 vertebrae_T12 vertebrae_T11 vertebrae_T10 vertebrae_T9 vertebrae_T8 vertebrae_T7 vertebrae_T6
+    vertebrae_T5 vertebrae_T4 vertebrae_T3 vertebrae_T2 vertebrae_T1 vertebrae_C7 vertebrae_C6 vertebrae_C5
+    vertebrae_C4 vertebrae_C3 vertebrae_C2 vertebrae_C1 heart aorta pulmonary_vein brachiocephalic_trunk
+    subclavian_artery_right subclavian_artery_left common_carotid_artery_right common_carotid_artery_left
+    brachiocephalic_vein_left brachiocephalic_vein_right atrial_appendage_left superior_vena_cava
+    inferior_vena_cava portal_vein_and_splenic_vein iliac_artery_left iliac_artery_right iliac_vena_left
+    iliac_vena_right humerus_left humerus_right scapula_left scapula_right clavicula_left clavicula_right
+    femur_left femur_right hip_left hip_right spinal_cord gluteus_maximus_left gluteus_maximus_right
+    gluteus_medius_left gluteus_medius_right gluteus_minimus_left gluteus_minimus_right autochthon_left
+    autochthon_right iliopsoas_left iliopsoas_right brain skull rib_left_1 rib_left_2 rib_left_3 rib_left_4
+    rib_left_5 rib_left_6 rib_left_7 rib_left_8 rib_left_9 rib_left_10 rib_left_11 rib_left_12 rib_right_1
+    rib_right_2 rib_right_3 rib_right_4 rib_right_5 rib_right_6 rib_right_7 rib_right_8 rib_right_9
+    rib_right_10 rib_right_11 rib_right_12 sternum costal_cartilages
+"""
+
+_PARTS = {
+    291: """
+    spleen kidney_right kidney_left gallbladder liver stomach pancreas adrenal_gland_right adrenal_gland_left
+    lung_upper_lobe_left lung_lower_lobe_left lung_upper_lobe_right lung_middle_lobe_right
+    lung_lower_lobe_right esophagus trachea thyroid_gland small_bowel duodenum colon urinary_bladder prostate
+    kidney_cyst_left kidney_cyst_right
+""",
+    292: """
+    sacrum vertebrae_S1 vertebrae_L5 vertebrae_L4 vertebrae_L3 vertebrae_L2 vertebrae_L1 vertebrae_T12
+    vertebrae_T11 vertebrae_T10 vertebrae_T9 vertebrae_T8 vertebrae_T7 vertebrae_T6 vertebrae_T5 vertebrae_T4
+    vertebrae_T3 vertebrae_T2 vertebrae_T1 vertebrae_C7 vertebrae_C6 vertebrae_C5 vertebrae_C4 vertebrae_C3
+    vertebrae_C2 vertebrae_C1
+""",
+    293: """
+    heart aorta pulmonary_vein brachiocephalic_trunk subclavian_artery_right subclavian_artery_left
+    common_carotid_artery_right common_carotid_artery_left brachiocephalic_vein_left
+    brachiocephalic_vein_right atrial_appendage_left superior_vena_cava inferior_vena_cava
+    portal_vein_and_splenic_vein iliac_artery_left iliac_artery_right iliac_vena_left iliac_vena_right
+""",
+    294: """
+    humerus_left humerus_right scapula_left scapula_right clavicula_left clavicula_right femur_left
+    femur_right hip_left hip_right spinal_cord gluteus_maximus_left gluteus_maximus_right gluteus_medius_left
+    gluteus_medius_right gluteus_minimus_left gluteus_minimus_right autochthon_left autochthon_right
+    iliopsoas_left iliopsoas_right brain skull
+""",
+    295: """
+    rib_left_1 rib_left_2 rib_left_3 rib_left_4 rib_left_5 rib_left_6 rib_left_7 rib_left_8 rib_left_9
+    rib_left_10 rib_left_11 rib_left_12 rib_right_1 rib_right_2 rib_right_3 rib_right_4 rib_right_5
+    rib_right_6 rib_right_7 rib_right_8 rib_right_9 rib_right_10 rib_right_11 rib_right_12 sternum
+    costal_cartilages
+""",
+}
+
+TOTAL_NAMES = _TOTAL.split()
+CLASS_MAP_TOTAL = {i + 1: n for i, n in enumerate(TOTAL_NAMES)}
+CLASS_MAP_TOTAL_INV = {n: i for i, n in CLASS_MAP_TOTAL.items()}
+PART_TASK_IDS = (291, 292, 293, 294, 295)
+PART_NAMES = {291: "class_map_part_organs", 292: "class_map_part_vertebrae", 293: "class_map_part_cardiac",
+              294: "class_map_part_muscles", 295: "class_map_part_ribs"}
+CLASS_MAP_PARTS = {tid: {i + 1: n for i, n in enumerate(txt.split())} for tid, txt in _PARTS.items()}
+
+
+def part_lut(task_id: int):
+    """uint8 LUT local argmax index -> global `total` label (index 0 = background stays 0)."""
+    import numpy as np
+    pm = CLASS_MAP_PARTS[task_id]
+    lut = np.zeros(max(pm) + 1, dtype=np.uint8)
+    for j, name in pm.items():
+        lut[j] = CLASS_MAP_TOTAL_INV[name]
+    return lut

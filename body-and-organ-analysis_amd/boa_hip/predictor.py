@@ -42,6 +42,7 @@ class HipPredictor:
         self._net = None
         self._gauss_dev: Optional[DeviceBuffer] = None
         self._loaded_fold = None
+        ctx.register(self)
 
     # ---- model management ---------------------------------------------------------------------------
     def set_parameters(self, weight_blobs: Sequence[np.ndarray]):
@@ -71,7 +72,8 @@ class HipPredictor:
 
     def close(self):
         if self._net is not None:
-            self.lib.boa_net_destroy(self._net)
+            if self.ctx.h is not None:
+                self.lib.boa_net_destroy(self._net)
             self._net = None
         self._gauss_dev = None
 

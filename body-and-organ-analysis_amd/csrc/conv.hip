@@ -86,8 +86,6 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
                     int ext = b[d] * w[d];
                     h[d] = (ext - 1) * g.s[d] + g.k[d];
                     tl[d] = ceil_div(dims[d], ext);
-                    // do not tile far beyond the tensor along an axis
-                    if (b[d] > 1 && (b[d] / 2) * w[d] >= dims[d]) bad = true;
                     HV *= h[d];
                     covered *= (long long)tl[d] * ext;
                     tiles *= tl[d];
