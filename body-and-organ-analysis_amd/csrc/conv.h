@@ -8,6 +8,7 @@
 struct ActSrc {
     const __half* data = nullptr;
     const float* ss = nullptr;  // [N][C][2] (scale, shift)
+    const unsigned* ss16 = nullptr;  // [N][C/2][2] words: {fp16 scales of (c, c+1), fp16 shifts of (c, c+1)}
     int C = 0;
 };
 
@@ -15,11 +16,13 @@ struct ConvGeom {
     int N, Di, Hi, Wi, Do, Ho, Wo;
     int Cout;
     int k[3], s[3];
+    int Cin;  // total input channels (both sources)
 };
 
 // tile configuration chosen on the host (see choose_conv_tile)
 struct ConvTile {
-    int R;           // M-tiles (32 output voxels each) per wave; block = 4 waves = 4R M-tiles
+    int variant;     // 0: k_conv_mfma (256 threads, 2 blocks/CU); 1: k_conv_ws (producer/consumer waves, persistent)
+    int R;           // M-tiles (32 output voxels each) per (consumer) wave; block tile = 4R M-tiles
     int w[3];        // wave M-tile shape, product 32
     int b[3];        // M-tiles per block along each axis, product 4R
     int h[3];        // input halo extents
@@ -50,7 +53,7 @@ int conv_first_nblk(const int P[3]);
 
 // InstanceNorm statistics -> (scale, shift) per (n, c):  scale = gamma * rsqrt(var + eps), shift = beta - mean * scale
 int launch_norm_finalize(boa_ctx* ctx, const float* partials, int nblk, int N, int C, double count,
-                         const float* gamma, const float* beta, float eps, float* ss_out);
+                         const float* gamma, const float* beta, float eps, float* ss_out, unsigned* ss16_out);
 
 // ConvTranspose3d with kernel == stride, + bias; input source with deferred norm; out fp16 raw.
 int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], const int s[3], int Cout,
@@ -61,6 +64,46 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
 int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const int P[3], int C, const float* w,
                 const float* bias, float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc,
                 uint16_t* nacc, const int PV[3], const int start[3]);
+
+// ---- shared device-side definitions -------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const __half* src0;
+    const __half* src1;
+    const float* ss0;
+    const float* ss1;
+    const unsigned* ss16_0;
+    const unsigned* ss16_1;
+    int C0, C1;
+    int N, Di, Hi, Wi, Do, Ho, Wo, Cout;
+    int k0, k1, k2, s0, s1, s2, p0, p1, p2;
+    int w0, w1, w2, b0, b1, b2, h0, h1, h2, t0, t1, t2;
+    int lw1, lw2, lb1, lb2;  // log2 of the (power-of-two) wave-tile / block-tile extents
+    const __half* wpk;
+    const float* bias;
+    __half* out;
+    float* partials;
+    float slope;
+};
+
+__device__ __forceinline__ uint4 norm_act8(uint4 raw, const float* sc, const float* sh, float slope) {
+    union {
+        uint4 u;
+        __half h[8];
+    } x;
+    x.u = raw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float f = __builtin_fmaf(__half2float(x.h[j]), sc[j], sh[j]);
+        f = f > 0.f ? f : f * slope;
+        x.h[j] = __float2half_rn(f);
+    }
+    return x.u;
+}
+
+int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double flops, double bytes);
 
 // layout helpers (tests / debug)
 int launch_nchw_to_ndhwc_f16(boa_ctx* ctx, const float* in, int N, int C, size_t vox, __half* out);

@@ -5,15 +5,14 @@
 //
 // Replaces `self.network(x)` (NN/inference/predict_from_raw_data.py:543), i.e. dynamic_network_architectures'
 // PlainConvUNet as configured by NN/utilities/plans_handling/plans_handler.py:59-92.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include "conv.h"
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ======================================================================================================
 // host-side weight packing
@@ -63,6 +62,21 @@ static size_t conv_lds_bytes(int HV, int taps) {
     return 2 * plane + (size_t)taps * 1024 + (size_t)HV * 4 + 1024;
 }
 
+size_t conv_ws_lds_bytes(int HV, int taps, int ncc, int Cout);
+bool conv_ws_supported(const int k[3], int HV);
+bool conv_ws_resident(int HV, int taps, int ncc, int Cout);
+
+static int conv_variant_override() {
+    static int v = [] {
+        const char* e = getenv("BOA_CONV_VARIANT");
+        return e ? atoi(e) : -1;
+    }();
+    return v;
+}
+
+// Pick the wave M-tile shape, the block tile and the kernel variant.  Cost model (cycles per 32-voxel M-tile):
+//   variant 1 (k_conv_ws): chunk time = max(MFMA time of the consumers, staging time of the producers) + barrier;
+//   variant 0 (k_conv_mfma): MFMA and staging serialised inside a block, partly hidden by the second block on the CU.
 bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
     const int dims[3] = {g.Do, g.Ho, g.Wo};
     int w[3];
@@ -72,88 +86,71 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
     const int taps = g.k[0] * g.k[1] * g.k[2];
     double best_cost = 1e30;
     bool found = false;
-    for (int R : {4, 2, 1}) {
-        const int M = 4 * R;
-        for (int b0 = 1; b0 <= M; b0 *= 2)
-            for (int b1 = 1; b0 * b1 <= M; b1 *= 2) {
-                int b2 = M / (b0 * b1);
-                if (b0 * b1 * b2 != M) continue;
-                int b[3] = {b0, b1, b2};
-                int h[3], tl[3];
-                long long HV = 1, covered = 1, tiles = 1;
-                bool bad = false;
-                for (int d = 0; d < 3; ++d) {
-                    int ext = b[d] * w[d];
-                    h[d] = (ext - 1) * g.s[d] + g.k[d];
-                    tl[d] = ceil_div(dims[d], ext);
-                    HV *= h[d];
-                    covered *= (long long)tl[d] * ext;
-                    tiles *= tl[d];
-                }
-                if (bad) continue;
-                size_t lds = conv_lds_bytes((int)HV, taps);
-                if (lds > 150 * 1024) continue;
-                int blocks_per_cu = lds <= 78 * 1024 ? 2 : 1;
-                long long nblocks = tiles * (g.Cout / 32) * g.N;
-                // cost model: LDS traffic per MFMA ((R+1)/R), halo re-read amplification, padding waste,
-                // occupancy (1 block/CU cannot overlap staging with MFMA), chip fill
-                double valid = (double)dims[0] * dims[1] * dims[2];
-                double waste = (double)covered / valid;
-                double amp = (double)HV * tiles / ((double)g.Di * g.Hi * g.Wi);
-                double fill = std::min(1.0, (double)nblocks / (double)(cu_count * blocks_per_cu));
-                double cost = waste * ((R + 1.0) / R + 0.15 * amp) * (blocks_per_cu == 1 ? 1.25 : 1.0) / fill;
-                if (cost < best_cost) {
-                    best_cost = cost;
-                    found = true;
-                    out->R = R;
+    const int force = conv_variant_override();
+    for (int variant : {1, 0}) {
+        if (force >= 0 && variant != force) continue;
+        for (int R : {4, 2, 1}) {
+            const int M = 4 * R;
+            for (int b0 = 1; b0 <= M; b0 *= 2)
+                for (int b1 = 1; b0 * b1 <= M; b1 *= 2) {
+                    int b2 = M / (b0 * b1);
+                    if (b0 * b1 * b2 != M) continue;
+                    int b[3] = {b0, b1, b2};
+                    int h[3], tl[3];
+                    long long HV = 1, covered = 1, tiles = 1;
                     for (int d = 0; d < 3; ++d) {
-                        out->w[d] = w[d];
-                        out->b[d] = b[d];
-                        out->h[d] = h[d];
-                        out->tiles[d] = tl[d];
+                        int ext = b[d] * w[d];
+                        h[d] = (ext - 1) * g.s[d] + g.k[d];
+                        tl[d] = ceil_div(dims[d], ext);
+                        HV *= h[d];
+                        covered *= (long long)tl[d] * ext;
+                        tiles *= tl[d];
                     }
-                    out->lds_bytes = lds;
+                    if (variant == 1 && !conv_ws_supported(g.k, (int)HV)) continue;
+                    const int ncc = g.Cin / 16;
+                    size_t lds = variant == 1 ? conv_ws_lds_bytes((int)HV, taps, ncc, g.Cout) : conv_lds_bytes((int)HV, taps);
+                    if (lds > 160 * 1024) continue;
+                    const long long nblocks = tiles * (g.Cout / 32) * g.N;
+                    const double valid = (double)dims[0] * dims[1] * dims[2];
+                    const double waste = (double)covered / valid;
+                    const double t_mfma = (double)taps * R * 32.0;
+                    double items = (2.0 * HV + taps * 64.0) / 256.0;
+                    double t_chunk, slots;
+                    if (variant == 1) {
+                        if (conv_ws_resident((int)HV, taps, ncc, g.Cout)) items = 2.0 * HV / 256.0;
+                        t_chunk = std::max(t_mfma * 1.1, items * 130.0) + 400.0;
+                        slots = cu_count;
+                    } else {
+                        const int bpc = lds <= 78 * 1024 ? 2 : 1;
+                        t_chunk = (t_mfma + items * 200.0 + 400.0) / (bpc == 2 ? 1.6 : 1.0);
+                        slots = cu_count;
+                    }
+                    const double rounds = std::ceil((double)nblocks / slots);  // quantisation on a part-filled chip
+                    const double cost = t_chunk * rounds * waste / (double)(M) * ((double)slots / (double)nblocks);
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        found = true;
+                        out->variant = variant;
+                        out->R = R;
+                        for (int d = 0; d < 3; ++d) {
+                            out->w[d] = w[d];
+                            out->b[d] = b[d];
+                            out->h[d] = h[d];
+                            out->tiles[d] = tl[d];
+                        }
+                        out->lds_bytes = lds;
+                    }
                 }
-            }
+        }
     }
     return found;
 }
 
-int conv_nblk(const ConvTile& t) { return t.tiles[0] * t.tiles[1] * t.tiles[2]; }
+// number of per-(n, cout) partial-statistics entries the conv kernel writes
+int conv_nblk(const ConvTile& t) { return t.tiles[0] * t.tiles[1] * t.tiles[2] * (t.variant == 1 ? 4 : 1); }
 
 // ======================================================================================================
 // MFMA conv kernel
-struct ConvArgs {
-    const __half* src0;
-    const __half* src1;
-    const float* ss0;
-    const float* ss1;
-    int C0, C1;
-    int N, Di, Hi, Wi, Do, Ho, Wo, Cout;
-    int k0, k1, k2, s0, s1, s2, p0, p1, p2;
-    int w0, w1, w2, b0, b1, b2, h0, h1, h2, t0, t1, t2;
-    const __half* wpk;
-    const float* bias;
-    __half* out;
-    float* partials;
-    float slope;
-};
-
-__device__ __forceinline__ uint4 norm_act8(uint4 raw, const float* sc, const float* sh, float slope) {
-    union {
-        uint4 u;
-        __half h[8];
-    } x;
-    x.u = raw;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float f = __builtin_fmaf(__half2float(x.h[j]), sc[j], sh[j]);
-        f = f > 0.f ? f : f * slope;
-        x.h[j] = __float2half_rn(f);
-    }
-    return x.u;
-}
-
 template <int R>
 __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -353,17 +350,23 @@ int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const Con
     BOA_REQUIRE(g.Cout % 32 == 0, "conv: Cout=%d must be a multiple of 32", g.Cout);
     ConvArgs a;
     a.src0 = s0.data; a.src1 = s1.data; a.ss0 = s0.ss; a.ss1 = s1.ss; a.C0 = s0.C; a.C1 = s1.C;
+    a.ss16_0 = s0.ss16; a.ss16_1 = s1.ss16;
+    BOA_REQUIRE((s0.ss == nullptr) == (s0.ss16 == nullptr) && (s1.ss == nullptr) == (s1.ss16 == nullptr),
+                "conv: ss and ss16 must be given together");
     a.N = g.N; a.Di = g.Di; a.Hi = g.Hi; a.Wi = g.Wi; a.Do = g.Do; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Cout;
     a.k0 = g.k[0]; a.k1 = g.k[1]; a.k2 = g.k[2]; a.s0 = g.s[0]; a.s1 = g.s[1]; a.s2 = g.s[2];
     a.p0 = (g.k[0] - 1) / 2; a.p1 = (g.k[1] - 1) / 2; a.p2 = (g.k[2] - 1) / 2;
     a.w0 = t.w[0]; a.w1 = t.w[1]; a.w2 = t.w[2]; a.b0 = t.b[0]; a.b1 = t.b[1]; a.b2 = t.b[2];
     a.h0 = t.h[0]; a.h1 = t.h[1]; a.h2 = t.h[2]; a.t0 = t.tiles[0]; a.t1 = t.tiles[1]; a.t2 = t.tiles[2];
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    a.lw1 = ilog2(t.w[1]); a.lw2 = ilog2(t.w[2]); a.lb1 = ilog2(t.b[1]); a.lb2 = ilog2(t.b[2]);
     a.wpk = wpk; a.bias = bias; a.out = out; a.partials = partials; a.slope = slope;
-    dim3 grid(conv_nblk(t), g.Cout / 32, g.N);
+    dim3 grid(t.tiles[0] * t.tiles[1] * t.tiles[2], g.Cout / 32, g.N);
     const int taps = g.k[0] * g.k[1] * g.k[2];
     const double vox = (double)g.N * g.Do * g.Ho * g.Wo;
     const double flops = 2.0 * vox * taps * (s0.C + s1.C) * g.Cout;
     const double bytes = 2.0 * ((double)g.N * g.Di * g.Hi * g.Wi * (s0.C + s1.C) + vox * g.Cout);
+    if (t.variant == 1) return launch_conv_ws(ctx, a, t, flops, bytes);
     KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);
     switch (t.R) {
         case 4: {
@@ -542,7 +545,8 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
 // InstanceNorm finalize: deterministic fp64 reduction of the per-block partials
 __global__ __launch_bounds__(64) void k_norm_finalize(const float* __restrict__ partials, int nblk, int C, double count,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, float* __restrict__ ss) {
+                                                      float eps, float* __restrict__ ss,
+                                                      unsigned short* __restrict__ ss16) {
     const int c = blockIdx.x, n = blockIdx.y;
     const float* ps = partials + (((size_t)n * C + c) * 2 + 0) * nblk;
     const float* pq = partials + (((size_t)n * C + c) * 2 + 1) * nblk;
@@ -565,14 +569,19 @@ __global__ __launch_bounds__(64) void k_norm_finalize(const float* __restrict__ 
         float shift = (float)((double)beta[c] - mean * (double)gamma[c] * inv);
         ss[((size_t)n * C + c) * 2 + 0] = scale;
         ss[((size_t)n * C + c) * 2 + 1] = shift;
+        if (ss16) {  // packed fp16 copy for k_conv_ws: per channel pair {s_c, s_c+1, t_c, t_c+1}
+            unsigned short* q16 = ss16 + ((size_t)n * C + (c & ~1)) * 2;
+            q16[c & 1] = f2us(scale);
+            q16[2 + (c & 1)] = f2us(shift);
+        }
     }
 }
 
 int launch_norm_finalize(boa_ctx* ctx, const float* partials, int nblk, int N, int C, double count,
-                         const float* gamma, const float* beta, float eps, float* ss_out) {
+                         const float* gamma, const float* beta, float eps, float* ss_out, unsigned* ss16_out) {
     KernelTimer tm(ctx, BOA_K_NORM_FINALIZE, 0, (double)N * C * nblk * 8.0);
     hipLaunchKernelGGL(k_norm_finalize, dim3(C, N), dim3(64), 0, ctx->stream, partials, nblk, C, count, gamma, beta,
-                       eps, ss_out);
+                       eps, ss_out, (unsigned short*)ss16_out);
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

@@ -1,5 +1,6 @@
 // PlainConvUNet on device + the sliding-window tile loop
 // (NN/inference/predict_from_raw_data.py:543,560-631; architecture per NN/utilities/plans_handling/plans_handler.py:59-92).
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -24,6 +25,7 @@ struct ConvLayer {
     __half* out = nullptr;
     float* partials = nullptr;
     float* ss = nullptr;
+    unsigned* ss16 = nullptr;
     int nblk = 0;
     size_t w_elems = 0;  // fp32 elements of W in the blob
 };
@@ -106,6 +108,7 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
     L.g.N = N;
     L.g.Di = din[0]; L.g.Hi = din[1]; L.g.Wi = din[2];
     L.g.Cout = cout;
+    L.g.Cin = cin0 + cin1;
     int dout[3];
     for (int a = 0; a < 3; ++a) {
         L.g.k[a] = k[a];
@@ -135,6 +138,7 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
     BOA_TRY(net_alloc(net, (size_t)N * vox * cout * sizeof(__half), (void**)&L.out));
     BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * L.nblk * sizeof(float), (void**)&L.partials));
     BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * sizeof(float), (void**)&L.ss));
+    BOA_TRY(net_alloc(net, (size_t)N * cout * sizeof(unsigned), (void**)&L.ss16));
     return BOA_OK;
 }
 
@@ -288,9 +292,28 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
     BOA_REQUIRE(N >= 1 && N <= net->maxN, "forward: batch %d exceeds max_batch %d", N, net->maxN);
     BOA_HIP_TRY(hipMemcpyAsync(net->dev_origins, host_origins, (size_t)N * 3 * sizeof(int), hipMemcpyHostToDevice,
                                c->stream));
+    static const bool layer_prof = getenv("BOA_LAYER_PROF") != nullptr;
+    auto prof_begin = [&]() {
+        if (layer_prof) hipEventRecord(c->t0[7], c->stream);
+    };
+    auto prof_end = [&](const char* what, const int* din, int cin, int cout, const int* k, const int* s, double flops,
+                        const ConvTile* t) {
+        if (!layer_prof) return;
+        hipEventRecord(c->t1[7], c->stream);
+        hipEventSynchronize(c->t1[7]);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, c->t0[7], c->t1[7]);
+        fprintf(stderr, "[layer] %-6s N=%d in=%dx%dx%d cin=%d cout=%d k=%d%d%d s=%d%d%d ", what, N, din[0], din[1], din[2], cin,
+                cout, k[0], k[1], k[2], s[0], s[1], s[2]);
+        if (t)
+            fprintf(stderr, "var=%d R=%d w=%d,%d,%d b=%d,%d,%d tiles=%d lds=%zu ", t->variant, t->R, t->w[0], t->w[1], t->w[2],
+                    t->b[0], t->b[1], t->b[2], t->tiles[0] * t->tiles[1] * t->tiles[2], t->lds_bytes);
+        fprintf(stderr, "%.1f us %.1f TFLOP/s\n", ms * 1e3, flops / (ms * 1e-3) / 1e12);
+    };
     auto run_conv = [&](ConvLayer& L, const ActSrc& a, const ActSrc& b) -> int {
         ConvGeom g = L.g;
         g.N = N;
+        prof_begin();
         if (L.first) {
             int nblk = 0;
             BOA_TRY(launch_conv_first(c, volume, V, vol_off, net->dev_origins, N, d.in_channels, d.patch, L.g.k, L.g.Cout,
@@ -298,8 +321,13 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
         } else {
             BOA_TRY(launch_conv_mfma(c, a, b, g, L.t, L.wpk, L.bias, d.lrelu_slope, L.out, L.partials));
         }
+        {
+            const int din[3] = {g.Di, g.Hi, g.Wi};
+            const double fl = 2.0 * N * (double)g.Do * g.Ho * g.Wo * g.k[0] * g.k[1] * g.k[2] * (L.Cin0 + L.Cin1) * g.Cout;
+            prof_end(L.first ? "first" : "conv", din, L.Cin0 + L.Cin1, g.Cout, g.k, g.s, fl, L.first ? nullptr : &L.t);
+        }
         double count = (double)g.Do * g.Ho * g.Wo;
-        BOA_TRY(launch_norm_finalize(c, L.partials, L.nblk, N, g.Cout, count, L.gamma, L.beta, d.norm_eps, L.ss));
+        BOA_TRY(launch_norm_finalize(c, L.partials, L.nblk, N, g.Cout, count, L.gamma, L.beta, d.norm_eps, L.ss, L.ss16));
         return BOA_OK;
     };
     ActSrc cur, none;
@@ -309,16 +337,20 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
             BOA_TRY(run_conv(L, cur, none));
             cur.data = L.out;
             cur.ss = L.ss;
+            cur.ss16 = L.ss16;
             cur.C = L.g.Cout;
         }
     for (int k = 0; k < d.n_stages - 1; ++k) {
         int sb = d.n_stages - 1 - k;
         UpLayer& U = net->up[k];
+        prof_begin();
         BOA_TRY(launch_convt_mfma(c, cur, N, U.din, U.s, U.Cout, U.wpk, U.bias, d.lrelu_slope, U.out));
+        prof_end("convT", U.din, U.Cin, U.Cout, U.s, U.s,
+                 2.0 * N * (double)U.din[0] * U.din[1] * U.din[2] * U.s[0] * U.s[1] * U.s[2] * U.Cin * U.Cout, nullptr);
         ConvLayer& SK = net->enc[sb - 1].back();
         ActSrc upsrc, skip;
-        upsrc.data = U.out; upsrc.ss = nullptr; upsrc.C = U.Cout;
-        skip.data = SK.out; skip.ss = SK.ss; skip.C = SK.g.Cout;
+        upsrc.data = U.out; upsrc.ss = nullptr; upsrc.ss16 = nullptr; upsrc.C = U.Cout;
+        skip.data = SK.out; skip.ss = SK.ss; skip.ss16 = SK.ss16; skip.C = SK.g.Cout;
         for (size_t i = 0; i < net->dec[k].size(); ++i) {
             ConvLayer& L = net->dec[k][i];
             if (i == 0)
@@ -327,6 +359,7 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
                 BOA_TRY(run_conv(L, cur, none));
             cur.data = L.out;
             cur.ss = L.ss;
+            cur.ss16 = L.ss16;
             cur.C = L.g.Cout;
         }
     }
@@ -389,7 +422,7 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     BOA_REQUIRE(ctx && dev_in && dims && host_w && host_b && kernel && stride && dev_out, "conv test: NULL argument");
     BOA_REQUIRE(impl == 0, "conv test: impl %d not available", impl);
     ConvGeom g;
-    g.N = N; g.Di = dims[0]; g.Hi = dims[1]; g.Wi = dims[2]; g.Cout = Cout;
+    g.N = N; g.Di = dims[0]; g.Hi = dims[1]; g.Wi = dims[2]; g.Cout = Cout; g.Cin = Cin;
     int dout[3];
     for (int a = 0; a < 3; ++a) {
         g.k[a] = kernel[a];
@@ -424,7 +457,7 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     ActSrc a, none;
     a.data = in16; a.ss = nullptr; a.C = Cin;
     T_(launch_conv_mfma(ctx, a, none, g, t, wpk, bias, 0.01f, out16, partials));
-    T_(launch_norm_finalize(ctx, partials, nblk, N, Cout, (double)vout, gamma, beta, 1e-5f, ss));
+    T_(launch_norm_finalize(ctx, partials, nblk, N, Cout, (double)vout, gamma, beta, 1e-5f, ss, nullptr));
     T_(launch_ndhwc_to_nchw_f32(ctx, out16, with_norm_act ? ss : nullptr, 0.01f, N, Cout, vout, dev_out));
     if (rc == BOA_OK) rc = boa_sync(ctx);
 #undef T_

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Per-layer timing of one tile batch of the `total` geometry (BOA_LAYER_PROF=1 prints from the C++ driver)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "body-and-organ-analysis_amd")]
+os.environ["BOA_LAYER_PROF"] = "1"
+import numpy as np  # noqa: E402
+from boa_hip import synthetic  # noqa: E402
+from boa_hip.device import Context  # noqa: E402
+from boa_hip.predictor import HipPredictor  # noqa: E402
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+ctx = Context(0)
+tid, cfg, blob, _ = synthetic.total_part_models()[0]
+p = HipPredictor(ctx, cfg.geometry, tile_step_size=0.8, max_batch=batch)
+p.set_parameters([blob])
+vol = np.random.default_rng(0).standard_normal((1, 160, 160, 224)).astype(np.float32)
+origins = np.array([[0, 0, 0], [32, 32, 96], [16, 8, 40], [32, 0, 64], [0, 32, 0], [8, 8, 8], [1, 2, 3], [30, 30, 90]][:batch], dtype=np.int32)
+for it in range(2):
+    print(f"--- pass {it}", file=sys.stderr)
+    p.network_forward(vol, origins)
+p.close()
+ctx.close()
