@@ -48,8 +48,9 @@ int conv_nblk(const ConvTile& t);
 // and outside the tile), fp32 VALU, stride 1.  w: dev fp32 [Cin][taps][Cout].
 int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins,
                       int N, int Cin, const int P[3], const int k[3], int Cout, const float* w, const float* bias,
-                      __half* out, float* partials, int* nblk_out);
+                      float* padded_scratch, __half* out, float* partials, int* nblk_out);
 int conv_first_nblk(const int P[3]);
+void conv_first_padded_dims(const int P[3], const int k[3], int out[3]);
 
 // InstanceNorm statistics -> (scale, shift) per (n, c):  scale = gamma * rsqrt(var + eps), shift = beta - mean * scale
 int launch_norm_finalize(boa_ctx* ctx, const float* partials, int nblk, int N, int C, double count,

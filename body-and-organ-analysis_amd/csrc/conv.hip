@@ -79,68 +79,79 @@ static int conv_variant_override() {
 //   variant 0 (k_conv_mfma): MFMA and staging serialised inside a block, partly hidden by the second block on the CU.
 bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
     const int dims[3] = {g.Do, g.Ho, g.Wo};
-    int w[3];
-    w[2] = std::min(32, next_pow2(dims[2]));
-    w[1] = std::min(32 / w[2], next_pow2(dims[1]));
-    w[0] = 32 / (w[2] * w[1]);
     const int taps = g.k[0] * g.k[1] * g.k[2];
+    const int ncc = g.Cin / 16;
     double best_cost = 1e30;
     bool found = false;
     const int force = conv_variant_override();
-    for (int variant : {1, 0}) {
-        if (force >= 0 && variant != force) continue;
-        for (int R : {4, 2, 1}) {
-            const int M = 4 * R;
-            for (int b0 = 1; b0 <= M; b0 *= 2)
-                for (int b1 = 1; b0 * b1 <= M; b1 *= 2) {
-                    int b2 = M / (b0 * b1);
-                    if (b0 * b1 * b2 != M) continue;
-                    int b[3] = {b0, b1, b2};
-                    int h[3], tl[3];
-                    long long HV = 1, covered = 1, tiles = 1;
-                    for (int d = 0; d < 3; ++d) {
-                        int ext = b[d] * w[d];
-                        h[d] = (ext - 1) * g.s[d] + g.k[d];
-                        tl[d] = ceil_div(dims[d], ext);
-                        HV *= h[d];
-                        covered *= (long long)tl[d] * ext;
-                        tiles *= tl[d];
-                    }
-                    if (variant == 1 && !conv_ws_supported(g.k, (int)HV)) continue;
-                    const int ncc = g.Cin / 16;
-                    size_t lds = variant == 1 ? conv_ws_lds_bytes((int)HV, taps, ncc, g.Cout) : conv_lds_bytes((int)HV, taps);
-                    if (lds > 160 * 1024) continue;
-                    const long long nblocks = tiles * (g.Cout / 32) * g.N;
-                    const double valid = (double)dims[0] * dims[1] * dims[2];
-                    const double waste = (double)covered / valid;
-                    const double t_mfma = (double)taps * R * 32.0;
-                    double items = (2.0 * HV + taps * 64.0) / 256.0;
-                    double t_chunk, slots;
-                    if (variant == 1) {
-                        if (conv_ws_resident((int)HV, taps, ncc, g.Cout)) items = 2.0 * HV / 256.0;
-                        t_chunk = std::max(t_mfma * 1.1, items * 130.0) + 400.0;
-                        slots = cu_count;
-                    } else {
-                        const int bpc = lds <= 78 * 1024 ? 2 : 1;
-                        t_chunk = (t_mfma + items * 200.0 + 400.0) / (bpc == 2 ? 1.6 : 1.0);
-                        slots = cu_count;
-                    }
-                    const double rounds = std::ceil((double)nblocks / slots);  // quantisation on a part-filled chip
-                    const double cost = t_chunk * rounds * waste / (double)(M) * ((double)slots / (double)nblocks);
-                    if (cost < best_cost) {
-                        best_cost = cost;
-                        found = true;
-                        out->variant = variant;
-                        out->R = R;
-                        for (int d = 0; d < 3; ++d) {
-                            out->w[d] = w[d];
-                            out->b[d] = b[d];
-                            out->h[d] = h[d];
-                            out->tiles[d] = tl[d];
+    // wave M-tile shapes: 32 voxels = w0 x w1 x w2 (powers of two), contiguous axis as long as possible first
+    for (int w2 = 32; w2 >= 4; w2 >>= 1) {
+        if (w2 > next_pow2(dims[2])) continue;
+        for (int w1 = 1; w1 * w2 <= 32; w1 <<= 1) {
+            const int w0 = 32 / (w2 * w1);
+            if (w1 > next_pow2(dims[1]) || w0 > next_pow2(dims[0])) continue;
+            const int w[3] = {w0, w1, w2};
+            for (int variant : {1, 0}) {
+                if (force >= 0 && variant != force) continue;
+                for (int R : {4, 2, 1}) {
+                    const int M = 4 * R;
+                    for (int b0 = 1; b0 <= M; b0 *= 2)
+                        for (int b1 = 1; b0 * b1 <= M; b1 *= 2) {
+                            const int b2 = M / (b0 * b1);
+                            if (b0 * b1 * b2 != M) continue;
+                            const int b[3] = {b0, b1, b2};
+                            int h[3], tl[3];
+                            long long HV = 1, covered = 1, tiles = 1;
+                            for (int d = 0; d < 3; ++d) {
+                                const int ext = b[d] * w[d];
+                                h[d] = (ext - 1) * g.s[d] + g.k[d];
+                                tl[d] = ceil_div(dims[d], ext);
+                                HV *= h[d];
+                                covered *= (long long)tl[d] * ext;
+                                tiles *= tl[d];
+                            }
+                            if (variant == 1 && !conv_ws_supported(g.k, (int)HV)) continue;
+                            const size_t lds = variant == 1 ? conv_ws_lds_bytes((int)HV, taps, ncc, g.Cout)
+                                                            : conv_lds_bytes((int)HV, taps);
+                            if (lds > 160 * 1024) continue;
+                            const long long nblocks = tiles * (g.Cout / 32) * g.N;
+                            const double valid = (double)dims[0] * dims[1] * dims[2];
+                            const double waste = (double)covered / valid;
+                            // LDS fragment reads are conflict-free when a wave row is contiguous (w2 lanes at the
+                            // stride of the conv); short rows / strided rows cost extra LDS cycles
+                            const double lds_pen = (g.s[2] > 1 ? 1.25 : 1.0) * (w2 < 16 ? 1.15 : 1.0);
+                            const double t_mfma = (double)taps * R * 32.0 * lds_pen;
+                            double t_chunk;
+                            const double slots = cu_count;
+                            if (variant == 1) {
+                                const bool res = conv_ws_resident((int)HV, taps, ncc, g.Cout);
+                                const double t_prod = (double)HV / 256.0 * 350.0 + (res ? 0.0 : taps * 64.0 / 256.0 * 60.0) + 700.0;
+                                t_chunk = std::max(t_mfma * 1.15, t_prod) + 500.0;
+                            } else {
+                                const double items = (2.0 * HV + taps * 64.0) / 256.0;
+                                const int bpc = lds <= 78 * 1024 ? 2 : 1;
+                                t_chunk = (taps * R * 200.0 + items * 1500.0 + 400.0) / (bpc == 2 ? 1.8 : 1.0);
+                            }
+                            // epilogue + tile turnaround amortised over the chunks of a tile
+                            const double t_tile = t_chunk * ncc + (variant == 1 ? 3000.0 : 6000.0);
+                            const double rounds = std::ceil((double)nblocks / slots);
+                            const double cost = t_tile * rounds * waste / (double)M * (slots / (double)nblocks);
+                            if (cost < best_cost) {
+                                best_cost = cost;
+                                found = true;
+                                out->variant = variant;
+                                out->R = R;
+                                for (int d = 0; d < 3; ++d) {
+                                    out->w[d] = w[d];
+                                    out->b[d] = b[d];
+                                    out->h[d] = h[d];
+                                    out->tiles[d] = tl[d];
+                                }
+                                out->lds_bytes = lds;
+                            }
                         }
-                        out->lds_bytes = lds;
-                    }
                 }
+            }
         }
     }
     return found;
@@ -398,14 +409,39 @@ int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const Con
 
 // ======================================================================================================
 // first conv: fp32 VALU, tiles gathered from the resident volume
+// Stage 1: k_gather_patches copies the N tiles out of the resident volume into a zero-padded dense fp32 buffer
+// [N][Cin][PX][PY][PZ] (conv padding + pad_nd_image zeros + tile overhang), so that stage 2 has no bounds logic.
+// Stage 2: k_conv_first<K0,K1,K2>: each thread computes FV consecutive voxels along the contiguous axis x 32 output
+// channels, so one LDS read of a weight quad feeds 4 * FV FMAs and one input value feeds up to 3 taps x 32
+// channels.  Weights live in LDS ([Cin][tap][32] floats, broadcast reads); a block covers FT0 x FT1 x FT2 voxels.
 #define FT0 4
 #define FT1 4
-#define FT2 16
+#define FT2 64
+#define FV 4
+
+__global__ __launch_bounds__(256) void k_gather_patches(const float* __restrict__ vol, const int* __restrict__ origins,
+                                                        int V0, int V1, int V2, int o0, int o1, int o2, int Cin, int P0,
+                                                        int P1, int P2, int pad0, int pad1, int pad2, int PX, int PY, int PZ,
+                                                        float* __restrict__ out) {
+    const int n = blockIdx.z, ci = blockIdx.y;
+    const size_t pvol = (size_t)PX * PY * PZ;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pvol) return;
+    const int z = (int)(i % PZ), y = (int)((i / PZ) % PY), x = (int)(i / ((size_t)PZ * PY));
+    const int px = x - pad0, py = y - pad1, pz = z - pad2;  // patch coordinates
+    float v = 0.f;
+    if (px >= 0 && px < P0 && py >= 0 && py < P1 && pz >= 0 && pz < P2) {
+        const int vx = origins[n * 3 + 0] + px - o0, vy = origins[n * 3 + 1] + py - o1, vz = origins[n * 3 + 2] + pz - o2;
+        if (vx >= 0 && vx < V0 && vy >= 0 && vy < V1 && vz >= 0 && vz < V2)
+            v = vol[(size_t)ci * V0 * V1 * V2 + ((size_t)vx * V1 + vy) * V2 + vz];
+    }
+    out[((size_t)n * Cin + ci) * pvol + i] = v;
+}
+
 struct FirstArgs {
-    const float* vol;
-    const int* origins;
-    int V0, V1, V2, o0, o1, o2;  // volume dims and position of the volume inside the padded grid
-    int N, Cin, P0, P1, P2, k0, k1, k2, Cout;
+    const float* padded;  // [N][Cin][PX][PY][PZ]
+    int PX, PY, PZ;
+    int N, Cin, P0, P1, P2, Cout;
     const float* w;  // [Cin][taps][Cout]
     const float* bias;
     __half* out;
@@ -413,6 +449,7 @@ struct FirstArgs {
     int t0, t1, t2;
 };
 
+template <int K0, int K1, int K2>
 __global__ __launch_bounds__(256) void k_conv_first(FirstArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -423,87 +460,122 @@ __global__ __launch_bounds__(256) void k_conv_first(FirstArgs p) {
     bt /= p.t2;
     const int ty = bt % p.t1;
     const int tx = bt / p.t1;
-    const int pad0 = (p.k0 - 1) / 2, pad1 = (p.k1 - 1) / 2, pad2 = (p.k2 - 1) / 2;
-    const int h0 = FT0 + p.k0 - 1, h1 = FT1 + p.k1 - 1, h2 = FT2 + p.k2 - 1;
-    const int HV = h0 * h1 * h2;
-    float* lds_in = (float*)smem;  // [Cin][HV]
-    float* lds_red = lds_in + p.Cin * HV;
-    const int org0 = p.origins[n * 3 + 0], org1 = p.origins[n * 3 + 1], org2 = p.origins[n * 3 + 2];
-    const int x0 = tx * FT0 - pad0, y0 = ty * FT1 - pad1, z0 = tz * FT2 - pad2;  // tile-local halo origin
-    const size_t vv = (size_t)p.V0 * p.V1 * p.V2;
-    for (int i = tid; i < p.Cin * HV; i += 256) {
-        int ci = i / HV;
-        int v = i % HV;
-        int hz = v % h2;
-        int t = v / h2;
-        int hy = t % h1;
-        int hx = t / h1;
-        int px = x0 + hx, py = y0 + hy, pz = z0 + hz;  // patch coordinates
-        float val = 0.f;
-        if (px >= 0 && px < p.P0 && py >= 0 && py < p.P1 && pz >= 0 && pz < p.P2) {
-            int vx = org0 + px - p.o0, vy = org1 + py - p.o1, vz = org2 + pz - p.o2;  // volume coordinates
-            if (vx >= 0 && vx < p.V0 && vy >= 0 && vy < p.V1 && vz >= 0 && vz < p.V2)
-                val = p.vol[(size_t)ci * vv + ((size_t)vx * p.V1 + vy) * p.V2 + vz];
+    constexpr int h0 = FT0 + K0 - 1, h1 = FT1 + K1 - 1, h2 = FT2 + K2 - 1;
+    constexpr int HV = h0 * h1 * h2;
+    constexpr int taps = K0 * K1 * K2;
+    float* lds_w = (float*)smem;                // [Cin][taps][32]
+    float* lds_in = lds_w + p.Cin * taps * 32;  // [Cin][HV]
+    float* lds_red = lds_in + ((p.Cin * HV + 3) & ~3);
+    for (int i = tid; i < p.Cin * taps * 32; i += 256) lds_w[i] = p.w[(size_t)(i >> 5) * p.Cout + cout0 + (i & 31)];
+    {
+        // halo tile from the padded buffer: always in bounds, compile-time index arithmetic, 4 loads in flight
+        const size_t pvol = (size_t)p.PX * p.PY * p.PZ;
+        const float* src = p.padded + (size_t)n * p.Cin * pvol;
+        const int total = p.Cin * HV;
+        for (int i0 = tid; i0 < total; i0 += 256 * 4) {
+            float v[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = min(i0 + b * 256, total - 1);
+                const int ci = i / HV, r = i % HV;
+                const int hz = r % h2, hy = (r / h2) % h1, hx = r / (h2 * h1);
+                v[b] = src[(size_t)ci * pvol + ((size_t)(tx * FT0 + hx) * p.PY + (ty * FT1 + hy)) * p.PZ + tz * FT2 + hz];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) lds_in[min(i0 + b * 256, total - 1)] = v[b];
         }
-        lds_in[i] = val;
     }
     __syncthreads();
-    const int lz = tid % FT2;
-    const int ly = (tid / FT2) % FT1;
-    const int lx = tid / (FT2 * FT1);
+    const int lzq = tid % (FT2 / FV);
+    const int ly = (tid / (FT2 / FV)) % FT1;
+    const int lx = tid / ((FT2 / FV) * FT1);
+    const int lz = lzq * FV;
     const int ox = tx * FT0 + lx, oy = ty * FT1 + ly, oz = tz * FT2 + lz;
-    const bool valid = ox < p.P0 && oy < p.P1 && oz < p.P2;
-    float acc[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = p.bias[cout0 + c];
-    const int taps = p.k0 * p.k1 * p.k2;
-    for (int ci = 0; ci < p.Cin; ++ci) {
-        int tap = 0;
-        for (int dx = 0; dx < p.k0; ++dx)
-            for (int dy = 0; dy < p.k1; ++dy)
-                for (int dz = 0; dz < p.k2; ++dz, ++tap) {
-                    float x = lds_in[ci * HV + ((lx + dx) * h1 + (ly + dy)) * h2 + lz + dz];
-                    const float* wr = p.w + ((size_t)ci * taps + tap) * p.Cout + cout0;  // wave-uniform -> scalar loads
-#pragma unroll
-                    for (int c = 0; c < 32; ++c) acc[c] = __builtin_fmaf(x, wr[c], acc[c]);
-                }
-    }
-    float s[32], q[32];
-    if (valid) {
-        __half* op = p.out + (((size_t)n * p.P0 + ox) * p.P1 + oy) * (size_t)p.P2 * p.Cout + (size_t)oz * p.Cout + cout0;
-        union {
-            uint4 u[4];
-            __half h[32];
-        } pk;
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            __half hv = __float2half_rn(acc[c]);
-            pk.h[c] = hv;
-            float vr = __half2float(hv);
-            s[c] = vr;
-            q[c] = vr * vr;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ((uint4*)op)[j] = pk.u[j];
-    } else {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) s[c] = q[c] = 0.f;
-    }
+    float acc[FV][32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
+        const float b = p.bias[cout0 + c];
 #pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            s[c] += __shfl_xor(s[c], m);
-            q[c] += __shfl_xor(q[c], m);
+        for (int v = 0; v < FV; ++v) acc[v][c] = b;
+    }
+    // The weight reads are wave-uniform; hipcc would scalarise all 27 x 32 of them (v_readfirstlane into SGPRs,
+    // ~2700 SGPR spills, occupancy 1).  A lane-opaque zero keeps them as plain broadcast LDS reads.
+    int lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));
+    for (int ci = 0; ci < p.Cin; ++ci) {
+        for (int dx = 0; dx < K0; ++dx)
+            for (int dy = 0; dy < K1; ++dy) {
+                const float* row = lds_in + ci * HV + ((lx + dx) * h1 + (ly + dy)) * h2 + lz;
+                float xin[FV + K2 - 1];
+#pragma unroll
+                for (int j = 0; j < FV + K2 - 1; ++j) xin[j] = row[j];
+                const float* wrow = lds_w + ((ci * taps) + (dx * K1 + dy) * K2) * 32 + lane_zero;
+#pragma unroll
+                for (int dz = 0; dz < K2; ++dz) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 8; ++c4) {
+                        const float4 w4 = *(const float4*)(wrow + dz * 32 + c4 * 4);  // broadcast read
+#pragma unroll
+                        for (int v = 0; v < FV; ++v) {
+                            acc[v][c4 * 4 + 0] = __builtin_fmaf(xin[v + dz], w4.x, acc[v][c4 * 4 + 0]);
+                            acc[v][c4 * 4 + 1] = __builtin_fmaf(xin[v + dz], w4.y, acc[v][c4 * 4 + 1]);
+                            acc[v][c4 * 4 + 2] = __builtin_fmaf(xin[v + dz], w4.z, acc[v][c4 * 4 + 2]);
+                            acc[v][c4 * 4 + 3] = __builtin_fmaf(xin[v + dz], w4.w, acc[v][c4 * 4 + 3]);
+                        }
+                    }
+                }
+            }
+    }
+    float s[32], q[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s[c] = q[c] = 0.f;
+#pragma unroll
+    for (int v = 0; v < FV; ++v) {
+        if (ox < p.P0 && oy < p.P1 && oz + v < p.P2) {
+            __half* op = p.out + (((size_t)n * p.P0 + ox) * p.P1 + oy) * (size_t)p.P2 * p.Cout + (size_t)(oz + v) * p.Cout + cout0;
+            union {
+                uint4 u[4];
+                __half h[32];
+            } pk;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                __half hv = __float2half_rn(acc[v][c]);
+                pk.h[c] = hv;
+                float vr = __half2float(hv);
+                s[c] += vr;
+                q[c] = __builtin_fmaf(vr, vr, q[c]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ((uint4*)op)[j] = pk.u[j];
         }
     }
+    // recursive-halving reduction over the wave: after step m a lane keeps half of its channels, summed with its
+    // partner's copy; 16 + 8 + ... shuffles per quantity instead of 6 x 32.  Lane l ends up owning channel
+    // 16*b0 + 8*b1 + 4*b2 + 2*b3 + b4 (b_i = bit i of the lane id).
+    const int lane_ = tid & 63;
+#define HALVE_STEP(M, HALF)                                                                  \
+    {                                                                                        \
+        const bool up = (lane_ & (M)) != 0;                                                  \
+        _Pragma("unroll") for (int i = 0; i < (HALF); ++i) {                                 \
+            const float ks = up ? s[i + (HALF)] : s[i], ss_ = up ? s[i] : s[i + (HALF)];     \
+            const float kq = up ? q[i + (HALF)] : q[i], sq_ = up ? q[i] : q[i + (HALF)];     \
+            s[i] = ks + __shfl_xor(ss_, (M));                                                \
+            q[i] = kq + __shfl_xor(sq_, (M));                                                \
+        }                                                                                    \
+    }
+    HALVE_STEP(1, 16)
+    HALVE_STEP(2, 8)
+    HALVE_STEP(4, 4)
+    HALVE_STEP(8, 2)
+    HALVE_STEP(16, 1)
+#undef HALVE_STEP
+    s[0] += __shfl_xor(s[0], 32);
+    q[0] += __shfl_xor(q[0], 32);
     const int wave = tid >> 6;
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            lds_red[(wave * 32 + c) * 2 + 0] = s[c];
-            lds_red[(wave * 32 + c) * 2 + 1] = q[c];
-        }
+    if (lane_ < 32) {
+        const int c = ((lane_ & 1) << 4) | ((lane_ & 2) << 2) | (lane_ & 4) | ((lane_ & 8) >> 2) | ((lane_ & 16) >> 4);
+        lds_red[(wave * 32 + c) * 2 + 0] = s[0];
+        lds_red[(wave * 32 + c) * 2 + 1] = q[0];
     }
     __syncthreads();
     if (tid < 64) {
@@ -517,25 +589,41 @@ __global__ __launch_bounds__(256) void k_conv_first(FirstArgs p) {
 
 int conv_first_nblk(const int P[3]) { return ceil_div(P[0], FT0) * ceil_div(P[1], FT1) * ceil_div(P[2], FT2); }
 
+// dims of the zero-padded gather buffer for a patch P and kernel k
+void conv_first_padded_dims(const int P[3], const int k[3], int out[3]) {
+    const int ft[3] = {FT0, FT1, FT2};
+    for (int a = 0; a < 3; ++a) out[a] = ceil_div(P[a], ft[a]) * ft[a] + (k[a] - 1);
+}
+
 int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins,
                       int N, int Cin, const int P[3], const int k[3], int Cout, const float* w, const float* bias,
-                      __half* out, float* partials, int* nblk_out) {
+                      float* padded_scratch, __half* out, float* partials, int* nblk_out) {
     BOA_REQUIRE(Cout % 32 == 0, "first conv: Cout=%d must be a multiple of 32", Cout);
-    BOA_REQUIRE(Cin >= 1 && Cin <= 8, "first conv: Cin=%d unsupported (1..8)", Cin);
-    FirstArgs a;
-    a.vol = volume; a.origins = dev_origins;
-    a.V0 = V[0]; a.V1 = V[1]; a.V2 = V[2];
-    a.o0 = vol_off ? vol_off[0] : 0; a.o1 = vol_off ? vol_off[1] : 0; a.o2 = vol_off ? vol_off[2] : 0;
-    a.N = N; a.Cin = Cin; a.P0 = P[0]; a.P1 = P[1]; a.P2 = P[2]; a.k0 = k[0]; a.k1 = k[1]; a.k2 = k[2]; a.Cout = Cout;
-    a.w = w; a.bias = bias; a.out = out; a.partials = partials;
-    a.t0 = ceil_div(P[0], FT0); a.t1 = ceil_div(P[1], FT1); a.t2 = ceil_div(P[2], FT2);
-    int nblk = a.t0 * a.t1 * a.t2;
-    if (nblk_out) *nblk_out = nblk;
-    int HV = (FT0 + k[0] - 1) * (FT1 + k[1] - 1) * (FT2 + k[2] - 1);
-    size_t lds = (size_t)Cin * HV * 4 + 1024;
+    BOA_REQUIRE(Cin >= 1 && Cin <= 4, "first conv: Cin=%d unsupported (1..4)", Cin);
+    const bool k333 = k[0] == 3 && k[1] == 3 && k[2] == 3, k133 = k[0] == 1 && k[1] == 3 && k[2] == 3;
+    BOA_REQUIRE(k333 || k133, "first conv: kernel %dx%dx%d not instantiated", k[0], k[1], k[2]);
+    int PD[3];
+    conv_first_padded_dims(P, k, PD);
+    const size_t pvol = (size_t)PD[0] * PD[1] * PD[2];
     const double vox = (double)N * P[0] * P[1] * P[2];
     KernelTimer tm(ctx, BOA_K_CONV_FIRST, 2.0 * vox * k[0] * k[1] * k[2] * Cin * Cout, vox * (4.0 * Cin + 2.0 * Cout));
-    hipLaunchKernelGGL(k_conv_first, dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)((pvol + 255) / 256), Cin, N), dim3(256), 0, ctx->stream, volume,
+                       dev_origins, V[0], V[1], V[2], vol_off ? vol_off[0] : 0, vol_off ? vol_off[1] : 0,
+                       vol_off ? vol_off[2] : 0, Cin, P[0], P[1], P[2], (k[0] - 1) / 2, (k[1] - 1) / 2, (k[2] - 1) / 2, PD[0],
+                       PD[1], PD[2], padded_scratch);
+    FirstArgs a;
+    a.padded = padded_scratch; a.PX = PD[0]; a.PY = PD[1]; a.PZ = PD[2];
+    a.N = N; a.Cin = Cin; a.P0 = P[0]; a.P1 = P[1]; a.P2 = P[2]; a.Cout = Cout;
+    a.w = w; a.bias = bias; a.out = out; a.partials = partials;
+    a.t0 = ceil_div(P[0], FT0); a.t1 = ceil_div(P[1], FT1); a.t2 = ceil_div(P[2], FT2);
+    const int nblk = a.t0 * a.t1 * a.t2;
+    if (nblk_out) *nblk_out = nblk;
+    const int HV = (FT0 + k[0] - 1) * (FT1 + k[1] - 1) * (FT2 + k[2] - 1);
+    const size_t lds = ((size_t)Cin * k[0] * k[1] * k[2] * 32 + (((size_t)Cin * HV + 3) & ~(size_t)3)) * 4 + 1024;
+    if (k333)
+        hipLaunchKernelGGL((k_conv_first<3, 3, 3>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_conv_first<1, 3, 3>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
@@ -543,15 +631,16 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
 
 // ======================================================================================================
 // InstanceNorm finalize: deterministic fp64 reduction of the per-block partials
-__global__ __launch_bounds__(64) void k_norm_finalize(const float* __restrict__ partials, int nblk, int C, double count,
+__global__ __launch_bounds__(256) void k_norm_finalize(const float* __restrict__ partials, int nblk, int C, double count,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, float* __restrict__ ss,
                                                       unsigned short* __restrict__ ss16) {
     const int c = blockIdx.x, n = blockIdx.y;
     const float* ps = partials + (((size_t)n * C + c) * 2 + 0) * nblk;
     const float* pq = partials + (((size_t)n * C + c) * 2 + 1) * nblk;
+    __shared__ double red[8];
     double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 64) {
+    for (int i = threadIdx.x; i < nblk; i += 256) {
         s += (double)ps[i];
         q += (double)pq[i];
     }
@@ -560,7 +649,14 @@ __global__ __launch_bounds__(64) void k_norm_finalize(const float* __restrict__ 
         s += __shfl_xor(s, m);
         q += __shfl_xor(q, m);
     }
+    if ((threadIdx.x & 63) == 0) {
+        red[(threadIdx.x >> 6) * 2] = s;
+        red[(threadIdx.x >> 6) * 2 + 1] = q;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        s = (red[0] + red[2]) + (red[4] + red[6]);  // fixed order: deterministic
+        q = (red[1] + red[3]) + (red[5] + red[7]);
         double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -580,7 +676,7 @@ __global__ __launch_bounds__(64) void k_norm_finalize(const float* __restrict__ 
 int launch_norm_finalize(boa_ctx* ctx, const float* partials, int nblk, int N, int C, double count,
                          const float* gamma, const float* beta, float eps, float* ss_out, unsigned* ss16_out) {
     KernelTimer tm(ctx, BOA_K_NORM_FINALIZE, 0, (double)N * C * nblk * 8.0);
-    hipLaunchKernelGGL(k_norm_finalize, dim3(C, N), dim3(64), 0, ctx->stream, partials, nblk, C, count, gamma, beta,
+    hipLaunchKernelGGL(k_norm_finalize, dim3(C, N), dim3(256), 0, ctx->stream, partials, nblk, C, count, gamma, beta,
                        eps, ss_out, (unsigned short*)ss16_out);
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
@@ -609,65 +705,97 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     const int ncc = p.Cin / 16;
     const size_t in_vox = (size_t)p.Di * p.Hi * p.Wi;
     const size_t total = (size_t)p.N * in_vox;
-    unsigned char* lds = smem + (size_t)wave * ncc * 1024;  // [cc][khalf][32 voxels][8 halves]
+    unsigned char* lds = smem + (size_t)wave * (ncc * 1024 + 32 * 80);  // [cc][khalf][32 voxels][8 halves] + slab
+    unsigned char* slab = lds + ncc * 1024;
     const size_t g = ((size_t)blockIdx.x * 4 + wave) * 32 + l31;  // flattened (n, voxel)
     const bool valid = g < total;
     const int n = valid ? (int)(g / in_vox) : 0;
     const size_t vi = valid ? g % in_vox : 0;
-    // stage this wave's 32 voxels: lane (l31, kh) moves octet kh of every 16-channel chunk
-    for (int cc = 0; cc < ncc; ++cc) {
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (valid) {
-            int cg = cc * 16 + kh * 8;
-            val = *(const uint4*)(p.src + ((size_t)n * in_vox + vi) * p.Cin + cg);
+    // stage this wave's 32 voxels: lane (l31, kh) moves octet kh of every 16-channel chunk; loads batched by 4
+    for (int c0 = 0; c0 < ncc; c0 += 4) {
+        uint4 val[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int cc = min(c0 + b, ncc - 1);
+            val[b] = *(const uint4*)(p.src + ((size_t)n * in_vox + vi) * p.Cin + cc * 16 + kh * 8);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int cc = min(c0 + b, ncc - 1);
+            uint4 o = val[b];
             if (p.ss) {
                 float sc[8], sh[8];
-                const float* ss = p.ss + ((size_t)n * p.Cin + cg) * 2;
+                const float* ss = p.ss + ((size_t)n * p.Cin + cc * 16 + kh * 8) * 2;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     sc[j] = ss[2 * j];
                     sh[j] = ss[2 * j + 1];
                 }
-                val = norm_act8(val, sc, sh, p.slope);
+                o = norm_act8(o, sc, sh, p.slope);
             }
+            if (!valid) o = make_uint4(0, 0, 0, 0);
+            *(uint4*)(lds + ((cc * 2 + kh) * 32 + l31) * 16) = o;
         }
-        *(uint4*)(lds + ((cc * 2 + kh) * 32 + l31) * 16) = val;
     }
-    __syncthreads();
-    const int iz = (int)(vi % p.Wi);
-    const int iy = (int)((vi / p.Wi) % p.Hi);
-    const int ix = (int)(vi / ((size_t)p.Wi * p.Hi));
+    __builtin_amdgcn_wave_barrier();
     const int Do = p.Di * p.s0, Ho = p.Hi * p.s1, Wo = p.Wi * p.s2;
     const int taps = p.s0 * p.s1 * p.s2;
     const int nco = p.Cout / 32;
-    for (int tap = 0; tap < taps; ++tap) {
+    const int npairs = taps * nco;
+    // after the slab transpose this lane stores couts [8 sq, 8 sq + 8) of input voxels sv and sv + 16 of the wave
+    const int sv = lane >> 2, sq = lane & 3;
+    size_t obase[2];
+    bool ovalid[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const size_t gg = ((size_t)blockIdx.x * 4 + wave) * 32 + sv + 16 * half;
+        ovalid[half] = gg < total;
+        const int nn = ovalid[half] ? (int)(gg / in_vox) : 0;
+        const size_t v2 = ovalid[half] ? gg % in_vox : 0;
+        const int iz = (int)(v2 % p.Wi), iy = (int)((v2 / p.Wi) % p.Hi), ix = (int)(v2 / ((size_t)p.Wi * p.Hi));
+        obase[half] = (size_t)nn * Do * Ho * Wo + ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2);
+    }
+    for (int pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
+        const int tap = pr / nco, co = pr - tap * nco;
         const int tz = tap % p.s2, ty = (tap / p.s2) % p.s1, tx = tap / (p.s2 * p.s1);
-        const size_t ovox = ((size_t)(ix * p.s0 + tx) * Ho + (iy * p.s1 + ty)) * Wo + (iz * p.s2 + tz);
-        for (int co = 0; co < nco; ++co) {
-            f32x16 acc;
+        f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            const __half* wb = p.wpk + (((size_t)tap * ncc * 2 + kh) * p.Cout + co * 32 + l31) * 8;
-            for (int cc = 0; cc < ncc; ++cc) {
-                f16x8 a = *(const f16x8*)(wb + (size_t)cc * 2 * p.Cout * 8);
-                f16x8 b = *(const f16x8*)(lds + ((cc * 2 + kh) * 32 + l31) * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
-            }
-            if (valid) {
-                __half* op = p.out + ((size_t)n * Do * Ho * Wo + ovox) * p.Cout + co * 32 + 4 * kh;
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const __half* wb = p.wpk + (((size_t)tap * ncc * 2 + kh) * p.Cout + co * 32 + l31) * 8;
+        for (int c0 = 0; c0 < ncc; c0 += 4) {
+            f16x8 a[4];
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    union {
-                        uint2 u;
-                        __half h[4];
-                    } pk;
+            for (int b = 0; b < 4; ++b) a[b] = *(const f16x8*)(wb + (size_t)min(c0 + b, ncc - 1) * 2 * p.Cout * 8);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        pk.h[j] = __float2half_rn(acc[gq * 4 + j] + p.bias[co * 32 + 8 * gq + 4 * kh + j]);
-                    *(uint2*)(op + 8 * gq) = pk.u;
+            for (int b = 0; b < 4; ++b) {
+                if (c0 + b < ncc) {
+                    f16x8 bf = *(const f16x8*)(lds + (((c0 + b) * 2 + kh) * 32 + l31) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[b], bf, acc, 0, 0, 0);
                 }
             }
         }
+        // + bias, fp16, transpose through the slab, 16-byte stores of whole 64-byte channel groups
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 bq = *(const float4*)(p.bias + co * 32 + 8 * gq + 4 * kh);
+            union {
+                uint2 u;
+                __half h[4];
+            } pk;
+            pk.h[0] = __float2half_rn(acc[gq * 4 + 0] + bq.x);
+            pk.h[1] = __float2half_rn(acc[gq * 4 + 1] + bq.y);
+            pk.h[2] = __float2half_rn(acc[gq * 4 + 2] + bq.z);
+            pk.h[3] = __float2half_rn(acc[gq * 4 + 3] + bq.w);
+            *(uint2*)(slab + l31 * 80 + (8 * gq + 4 * kh) * 2) = pk.u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const size_t toff = ((size_t)tx * Ho + ty) * Wo + tz;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint4 d = *(const uint4*)(slab + (sv + 16 * half) * 80 + sq * 16);
+            if (ovalid[half]) *(uint4*)(p.out + (obase[half] + toff) * p.Cout + co * 32 + sq * 8) = d;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -679,13 +807,18 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
     a.Di = din[0]; a.Hi = din[1]; a.Wi = din[2]; a.s0 = s[0]; a.s1 = s[1]; a.s2 = s[2];
     a.wpk = wpk; a.bias = bias; a.out = out; a.slope = slope;
     size_t total = (size_t)N * din[0] * din[1] * din[2];
-    int grid = (int)((total + 127) / 128);
-    size_t lds = (size_t)4 * (src.C / 16) * 1024;
+    int gx = (int)((total + 127) / 128);
+    // split the (tap, cout-chunk) pairs over gridDim.y only as far as needed to fill the chip: every y-slice
+    // re-stages the block's input voxels
+    const int npairs = s[0] * s[1] * s[2] * (Cout / 32);
+    int gy = std::min(npairs, std::max(1, ceil_div(2 * ctx->cu_count, gx)));
+    size_t lds = (size_t)4 * ((src.C / 16) * 1024 + 32 * 80);
+    BOA_REQUIRE(lds <= 160 * 1024, "convT: Cin=%d needs %zu bytes of LDS", src.C, lds);
     static bool once = (hipFuncSetAttribute((const void*)k_convt_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
     const double taps = (double)s[0] * s[1] * s[2];
     KernelTimer tm(ctx, BOA_K_CONVT, 2.0 * total * taps * src.C * Cout, 2.0 * total * (src.C + taps * Cout));
-    hipLaunchKernelGGL(k_convt_mfma, dim3(grid), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k_convt_mfma, dim3(gx, gy), dim3(256), lds, ctx->stream, a);
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

@@ -50,7 +50,7 @@ struct boa_net {
     std::vector<std::vector<ConvLayer>> dec;  // [d][conv]
     float *head_w = nullptr, *head_b = nullptr;
     int* dev_origins = nullptr;
-    float* ident_ss = nullptr;
+    float* first_padded = nullptr;  // zero-padded fp32 gather buffer of the first conv
     std::vector<void*> allocs;
     int dims[BOA_MAX_STAGES][3];
 };
@@ -276,6 +276,13 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
     if ((rc = net_alloc(net, (size_t)d.num_classes * d.features[0] * sizeof(float), (void**)&net->head_w))) return fail(rc);
     if ((rc = net_alloc(net, d.num_classes * sizeof(float), (void**)&net->head_b))) return fail(rc);
     if ((rc = net_alloc(net, (size_t)max_batch * 3 * sizeof(int), (void**)&net->dev_origins))) return fail(rc);
+    {
+        int PD[3];
+        conv_first_padded_dims(d.patch, d.kernel[0], PD);
+        if ((rc = net_alloc(net, (size_t)max_batch * d.in_channels * PD[0] * PD[1] * PD[2] * sizeof(float),
+                            (void**)&net->first_padded)))
+            return fail(rc);
+    }
     if (host_weights) {
         rc = boa_net_load_weights(net, host_weights, n_floats);
         if (rc) return fail(rc);
@@ -317,7 +324,7 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
         if (L.first) {
             int nblk = 0;
             BOA_TRY(launch_conv_first(c, volume, V, vol_off, net->dev_origins, N, d.in_channels, d.patch, L.g.k, L.g.Cout,
-                                      L.wfirst, L.bias, L.out, L.partials, &nblk));
+                                      L.wfirst, L.bias, net->first_padded, L.out, L.partials, &nblk));
         } else {
             BOA_TRY(launch_conv_mfma(c, a, b, g, L.t, L.wpk, L.bias, d.lrelu_slope, L.out, L.partials));
         }
