@@ -1,0 +1,224 @@
+"""Body-composition aggregation on the device (host side).
+
+Mirrors the numeric part of the reference's BCA pipeline for arrays already in SimpleITK order (z, y, x):
+  BCA/tissue/subclassification.py:10-63   subclassify_tissues           -> boa_tissue_aggregate (fused)
+  BCA/report/builder.py:397-444           slice-wise tissue volumes      -> per-slice counts from the same pass
+  BCA/report/builder.py:44-112            AggregatableBodyPart.from_body_regions
+  BCA/report/builder.py:163-307           aggregation groups + descriptive statistics + mean HU per tissue
+  BCA/report/builder.py:520-598           create_json (numeric content of bca-measurements.json)
+  BCA/body_regions/postprocess.py:8-40    largest-connected-component filters (boa_ccl26 + boa_ccl_filter_largest)
+The per-voxel work (one pass over CT + regions + parts, 5 B/voxel) runs in libboa_hip.so; the host only turns
+Z x 2 x 8 integer tables into the tiny DataFrames/dicts the reference produces (pandas `describe()` is called on
+the same per-slice table, so the statistics follow pandas' arithmetic exactly).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from ._lib import check
+from .device import Context, DeviceBuffer
+
+REGION = dict(SUBCUTANEOUS_TISSUE=1, MUSCLE=2, ABDOMINAL_CAVITY=3, THORACIC_CAVITY=4, BONE=5, GLANDS=6, PERICARDIUM=7,
+              BREAST_IMPLANT=8, MEDIASTINUM=9, BRAIN=10, NERVOUS_SYSTEM=11)  # BCA/body_regions/definition.py:4-15
+TISSUES = [("MUSCLE", 1), ("BONE", 2), ("SAT", 3), ("VAT", 4), ("IMAT", 5), ("PAT", 6), ("EAT", 7)]  # tissue/definition.py
+COLS = ["Bone", "Muscle", "TAT", "IMAT", "SAT", "VAT", "PAT", "EAT"]
+_ROW = {"Mean": "mean", "StdDev": "std", "Minimum": "min", "25%": "q1", "Median": "q2", "75%": "q3", "Maximum": "max",
+        "Total": "sum", "MeanHU": "mean_hu"}
+
+
+def _tname(name):
+    return name.capitalize() if name in ("BONE", "MUSCLE") else name
+
+
+class DeviceVolume:
+    """int16 CT / uint8 label volumes resident on the device, (z, y, x)."""
+
+    def __init__(self, ctx: Context, arr: np.ndarray):
+        assert arr.ndim == 3
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in arr.shape)
+        self.dtype = arr.dtype
+        self.buf = ctx.from_numpy(np.ascontiguousarray(arr))
+
+    def free(self):
+        self.buf.free()
+
+
+def tissue_aggregate(ctx: Context, ct: DeviceBuffer, regions: DeviceBuffer, parts: Optional[DeviceBuffer], shape,
+                     want_tissues: bool = True):
+    """One pass: tissues (uint8, optional), counts uint32 [Z,2,8], hu_sums int64 [Z,2,8] ([.,0,.] all voxels,
+    [.,1,.] body_parts == TORSO)."""
+    Z, Y, X = (int(s) for s in shape)
+    tis = ctx.alloc(Z * Y * X) if want_tissues else None
+    cnt = ctx.alloc(Z * 16 * 4)
+    sums = ctx.alloc(Z * 16 * 8)
+    check(ctx.lib.boa_tissue_aggregate(ctx.h, ct.vp, regions.vp, parts.vp if parts else None, tis.vp if tis else None,
+                                       Z, Y, X, cnt.vp, sums.vp), "boa_tissue_aggregate")
+    counts = cnt.download((Z, 2, 8), np.uint32)
+    hu_sums = sums.download((Z, 2, 8), np.int64)
+    cnt.free()
+    sums.free()
+    return tis, counts, hu_sums
+
+
+def slice_label_presence(ctx: Context, labels: DeviceBuffer, shape) -> np.ndarray:
+    Z, Y, X = (int(s) for s in shape)
+    d = ctx.alloc(Z * 256)
+    check(ctx.lib.boa_slice_label_presence(ctx.h, labels.vp, Z, Y, X, d.vp), "boa_slice_label_presence")
+    out = d.download((Z, 256), np.uint8).astype(bool)
+    d.free()
+    return out
+
+
+def examined_body_part(present: np.ndarray, spacing_xyz, min_abdomen=200, min_neck=100, min_thorax=200) -> Dict[str, bool]:
+    """AggregatableBodyPart.from_body_regions (builder.py:44-112) from the per-slice presence table."""
+    thick = spacing_xyz[2]
+    depth = present.shape[0]
+    res = dict(abdomen=False, neck=False, thorax=False)
+    abd = present[:, REGION["ABDOMINAL_CAVITY"]]
+    sl = np.where(abd)[0]
+    n_abd = sl.max() - sl.min() + 1 if sl.size else 0
+    if n_abd * thick >= min_abdomen:
+        res["abdomen"] = True
+    med = np.where(present[:, REGION["MEDIASTINUM"]])[0]
+    n_above = depth - med.max() if med.size else 0
+    if n_above * thick >= min_neck:
+        res["neck"] = True
+    thx = present[:, REGION["THORACIC_CAVITY"]] | present[:, REGION["MEDIASTINUM"]] | present[:, REGION["PERICARDIUM"]]
+    ts = np.where(thx)[0]
+    n_thx = ts.max() - ts.min() + 1 if ts.size else 0
+    if np.logical_and(abd, thx).any() and n_thx * thick >= min_thorax:
+        res["thorax"] = True
+    return res
+
+
+def aggregation_groups(present: np.ndarray, depth: int, parts: Dict[str, bool], vertebrae=None):
+    """Slice ranges of generate_aggregated_measurements (builder.py:170-216)."""
+    def rng(col):
+        s = np.where(col)[0]
+        return int(s.min()), int(s.max()) + 1
+
+    groups = [("Whole Scan", 0, depth)]
+    if parts["abdomen"]:
+        groups.append(("Abdominal Cavity", *rng(present[:, REGION["ABDOMINAL_CAVITY"]])))
+    if parts["thorax"]:
+        thx = present[:, REGION["THORACIC_CAVITY"]] | present[:, REGION["MEDIASTINUM"]] | present[:, REGION["PERICARDIUM"]]
+        groups.append(("Thoracic Cavity", *rng(thx)))
+        groups.append(("Mediastinum", *rng(present[:, REGION["MEDIASTINUM"]])))
+        groups.append(("Pericardium", *rng(present[:, REGION["PERICARDIUM"]])))
+    if parts["abdomen"] and parts["thorax"]:
+        if groups[1][0] != "Abdominal Cavity":
+            raise ValueError("Something went wrong for Abdominal Cavity")
+        if groups[2][0] != "Thoracic Cavity":
+            raise ValueError("Something went wrong for Thoracic Cavity")
+        groups.insert(1, ("Ventral Cavity", groups[1][1], groups[2][2]))
+    if vertebrae:
+        for name, g in vertebrae.items():
+            groups.append((name, g[0], g[1]))
+    return groups
+
+
+def _slicewise(counts_a: np.ndarray, ml_per_voxel: float):
+    import pandas as pd
+    data = {_tname(n): counts_a[:, v].astype(np.int64) * ml_per_voxel for n, v in TISSUES}
+    df = pd.DataFrame(data)
+    df["TAT"] = df.SAT + df.VAT + df.IMAT + df.PAT + df.EAT
+    df["slice_idx"] = range(len(df))
+    return df[["slice_idx"] + COLS]
+
+
+def _descriptive(df, counts_a, sums_a, lo, hi):
+    """_descriptive_statistics_from_measurements (builder.py:263-307) for slices [lo, hi)."""
+    sw = df[(df.slice_idx >= lo) & (df.slice_idx < hi)].drop("slice_idx", axis=1)
+    m = sw.describe()
+    m.drop("count", inplace=True)
+    m.index = ["Mean", "StdDev", "Minimum", "25%", "Median", "75%", "Maximum"]
+    m.loc["Total"] = sw.sum()
+    c = counts_a[lo:hi].astype(np.int64).sum(axis=0)
+    s = sums_a[lo:hi].sum(axis=0)
+    for n, v in TISSUES:
+        m.loc["MeanHU", _tname(n)] = (float(s[v]) / float(c[v])) if c[v] else None
+    adip = [5, 3, 4, 6, 7]
+    ca, sa = int(c[adip].sum()), int(s[adip].sum())
+    m.loc["MeanHU", "TAT"] = (float(sa) / float(ca)) if ca else None
+    return m.replace({np.nan: None})
+
+
+def bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae=None) -> dict:
+    ml = np.prod(spacing_xyz) / 1000.0
+    depth = counts.shape[0]
+    df = _slicewise(counts[:, 0], ml)
+    d2 = _slicewise(counts[:, 1], ml)
+    parts = examined_body_part(present, spacing_xyz)
+    groups = aggregation_groups(present, depth, parts, vertebrae)
+    agg = {}
+    for name, lo, hi in groups:
+        m = _descriptive(df, counts[:, 0], hu_sums[:, 0], lo, hi)
+        m2 = _descriptive(d2, counts[:, 1], hu_sums[:, 1], lo, hi)
+        key = name.lower().replace(" ", "_").replace("-", "_")
+        agg[key] = {
+            "num_slices": int(hi - lo), "min_slice_idx": int(lo), "max_slice_idx": int(hi),
+            "measurements": m.rename(index=_ROW, columns={c: c.lower() for c in m.columns}).to_dict(),
+            "measurements_no_extremities": m2.rename(index=_ROW, columns={c: c.lower() for c in m2.columns}).to_dict(),
+        }
+
+    def recs(d):
+        return d.rename(columns={c: c.lower() for c in d.columns}).drop("slice_idx", axis=1).astype(float).to_dict("records")
+
+    return {"slices": recs(df), "slices_no_extremities": recs(d2), "aggregated": agg, "body_parts": parts}
+
+
+def bca_measurements(ctx: Context, ct: np.ndarray, regions: np.ndarray, parts: np.ndarray, spacing_xyz,
+                     vertebrae=None, return_tissues: bool = False):
+    """CT (z,y,x) int16 + body_regions + body_parts -> bca-measurements dict (+ tissues array)."""
+    if ct.shape != regions.shape or ct.shape != parts.shape:
+        raise ValueError("image, body_regions and body_parts must have the same shape")
+    shape = ct.shape
+    d_ct = ctx.from_numpy(np.ascontiguousarray(ct, dtype=np.int16))
+    d_rg = ctx.from_numpy(np.ascontiguousarray(regions, dtype=np.uint8))
+    d_pt = ctx.from_numpy(np.ascontiguousarray(parts, dtype=np.uint8))
+    try:
+        tis, counts, hu_sums = tissue_aggregate(ctx, d_ct, d_rg, d_pt, shape, want_tissues=return_tissues)
+        present = slice_label_presence(ctx, d_rg, shape)
+        out = bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae)
+        if return_tissues:
+            t = tis.download(shape, np.uint8)
+            tis.free()
+            return out, t
+        return out
+    finally:
+        for b in (d_ct, d_rg, d_pt):
+            b.free()
+
+
+# ---- connected-component post-processing of the body-region segmentation --------------------------------
+def postprocess_region_segmentation(ctx: Context, seg: np.ndarray) -> np.ndarray:
+    """BCA/body_regions/postprocess.py:18-40 on the device: for the masks {seg > 0}, {thoracic, mediastinum,
+    pericardium}, {pericardium}, {abdominal cavity}: all 26-connected components except the largest -> 255."""
+    shape = seg.shape
+    n = int(np.prod(shape))
+    d_seg = ctx.from_numpy(np.ascontiguousarray(seg, dtype=np.uint8))
+    d_mask = ctx.alloc(n)
+    d_roots = ctx.alloc(n * 4)
+    d_sizes = ctx.alloc(n * 4)
+    ncomp = C.c_int()
+
+    def run(mode, vals):
+        v = (C.c_int * 3)(*vals)
+        check(ctx.lib.boa_label_select(ctx.h, d_seg.vp, n, mode, v, d_mask.vp))
+        check(ctx.lib.boa_ccl26(ctx.h, d_mask.vp, shape[0], shape[1], shape[2], d_roots.vp, d_sizes.vp, C.byref(ncomp)))
+        if ncomp.value > 1:
+            check(ctx.lib.boa_ccl_filter_largest(ctx.h, d_roots.vp, d_sizes.vp, n, d_seg.vp, 255))
+
+    try:
+        run(1, (0, 0, 0))
+        run(2, (REGION["THORACIC_CAVITY"], REGION["MEDIASTINUM"], REGION["PERICARDIUM"]))
+        run(0, (REGION["PERICARDIUM"], 0, 0))
+        run(0, (REGION["ABDOMINAL_CAVITY"], 0, 0))
+        return d_seg.download(shape, np.uint8)
+    finally:
+        for b in (d_seg, d_mask, d_roots, d_sizes):
+            b.free()

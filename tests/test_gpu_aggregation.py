@@ -1,0 +1,174 @@
+"""GPU parity tests of the body-composition / HU-measurement kernels (through the C ABI) against the golden
+vectors produced by the reference (G8, G9) and against the oracle.  Integer results are bit-exact; floating
+point statistics carry the tolerance stated in each test."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from boa_hip.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def _json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def _cmp(a, b, rtol, path=""):
+    if isinstance(a, dict):
+        assert set(a) == set(b), (path, set(a) ^ set(b))
+        for k in a:
+            _cmp(a[k], b[k], rtol, f"{path}/{k}")
+    elif isinstance(a, list):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _cmp(x, y, rtol, f"{path}[{i}]")
+    elif a is None or b is None or isinstance(a, (bool, str)):
+        assert a == b, (path, a, b)
+    else:
+        assert np.isclose(a, b, rtol=rtol, atol=0), (path, a, b)
+
+
+def test_g8_tissues_and_bca_json(ctx):
+    """tissue map bit-exact; bca-measurements.json numeric content: slice volumes exact (count x constant),
+    pandas describe() statistics rtol 1e-12, mean HU rtol 1e-9 (exact integer sums vs numpy pairwise fp64)."""
+    from boa_hip import bca
+    z = _npz("g8_bca.npz")
+    g = _json("g8_bca_measurements.json")
+    js, tis = bca.bca_measurements(ctx, z["ct"], z["regions"], z["parts"], tuple(z["spacing"]),
+                                   {k: tuple(v) for k, v in g["vertebrae"].items()}, return_tissues=True)
+    np.testing.assert_array_equal(tis, z["tissues"])
+    js = json.loads(json.dumps(js, default=float))
+    _cmp(js["slices"], g["json"]["slices"], 1e-15)
+    _cmp(js["slices_no_extremities"], g["json"]["slices_no_extremities"], 1e-15)
+    _cmp(js, g["json"], 1e-9)
+
+
+def test_tissue_counts_random_vs_oracle(ctx):
+    """Ragged (non multiple-of-8) slice size -> scalar path; all label / HU combinations incl. edges of the HU windows."""
+    from boa_hip import bca
+    from oracle import bca as obca
+    rng = np.random.default_rng(0)
+    shape = (7, 13, 11)
+    ct = rng.choice(np.array([-1001, -1000, -191, -190, -31, -30, -29, 0, 150, 151, 3000, 3001], np.int16), size=shape)
+    regions = rng.integers(0, 12, size=shape).astype(np.uint8)
+    parts = rng.integers(0, 4, size=shape).astype(np.uint8)
+    d = [ctx.from_numpy(a) for a in (ct, regions, parts)]
+    tis, counts, sums = bca.tissue_aggregate(ctx, d[0], d[1], d[2], shape)
+    t = tis.download(shape, np.uint8)
+    ref = obca.subclassify_tissues(ct, regions)
+    np.testing.assert_array_equal(t, ref)
+    for a, m in ((0, np.ones(shape, bool)), (1, parts == 1)):
+        for k in range(1, 8):
+            sel = (ref == k) & m
+            np.testing.assert_array_equal(counts[:, a, k], sel.sum(axis=(1, 2)))
+            np.testing.assert_array_equal(sums[:, a, k], np.where(sel, ct.astype(np.int64), 0).sum(axis=(1, 2)))
+
+
+def test_g9_metrics_for_each_region(ctx):
+    """Per-label HU statistics from one histogram pass vs the reference's metrics_for_each_region: counts / min /
+    max / median / percentiles / mean exact, std and cnr rtol 1e-9."""
+    from boa_hip import measurements as M
+    z = _npz("g9_measurements.npz")
+    g = _json("g9_measurements.json")
+    am, asd = g["auto"]
+    res = M.metrics_for_each_region(ctx, z["ct"], z["lab"], g["label_map"], am, asd, z["spacing"])
+    res = json.loads(json.dumps(res, default=float))
+    for region, want in g["with_ref"].items():
+        got = res[region]
+        assert got["present"] == want["present"]
+        if not want["present"]:
+            continue
+        for k in ("volume_ml", "min_hu", "max_hu", "median_hu", "25th_percentile_hu", "75th_percentile_hu", "mean_hu"):
+            assert got[k] == want[k], (region, k, got[k], want[k])
+        assert np.isclose(got["std_hu"], want["std_hu"], rtol=1e-9, atol=0)
+        assert np.isclose(got["cnr"], want["cnr"], rtol=1e-9, atol=0)
+    res2 = M.metrics_for_each_region(ctx, z["ct"], z["lab"], {"spleen": 1}, None, None, z["spacing"])
+    assert res2["spleen"]["cnr"] is None and res2["spleen"]["mean_hu"] == g["no_ref"]["spleen"]["mean_hu"]
+
+
+def test_erosion_vs_oracle(ctx):
+    """Separable 6^3 (end-padded) erosion == scipy binary_erosion restatement of erode_region, incl. borders."""
+    from boa_hip import measurements as M
+    from oracle import measurements as OM
+    rng = np.random.default_rng(1)
+    for shape, p in [((20, 24, 28), 0.97), ((9, 31, 17), 0.995), ((6, 6, 6), 1.0), ((5, 40, 40), 0.99)]:
+        m = rng.random(shape) < p
+        np.testing.assert_array_equal(M.erode_region(ctx, m), OM.erode_region(m))
+    m = rng.random((16, 16, 16)) < 0.98
+    np.testing.assert_array_equal(M.erode_region(ctx, m, 3), OM.erode_region(m, 3))
+
+
+def test_total_measurements_vs_oracle(ctx):
+    """compute_measurements (`total` branch: autochthon reference, all labels, ct_pfav, CNR-adjusted regions)."""
+    from boa_hip import label_maps
+    from boa_hip import measurements as M
+    from oracle import measurements as OM
+    rng = np.random.default_rng(2)
+    shape = (40, 56, 64)
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    seg = np.zeros(shape, np.uint8)
+    lm = dict(label_maps.CLASS_MAP_TOTAL_INV)
+
+    def blob(label, c, r):
+        seg[((zz - c[0]) / r[0]) ** 2 + ((yy - c[1]) / r[1]) ** 2 + ((xx - c[2]) / r[2]) ** 2 < 1] = label
+    blob(lm["autochthon_left"], (20, 40, 20), (16, 9, 9))
+    blob(lm["autochthon_right"], (20, 40, 44), (16, 9, 9))
+    blob(lm["aorta"], (20, 20, 32), (18, 7, 7))
+    blob(lm["spleen"], (10, 12, 12), (6, 6, 6))
+    for i, nm in enumerate(M.LUNG_MASKS):
+        blob(lm[nm], (8 + 6 * i, 10, 50), (4, 5, 6))
+    ct = rng.normal(40, 120, size=shape).astype(np.int16)
+    ct[seg == lm["lung_upper_lobe_left"]] = rng.normal(-120, 60, size=(seg == lm["lung_upper_lobe_left"]).sum()).astype(np.int16)
+    for nm in ("autochthon_left", "autochthon_right", "aorta"):  # homogeneous organs: the eroded masks are non-empty
+        sel = seg == lm[nm]
+        ct[sel] = rng.normal(60, 12, size=sel.sum()).astype(np.int16)
+    ct[18:22, 38:42, 18:22] = -100  # a fat pocket inside the left autochthon (removed before the erosion)
+    spacing = (0.8, 0.8, 2.0)
+    got, fat = M.total_measurements(ctx, ct, seg, lm, spacing, cnr_adjustment=True)
+    want, wfat = OM.total_measurements(ct, seg, lm, spacing, cnr_adjustment=True)
+    np.testing.assert_array_equal(fat, wfat)
+    assert got["info"]["autochthon_mean"] is not None and got["cnr_adjusted"]["aorta"]["present"]
+    got = json.loads(json.dumps(got, default=float))
+    want = json.loads(json.dumps(want, default=float))
+    _cmp(got, want, 1e-9)
+
+
+def test_ccl_and_region_postprocess_vs_oracle(ctx):
+    """26-connected components by device union-find + largest-component filters vs scipy.ndimage.label."""
+    from boa_hip import bca
+    from oracle import bca as obca
+    rng = np.random.default_rng(3)
+    shape = (24, 40, 36)
+    seg = np.zeros(shape, np.uint8)
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    seg[(yy - 20) ** 2 + (xx - 18) ** 2 < 15 ** 2] = 1
+    seg[(yy - 20) ** 2 + (xx - 18) ** 2 < 11 ** 2] = 4
+    seg[((zz - 12) ** 2 + (yy - 20) ** 2 + (xx - 18) ** 2) < 6 ** 2] = 9
+    seg[((zz - 12) ** 2 + (yy - 20) ** 2 + (xx - 18) ** 2) < 3 ** 2] = 7
+    seg[2:5, 2:5, 2:5] = 7          # second pericardium blob -> 255
+    seg[20:22, 34:36, 30:33] = 3    # abdominal blobs
+    seg[5:12, 30:38, 2:9] = 3
+    seg[0, 0, 0] = 2                # isolated foreground voxel, diagonal neighbour joins it to the cube at [2:5]? no -> separate
+    seg[1, 1, 1] = 2                # 26-connected to [0,0,0] and to [2,2,2]
+    noise = rng.random(shape) < 0.002
+    seg[noise & (seg == 0)] = 6
+    got = bca.postprocess_region_segmentation(ctx, seg)
+    want = obca.postprocess_region_segmentation(seg)
+    np.testing.assert_array_equal(got, want)
+    assert (got == 255).sum() > 0

@@ -97,3 +97,27 @@ def test_oracle_network_accepts_upstream_key_names():
     assert not res.missing_keys and not res.unexpected_keys
     y = net(torch.zeros(1, 1, 16, 16, 16))
     assert tuple(y.shape) == (1, 3, 16, 16, 16)
+
+
+def test_every_product_module_imports():
+    import importlib
+    for m in ("boa_hip", "boa_hip._lib", "boa_hip.device", "boa_hip.sliding_window", "boa_hip.plans", "boa_hip.predictor",
+              "boa_hip.synthetic", "boa_hip.label_maps", "boa_hip.bca", "boa_hip.measurements", "boa_hip.compute.config",
+              "boa_hip.compute.constants", "boa_hip.compute.util"):
+        importlib.import_module(m)
+
+
+def test_stats_from_hist_matches_numpy():
+    """Order statistics / mean from an integer histogram are bit-identical to numpy on the raw values."""
+    from boa_hip import measurements as M
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 10, 101, 1000, 4097):
+        x = rng.integers(-1100, 1300, size=n).astype(np.int16)
+        h = np.bincount(x.astype(np.int64) - M.HU_MIN, minlength=M.NBINS)
+        st = M.stats_from_hist(h)
+        assert st["n"] == n
+        assert st["mean"] == float(np.mean(x)) and st["min"] == float(np.min(x)) and st["max"] == float(np.max(x))
+        assert st["median"] == float(np.median(x))
+        assert st["p25"] == float(np.percentile(x, 25)) and st["p75"] == float(np.percentile(x, 75))
+        assert np.isclose(st["std"], float(np.std(x)), rtol=1e-12, atol=1e-12)
+    assert M.stats_from_hist(np.zeros(M.NBINS, np.int64)) is None
