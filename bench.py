@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, nargs="+", default=[512])
-    ap.add_argument("--batch", type=int, default=4, help="tiles per conv-stack launch")
+    ap.add_argument("--batch", type=int, default=8, help="tiles per conv-stack launch")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=4)
     ap.add_argument("--dump", type=str, default=None, help="write per-kernel-class timings to this JSON file")
@@ -81,11 +81,8 @@ def main():
     dist = None
     import torch
     if world > 1:
-        import torch.distributed as dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_
+        from boa_hip import distributed as D
+        dist = D.init("nccl", rank, world, local_rank)  # backend "nccl" is RCCL on ROCm
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
 
     from boa_hip import label_maps, synthetic

@@ -306,3 +306,37 @@ def test_sliding_window_end_to_end(ctx):
         # on-device argmax is exactly the argmax of the on-device fp16 logits
         np.testing.assert_array_equal(seg, got.argmax(0).astype(np.uint8))
         p.close()
+
+
+def test_total_pipeline_vs_oracle(ctx):
+    """`total` array pipeline (5 part models, crop_to_nonzero, CTNormalization, step 0.8, argmax, part merge) vs
+    the oracle pipeline with torch-CPU fp32 networks.  A zero slab forces a non-trivial crop.  Label agreement
+    >= 97 % (five random-weight fp16 nets; every other step is exact)."""
+    import torch
+    from boa_hip import label_maps, plans, totalseg
+    from oracle import pipeline as opipe
+    from oracle.network import build_from_arch, network_fn_from_module
+    rng = np.random.default_rng(11)
+    ct = rng.normal(0, 300, size=(44, 40, 52)).astype(np.int16)
+    ct[ct == 0] = 1
+    ct[:3] = 0
+    ct[:, :, -5:] = 0
+    models, omodels = [], []
+    for tid, nc in zip(label_maps.PART_TASK_IDS, (25, 27, 19, 24, 27)):
+        pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc)
+        cfg = plans.model_config_from_plans(pj, dj)
+        sd = plans.synthetic_state_dict(cfg.geometry, seed=tid)
+        models.append((tid, cfg, [plans.weight_blob_from_state_dict(cfg.geometry, sd)]))
+        net = build_from_arch(pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"], 1, nc)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        omodels.append((network_fn_from_module(net, 8), (32, 32, 32), nc, cfg.intensity_properties["0"],
+                        label_maps.CLASS_MAP_PARTS[tid]))
+    ts = totalseg.TotalSegmentatorHip(ctx, models, step_size=0.8, max_batch=4)
+    got = ts.predict(ct)
+    ts.close()
+    want = opipe.predict_total(ct, omodels, label_maps.CLASS_MAP_TOTAL_INV, 0.8)
+    assert got.shape == ct.shape and got.dtype == np.uint8
+    assert (got[:3] == 0).all() and (got[:, :, -5:] == 0).all()  # outside the crop box
+    agree = float((got == want).mean())
+    print("total pipeline label agreement", agree, "labels present", len(np.unique(got)))
+    assert agree >= 0.97
