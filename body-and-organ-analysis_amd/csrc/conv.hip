@@ -840,7 +840,7 @@ struct HeadArgs {
     int V0, V1, V2, s0, s1, s2;
 };
 
-template <int F0>
+template <int F0, int VPT>
 __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* lw = (float*)smem;        // [C][F0]
@@ -851,32 +851,36 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
     for (int i = threadIdx.x; i < 2 * F0; i += 256) lss[i] = p.ss[i];
     __syncthreads();
     const size_t pv = (size_t)p.P0 * p.P1 * p.P2;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VPT;  // first of VPT consecutive voxels along z
     if (i >= pv) return;
-    float y[F0];
-    {
-        const uint4* ap = (const uint4*)(p.act + i * F0);
+    float y[VPT][F0];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const uint4* ap = (const uint4*)(p.act + (i + u) * F0);
 #pragma unroll
         for (int v = 0; v < F0 / 8; ++v) {
             union {
-                uint4 u;
+                uint4 u4;
                 __half h[8];
             } x;
-            x.u = ap[v];
+            x.u4 = ap[v];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 int c = v * 8 + j;
                 float f = __builtin_fmaf(__half2float(x.h[j]), lss[2 * c], lss[2 * c + 1]);
-                y[c] = f > 0.f ? f : f * p.slope;
+                y[u][c] = f > 0.f ? f : f * p.slope;
             }
         }
     }
     if (p.logits) {
         for (int c = 0; c < p.C; ++c) {
-            float sum = lb[c];
 #pragma unroll
-            for (int k = 0; k < F0; ++k) sum = __builtin_fmaf(lw[c * F0 + k], y[k], sum);
-            p.logits[(size_t)c * pv + i] = sum;
+            for (int u = 0; u < VPT; ++u) {
+                float sum = lb[c];
+#pragma unroll
+                for (int k = 0; k < F0; ++k) sum = __builtin_fmaf(lw[c * F0 + k], y[u][k], sum);
+                p.logits[(size_t)c * pv + i + u] = sum;
+            }
         }
         return;
     }
@@ -885,16 +889,39 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
     const int p0 = (int)(i / ((size_t)p.P2 * p.P1));
     const size_t vv = (size_t)p.V0 * p.V1 * p.V2;
     const size_t vi = ((size_t)(p.s0 + p0) * p.V1 + (p.s1 + p1)) * p.V2 + (p.s2 + p2);
-    const float g = p.gauss ? us2f(p.gauss[i]) : 1.0f;
-    for (int c = 0; c < p.C; ++c) {
-        float sum = lb[c];
+    float g[VPT];
 #pragma unroll
-        for (int k = 0; k < F0; ++k) sum = __builtin_fmaf(lw[c * F0 + k], y[k], sum);
-        if (p.gauss) sum = sum * g;
+    for (int u = 0; u < VPT; ++u) g[u] = p.gauss ? us2f(p.gauss[i + u]) : 1.0f;
+    for (int c = 0; c < p.C; ++c) {
+        float sum[VPT];
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) sum[u] = lb[c];
+#pragma unroll
+        for (int k = 0; k < F0; ++k) {
+            const float wk = lw[c * F0 + k];
+#pragma unroll
+            for (int u = 0; u < VPT; ++u) sum[u] = __builtin_fmaf(wk, y[u][k], sum[u]);
+        }
         unsigned short* ap = p.acc + (size_t)c * vv + vi;
-        *ap = f2us(us2f(*ap) + sum);
+        if (VPT == 2) {
+            union {
+                unsigned u32;
+                unsigned short h[2];
+            } a;
+            a.u32 = *(const unsigned*)ap;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float pr = p.gauss ? sum[u] * g[u] : sum[u];  // prediction *= gaussian (fp32)
+                a.h[u] = f2us(us2f(a.h[u]) + pr);             // fp16 += fp32 (fp32 add, RTNE to fp16)
+            }
+            *(unsigned*)ap = a.u32;
+        } else {
+            float pr = p.gauss ? sum[0] * g[0] : sum[0];
+            *ap = f2us(us2f(*ap) + pr);
+        }
     }
-    p.nacc[vi] = f2us(us2f(p.nacc[vi]) + g);
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) p.nacc[vi + u] = f2us(us2f(p.nacc[vi + u]) + g[u]);
 }
 
 int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const int P[3], int C, const float* w,
@@ -904,23 +931,26 @@ int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const 
     HeadArgs a;
     a.act = act; a.ss = ss; a.F0 = F0; a.P0 = P[0]; a.P1 = P[1]; a.P2 = P[2]; a.C = C; a.w = w; a.bias = bias;
     a.slope = slope; a.logits = logits_out; a.gauss = gauss; a.acc = acc; a.nacc = nacc;
+    bool pair = (P[2] % 2 == 0) && F0 == 32;
     if (!logits_out) {
         for (int d = 0; d < 3; ++d)
             BOA_REQUIRE(start[d] >= 0 && start[d] + P[d] <= PV[d], "head: tile [%d,%d) outside accumulator dim %d (%d)",
                         start[d], start[d] + P[d], d, PV[d]);
         a.V0 = PV[0]; a.V1 = PV[1]; a.V2 = PV[2]; a.s0 = start[0]; a.s1 = start[1]; a.s2 = start[2];
+        pair = pair && (PV[2] % 2 == 0) && (start[2] % 2 == 0) && (((uintptr_t)acc) % 4 == 0);
     } else {
         a.V0 = a.V1 = a.V2 = a.s0 = a.s1 = a.s2 = 0;
     }
     size_t pv = (size_t)P[0] * P[1] * P[2];
     size_t lds = ((size_t)C * F0 + C + 2 * F0) * 4;
-    int grid = (int)((pv + 255) / 256);
     double bytes = (double)pv * (2.0 * F0 + (logits_out ? 4.0 * C : (4.0 * (C + 1) + 2.0)));
     KernelTimer tm(ctx, BOA_K_HEAD_ACCUM, 2.0 * pv * F0 * C, bytes);
-    if (F0 == 32)
-        hipLaunchKernelGGL(k_head<32>, dim3(grid), dim3(256), lds, ctx->stream, a);
+    if (pair)
+        hipLaunchKernelGGL((k_head<32, 2>), dim3((unsigned)((pv / 2 + 255) / 256)), dim3(256), lds, ctx->stream, a);
+    else if (F0 == 32)
+        hipLaunchKernelGGL((k_head<32, 1>), dim3((unsigned)((pv + 255) / 256)), dim3(256), lds, ctx->stream, a);
     else
-        hipLaunchKernelGGL(k_head<64>, dim3(grid), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL((k_head<64, 1>), dim3((unsigned)((pv + 255) / 256)), dim3(256), lds, ctx->stream, a);
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

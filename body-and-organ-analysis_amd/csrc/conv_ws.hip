@@ -58,7 +58,7 @@ struct TileWalk {
     int first, stride, count;
 };
 
-__device__ __forceinline__ TileWalk tile_walk(int total_tiles) {
+__device__ __forceinline__ TileWalk tile_walk(int total_tiles, bool getenv_free_walk_contiguous) {
     TileWalk w;
     const int G = (int)gridDim.x, b = (int)blockIdx.x;
     if (G % 8 != 0 || total_tiles < G) {
@@ -71,6 +71,16 @@ __device__ __forceinline__ TileWalk tile_walk(int total_tiles) {
     const int q = total_tiles / 8, rem = total_tiles % 8;
     const int lo = xcd * q + min(xcd, rem);
     const int len = q + (xcd < rem ? 1 : 0);
+    if (getenv_free_walk_contiguous) {
+        // contiguous run per workgroup: consecutive tiles of a workgroup are neighbours along x (x-fastest tile order),
+        // so the x-halo planes a tile re-reads were fetched by the same CU one tile earlier; neighbouring workgroups of
+        // the XCD walk neighbouring lines
+        const int cq = len / per, cr = len % per;
+        w.first = lo + slot * cq + min(slot, cr);
+        w.stride = 1;
+        w.count = cq + (slot < cr ? 1 : 0);
+        return w;
+    }
     w.first = lo + slot;
     w.stride = per;
     w.count = slot < len ? (len - slot + per - 1) / per : 0;
@@ -254,6 +264,8 @@ __device__ __forceinline__ void prod_stage(const ConvArgs& p, const TileCoord& t
 template <int R, int K0, int K1, int K2>
 __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R], const unsigned char* ap, int h1, int h2,
                                               f32x16 (&acc)[R]) {
+    // Prefetch distance is one tap.  (Distance 2 with the pipeline pinned by sched_barrier(0) was measured slower:
+    // 1558 vs 1405 us on the 32->32 @128^3 layer at batch 8 -- 13 spilled VGPRs and a stiffer schedule.)
     constexpr int T = K0 * K1 * K2;
     f16x8 a[2];
     f16x8 b[2][R];
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     const int buf_bytes = resident_w ? 2 * plane : 2 * plane + taps * 1024;
     unsigned char* bufs = smem + wres_bytes;
 
-    const TileWalk walk = tile_walk(total_tiles);
+    const TileWalk walk = tile_walk(total_tiles, !(dbg & 128));
     const int my_chunks = walk.count * ncc;
 
     if (resident_w) {
