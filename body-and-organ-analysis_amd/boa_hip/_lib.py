@@ -71,6 +71,8 @@ _PROTOS = {
     "boa_ccl_filter_largest": (i32, [vp, vp, vp, u64, vp, i32]),
     "boa_ccl_remove_small": (i32, [vp, vp, vp, u64, C.c_uint32, vp]),
     "boa_label_select": (i32, [vp, vp, u64, i32, ip, vp]),
+    "boa_resample_cubic": (i32, [vp, vp, i32, ip, vp, i32, ip]),
+    "boa_resample_nearest_u8": (i32, [vp, vp, ip, vp, ip]),
 }
 
 EXPORTS = sorted(_PROTOS)

@@ -223,6 +223,19 @@ int boa_ccl_remove_small(boa_ctx* ctx, const int32_t* dev_roots, const uint32_t*
 int boa_label_select(boa_ctx* ctx, const uint8_t* dev_labels, size_t n, int mode, const int vals[3],
                      uint8_t* dev_mask_out);
 
+/* ------------------------------------------------------------------ resampling (TS/resampling.py) --- */
+/* change_spacing / resample_img order 3 (TS/resampling.py:24-56,129-222): scipy.ndimage.zoom(data, zoom, order=3,
+ * mode="nearest") restated in fp64 (edge pad 12, cubic B-spline prefilter with 'reflect' initialisation, 64-tap
+ * interpolation, coordinate = out * (n_in - 1) / (n_out - 1)); only the shapes determine the sampling grid.
+ * in_dtype: 0 int16, 1 float32, 2 float64, 3 int32; out_dtype: 0 int32 (`.astype(np.int32)` truncation), 1 float64.
+ * Every fp64 operation in scipy's order with scipy's constants: bit-identical to scipy 1.15.3 on the golden vectors
+ * (tests/golden/g5_resample.npz) including the int32 truncation.  Synchronous (frees its fp64 scratch of (X+24)(Y+24)(Z+24) doubles). */
+int boa_resample_cubic(boa_ctx* ctx, const void* dev_in, int in_dtype, const int in_dims[3], void* dev_out, int out_dtype,
+                       const int out_dims[3]);
+/* order 0 (labels back to the original grid, TS/nnunet.py:685-687): index floor(out * (n_in-1)/(n_out-1) + 0.5). */
+int boa_resample_nearest_u8(boa_ctx* ctx, const uint8_t* dev_in, const int in_dims[3], uint8_t* dev_out,
+                            const int out_dims[3]);
+
 #ifdef __cplusplus
 }
 #endif
