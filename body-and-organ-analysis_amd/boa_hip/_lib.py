@@ -62,7 +62,7 @@ _PROTOS = {
     "boa_net_predict_sliding_window": (i32, [vp, vp, ip, ip, ip, ip, i32, vp, vp, vp]),
     "boa_conv_block_test": (i32, [vp, vp, i32, i32, ip, vp, vp, vp, vp, i32, ip, ip, i32, i32, vp]),
     "boa_convtranspose_test": (i32, [vp, vp, i32, i32, ip, vp, vp, i32, ip, vp]),
-    "boa_tissue_aggregate": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "boa_tissue_aggregate": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "boa_slice_label_presence": (i32, [vp, vp, i32, i32, i32, vp]),
     "boa_label_hu_histogram": (i32, [vp, vp, vp, vp, u64, i32, i32, vp]),
     "boa_label_hu_mask": (i32, [vp, vp, vp, vp, i32, i32, i32, u64, vp]),
@@ -71,6 +71,9 @@ _PROTOS = {
     "boa_ccl_filter_largest": (i32, [vp, vp, vp, u64, vp, i32]),
     "boa_ccl_remove_small": (i32, [vp, vp, vp, u64, C.c_uint32, vp]),
     "boa_label_select": (i32, [vp, vp, u64, i32, ip, vp]),
+    "boa_fill_holes_2d": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+    "boa_mask_assign": (i32, [vp, vp, u64, i32, i32, vp]),
+    "boa_median3_inplane": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "boa_resample_cubic": (i32, [vp, vp, i32, ip, vp, i32, ip]),
     "boa_resample_nearest_u8": (i32, [vp, vp, ip, vp, ip]),
 }

@@ -47,16 +47,37 @@ class DeviceVolume:
         self.buf.free()
 
 
+def slice_axis_from_orientation(orientation) -> int:
+    """subclassification.py:24-35: the array axis (of the (z,y,x) SimpleITK array) that gets kernel size 1."""
+    if orientation is None:
+        raise ValueError("Orientation must be set")
+    orientation = tuple(orientation)
+    if "I" in orientation:
+        return orientation[::-1].index("I")
+    if "S" in orientation:
+        return orientation[::-1].index("S")
+    raise ValueError(f"The orientation {orientation} does not contain neither I nor S.")
+
+
+def median_filter_inplane(ctx: Context, ct: DeviceBuffer, shape, flat_axis: int = 0) -> DeviceBuffer:
+    """scipy.ndimage.median_filter(image, size=[3,3,3] with 1 on `flat_axis`) on the device (int16)."""
+    Z, Y, X = (int(s) for s in shape)
+    out = ctx.alloc(Z * Y * X * 2)
+    check(ctx.lib.boa_median3_inplane(ctx.h, ct.vp, Z, Y, X, int(flat_axis), out.vp), "boa_median3_inplane")
+    return out
+
+
 def tissue_aggregate(ctx: Context, ct: DeviceBuffer, regions: DeviceBuffer, parts: Optional[DeviceBuffer], shape,
-                     want_tissues: bool = True):
+                     want_tissues: bool = True, ct_rules: Optional[DeviceBuffer] = None):
     """One pass: tissues (uint8, optional), counts uint32 [Z,2,8], hu_sums int64 [Z,2,8] ([.,0,.] all voxels,
-    [.,1,.] body_parts == TORSO)."""
+    [.,1,.] body_parts == TORSO).  ct_rules: the (median-filtered) CT the derivation rules look at, default ct."""
     Z, Y, X = (int(s) for s in shape)
     tis = ctx.alloc(Z * Y * X) if want_tissues else None
     cnt = ctx.alloc(Z * 16 * 4)
     sums = ctx.alloc(Z * 16 * 8)
-    check(ctx.lib.boa_tissue_aggregate(ctx.h, ct.vp, regions.vp, parts.vp if parts else None, tis.vp if tis else None,
-                                       Z, Y, X, cnt.vp, sums.vp), "boa_tissue_aggregate")
+    check(ctx.lib.boa_tissue_aggregate(ctx.h, ct.vp, ct_rules.vp if ct_rules else None, regions.vp,
+                                       parts.vp if parts else None, tis.vp if tis else None, Z, Y, X, cnt.vp, sums.vp),
+          "boa_tissue_aggregate")
     counts = cnt.download((Z, 2, 8), np.uint32)
     hu_sums = sums.download((Z, 2, 8), np.int64)
     cnt.free()
@@ -172,16 +193,20 @@ def bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebra
 
 
 def bca_measurements(ctx: Context, ct: np.ndarray, regions: np.ndarray, parts: np.ndarray, spacing_xyz,
-                     vertebrae=None, return_tissues: bool = False):
-    """CT (z,y,x) int16 + body_regions + body_parts -> bca-measurements dict (+ tissues array)."""
+                     vertebrae=None, return_tissues: bool = False, median_filtering: bool = False, orientation="LPS"):
+    """CT (z,y,x) int16 + body_regions + body_parts -> bca-measurements dict (+ tissues array).
+    median_filtering: subclassify on the 3x3 in-plane median of the CT (run_pipeline(median_filtering=True))."""
     if ct.shape != regions.shape or ct.shape != parts.shape:
         raise ValueError("image, body_regions and body_parts must have the same shape")
     shape = ct.shape
     d_ct = ctx.from_numpy(np.ascontiguousarray(ct, dtype=np.int16))
     d_rg = ctx.from_numpy(np.ascontiguousarray(regions, dtype=np.uint8))
     d_pt = ctx.from_numpy(np.ascontiguousarray(parts, dtype=np.uint8))
+    d_med = None
     try:
-        tis, counts, hu_sums = tissue_aggregate(ctx, d_ct, d_rg, d_pt, shape, want_tissues=return_tissues)
+        if median_filtering:
+            d_med = median_filter_inplane(ctx, d_ct, shape, slice_axis_from_orientation(orientation))
+        tis, counts, hu_sums = tissue_aggregate(ctx, d_ct, d_rg, d_pt, shape, want_tissues=return_tissues, ct_rules=d_med)
         present = slice_label_presence(ctx, d_rg, shape)
         out = bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae)
         if return_tissues:
@@ -190,8 +215,36 @@ def bca_measurements(ctx: Context, ct: np.ndarray, regions: np.ndarray, parts: n
             return out, t
         return out
     finally:
-        for b in (d_ct, d_rg, d_pt):
-            b.free()
+        for b in (d_ct, d_rg, d_pt, d_med):
+            if b is not None:
+                b.free()
+
+
+def create_vertebrae_info(ctx: Context, total_zyx: np.ndarray, class_map_total: Dict[int, str], parts: Dict[str, bool],
+                          d_total: Optional[DeviceBuffer] = None) -> Dict[str, Tuple[int, int]]:
+    """BCA/commands.py:24-45: slice range (min, max+1) of every vertebra label that is present and whose body part
+    (C -> neck, T -> thorax, L -> abdomen) was detected.  One presence pass on the device."""
+    own = d_total is None
+    if own:
+        d_total = ctx.from_numpy(np.ascontiguousarray(total_zyx, dtype=np.uint8))
+    try:
+        present = slice_label_presence(ctx, d_total, total_zyx.shape)
+    finally:
+        if own:
+            d_total.free()
+    info = {}
+    for label, name in class_map_total.items():
+        if not name.startswith("vertebrae_"):
+            continue
+        vid = name[len("vertebrae_"):]
+        idx = np.where(present[:, int(label)])[0]
+        if len(idx) == 0:
+            continue
+        if ("C" in vid and not parts["neck"]) or ("T" in vid and not parts["thorax"]) or \
+                ("L" in vid and not parts["abdomen"]):
+            continue
+        info[vid] = (int(idx.min()), int(idx.max() + 1))
+    return info
 
 
 # ---- connected-component post-processing of the body-region segmentation --------------------------------
@@ -221,4 +274,38 @@ def postprocess_region_segmentation(ctx: Context, seg: np.ndarray) -> np.ndarray
         return d_seg.download(shape, np.uint8)
     finally:
         for b in (d_seg, d_mask, d_roots, d_sizes):
+            b.free()
+
+
+def postprocess_part_segmentation(ctx: Context, seg: np.ndarray, threshold: int = 3000) -> np.ndarray:
+    """BCA/body_parts/postprocess.py:7-60 (`remove_small_labeled_objects`) on the device.  Per label (ascending):
+    slice-wise external-contour fill (boa_fill_holes_2d), remove 26-connected objects with <= threshold-1 voxels,
+    remove 26-connected holes with <= threshold-1 voxels, `out[filled] = label`."""
+    seg = np.ascontiguousarray(seg, dtype=np.uint8)
+    shape = tuple(int(v) for v in seg.shape)
+    Z, Y, X = shape
+    n = Z * Y * X
+    d_seg = ctx.from_numpy(seg)
+    d_out = ctx.zeros(n)
+    d_mask, d_fill, d_tmp = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    d_roots, d_sizes = ctx.alloc(n * 4), ctx.alloc(n * 4)
+    ncomp = C.c_int()
+    try:
+        labels = np.flatnonzero(slice_label_presence(ctx, d_seg, shape).any(axis=0))
+        for label in labels[labels > 0]:
+            v = (C.c_int * 3)(int(label), 0, 0)
+            check(ctx.lib.boa_label_select(ctx.h, d_seg.vp, n, 0, v, d_mask.vp))
+            check(ctx.lib.boa_fill_holes_2d(ctx.h, d_mask.vp, Z, Y, X, d_roots.vp, d_tmp.vp, d_fill.vp), "boa_fill_holes_2d")
+            # small foreground objects
+            check(ctx.lib.boa_ccl26(ctx.h, d_fill.vp, Z, Y, X, d_roots.vp, d_sizes.vp, C.byref(ncomp)))
+            check(ctx.lib.boa_ccl_remove_small(ctx.h, d_roots.vp, d_sizes.vp, n, threshold - 1, d_fill.vp))
+            # small holes: the same on the inverted mask
+            zero = (C.c_int * 3)(0, 0, 0)
+            check(ctx.lib.boa_label_select(ctx.h, d_fill.vp, n, 0, zero, d_mask.vp))       # d_mask = ~filled
+            check(ctx.lib.boa_ccl26(ctx.h, d_mask.vp, Z, Y, X, d_roots.vp, d_sizes.vp, C.byref(ncomp)))
+            check(ctx.lib.boa_ccl_remove_small(ctx.h, d_roots.vp, d_sizes.vp, n, threshold - 1, d_mask.vp))
+            check(ctx.lib.boa_mask_assign(ctx.h, d_mask.vp, n, 1, int(label), d_out.vp))   # out[~d_mask] = label
+        return d_out.download(shape, np.uint8)
+    finally:
+        for b in (d_seg, d_out, d_mask, d_fill, d_tmp, d_roots, d_sizes):
             b.free()

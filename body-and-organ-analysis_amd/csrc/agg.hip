@@ -28,6 +28,7 @@ __device__ __forceinline__ int tissue_of(int hu, int region) {
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_tissue_aggregate(const short* __restrict__ ct,
+                                                          const short* __restrict__ ct_rules,
                                                           const unsigned char* __restrict__ regions,
                                                           const unsigned char* __restrict__ parts,
                                                           unsigned char* __restrict__ tissues, int slice_vox,
@@ -51,22 +52,25 @@ __global__ __launch_bounds__(256) void k_tissue_aggregate(const short* __restric
     const int nvec = slice_vox / VEC;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
         short hu[VEC] __attribute__((aligned(16)));
+        short hr[VEC] __attribute__((aligned(16)));
         unsigned char rg[VEC] __attribute__((aligned(8)));
         unsigned char pt[VEC] __attribute__((aligned(8)));
         unsigned char ts[VEC] __attribute__((aligned(8)));
         const size_t o = base + (size_t)i * VEC;
         if (VEC == 8) {
             *(uint4*)hu = *(const uint4*)(ct + o);
+            *(uint4*)hr = ct_rules ? *(const uint4*)(ct_rules + o) : *(const uint4*)hu;
             *(uint2*)rg = *(const uint2*)(regions + o);
             if (parts) *(uint2*)pt = *(const uint2*)(parts + o);
         } else {
             hu[0] = ct[o];
+            hr[0] = ct_rules ? ct_rules[o] : hu[0];
             rg[0] = regions[o];
             if (parts) pt[0] = parts[o];
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const int t = tissue_of(hu[j], rg[j]);
+            const int t = tissue_of(hr[j], rg[j]);
             ts[j] = (unsigned char)t;
             const bool torso = parts && pt[j] == 1;
 #pragma unroll
@@ -109,8 +113,8 @@ __global__ __launch_bounds__(256) void k_tissue_aggregate(const short* __restric
     }
 }
 
-extern "C" int boa_tissue_aggregate(boa_ctx* c, const int16_t* dev_ct, const uint8_t* dev_regions,
-                                    const uint8_t* dev_parts, uint8_t* dev_tissues_out, int Z, int Y, int X,
+extern "C" int boa_tissue_aggregate(boa_ctx* c, const int16_t* dev_ct, const int16_t* dev_ct_rules,
+                                    const uint8_t* dev_regions, const uint8_t* dev_parts, uint8_t* dev_tissues_out, int Z, int Y, int X,
                                     uint32_t* dev_counts, int64_t* dev_hu_sums) {
     BOA_REQUIRE(c && dev_ct && dev_regions && dev_counts && dev_hu_sums, "boa_tissue_aggregate: NULL argument");
     BOA_REQUIRE(Z > 0 && Y > 0 && X > 0 && (long long)Y * X < (1ll << 30), "boa_tissue_aggregate: bad dims");
@@ -122,13 +126,13 @@ extern "C" int boa_tissue_aggregate(boa_ctx* c, const int16_t* dev_ct, const uin
     const int nvec = vec8 ? sv / 8 : sv;
     int gx = std::min(ceil_div(nvec, 256), 64);
     const double vox = (double)Z * sv;
-    KernelTimer t(c, BOA_K_OTHER, 0, vox * (3.0 + (dev_parts ? 1 : 0) + (dev_tissues_out ? 1 : 0)));
+    KernelTimer t(c, BOA_K_OTHER, 0, vox * (3.0 + (dev_ct_rules ? 2 : 0) + (dev_parts ? 1 : 0) + (dev_tissues_out ? 1 : 0)));
     if (vec8)
-        hipLaunchKernelGGL(k_tissue_aggregate<8>, dim3(gx, Z), dim3(256), 0, c->stream, dev_ct, dev_regions, dev_parts,
-                           dev_tissues_out, sv, dev_counts, (long long*)dev_hu_sums);
+        hipLaunchKernelGGL(k_tissue_aggregate<8>, dim3(gx, Z), dim3(256), 0, c->stream, dev_ct, dev_ct_rules, dev_regions,
+                           dev_parts, dev_tissues_out, sv, dev_counts, (long long*)dev_hu_sums);
     else
-        hipLaunchKernelGGL(k_tissue_aggregate<1>, dim3(gx, Z), dim3(256), 0, c->stream, dev_ct, dev_regions, dev_parts,
-                           dev_tissues_out, sv, dev_counts, (long long*)dev_hu_sums);
+        hipLaunchKernelGGL(k_tissue_aggregate<1>, dim3(gx, Z), dim3(256), 0, c->stream, dev_ct, dev_ct_rules, dev_regions,
+                           dev_parts, dev_tissues_out, sv, dev_counts, (long long*)dev_hu_sums);
     t.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

@@ -1,0 +1,163 @@
+// Slice-wise morphology for the BCA post-processing:
+//   boa_fill_holes_2d   per-slice external-contour fill of body_parts/postprocess.py:31-39
+//                       (cv2.findContours(RETR_EXTERNAL) + drawContours(FILLED)): the filled set is the foreground
+//                       plus every background pixel that is not 4-connected to the slice border through background
+//                       (8-connected foreground / 4-connected background duality) -- union-find over the background.
+//   boa_median3_inplane scipy.ndimage.median_filter(size 3 on two axes, 1 on the slice axis, mode="reflect") of
+//                       tissue/subclassification.py:21-36 on int16 HU.
+//   boa_mask_assign     out[mask (!)= 0] = value   (`out[filled] = label`, body_parts/postprocess.py:50).
+#include "common.h"
+
+#define AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+__device__ __forceinline__ int uf2_find(int* L, int i) {
+    int p = AGENT_LOAD(&L[i]);
+    while (p != i) {
+        i = p;
+        p = AGENT_LOAD(&L[i]);
+    }
+    return i;
+}
+
+__device__ __forceinline__ void uf2_union(int* L, int a, int b) {
+    while (true) {
+        a = uf2_find(L, a);
+        b = uf2_find(L, b);
+        if (a == b) return;
+        if (a < b) {
+            int t = a;
+            a = b;
+            b = t;
+        }
+        int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bg_init(const unsigned char* __restrict__ mask, size_t n, int* __restrict__ L,
+                                                 unsigned char* __restrict__ flag) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        L[i] = mask[i] ? -1 : (int)i;
+        flag[i] = 0;
+    }
+}
+
+// 4-connected, in-slice: merge with the left and the upper background neighbour
+__global__ __launch_bounds__(256) void k_bg_merge(const unsigned char* __restrict__ mask, size_t n, int Y, int X, int* L) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || mask[i]) return;
+    const int x = (int)(i % X);
+    const int y = (int)((i / X) % Y);
+    if (x > 0 && !mask[i - 1]) uf2_union(L, (int)i, (int)(i - 1));
+    if (y > 0 && !mask[i - X]) uf2_union(L, (int)i, (int)(i - X));
+}
+
+__global__ __launch_bounds__(256) void k_bg_flag_border(const unsigned char* __restrict__ mask, size_t n, int Y, int X,
+                                                        int* L, unsigned char* flag) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || mask[i]) return;
+    const int x = (int)(i % X);
+    const int y = (int)((i / X) % Y);
+    if (x == 0 || y == 0 || x == X - 1 || y == Y - 1) flag[uf2_find(L, (int)i)] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_bg_fill(const unsigned char* __restrict__ mask, size_t n, int* L,
+                                                 const unsigned char* __restrict__ flag, unsigned char* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned char v = 1;
+    if (!mask[i]) v = flag[uf2_find(L, (int)i)] ? 0 : 1;
+    out[i] = v;
+}
+
+extern "C" int boa_fill_holes_2d(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int X, int32_t* dev_scratch_i32,
+                                 uint8_t* dev_scratch_u8, uint8_t* dev_out) {
+    BOA_REQUIRE(c && dev_mask && dev_scratch_i32 && dev_scratch_u8 && dev_out && Z > 0 && Y > 0 && X > 0,
+                "boa_fill_holes_2d: bad argument");
+    BOA_REQUIRE(dev_out != dev_scratch_u8 && dev_out != dev_mask, "boa_fill_holes_2d: out must not alias mask/scratch");
+    const size_t n = (size_t)Z * Y * X;
+    BOA_REQUIRE(n < (1ull << 31), "boa_fill_holes_2d: volume too large for int32 indices");
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    KernelTimer t(c, BOA_K_OTHER, 0, (double)n * 12.0);
+    hipLaunchKernelGGL(k_bg_init, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, dev_scratch_i32, dev_scratch_u8);
+    hipLaunchKernelGGL(k_bg_merge, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, Y, X, dev_scratch_i32);
+    hipLaunchKernelGGL(k_bg_flag_border, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, Y, X, dev_scratch_i32,
+                       dev_scratch_u8);
+    hipLaunchKernelGGL(k_bg_fill, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, dev_scratch_i32, dev_scratch_u8, dev_out);
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cswap(short& a, short& b) {
+    const short lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo;
+    b = hi;
+}
+
+// flat_axis: the axis (0 = z, 1 = y, 2 = x of the [Z][Y][X] array) with kernel size 1
+__global__ __launch_bounds__(256) void k_median3_inplane(const short* __restrict__ in, int Z, int Y, int X, int flat_axis,
+                                                         short* __restrict__ out) {
+    const size_t n = (size_t)Z * Y * X;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % X);
+    const int y = (int)((i / X) % Y);
+    const int z = (int)(i / ((size_t)X * Y));
+    const int dims[3] = {Z, Y, X};
+    const int pos[3] = {z, y, x};
+    const int a0 = flat_axis == 0 ? 1 : 0, a1 = flat_axis == 2 ? 1 : 2;
+    const size_t strides[3] = {(size_t)Y * X, (size_t)X, 1};
+    short v[9];
+#pragma unroll
+    for (int d0 = -1; d0 <= 1; ++d0)
+#pragma unroll
+        for (int d1 = -1; d1 <= 1; ++d1) {
+            // mode="reflect" (d c b a | a b c d): for a radius-1 window the mirrored index is the clamped index
+            const int p0 = min(max(pos[a0] + d0, 0), dims[a0] - 1);
+            const int p1 = min(max(pos[a1] + d1, 0), dims[a1] - 1);
+            v[(d0 + 1) * 3 + d1 + 1] = in[(size_t)pos[flat_axis] * strides[flat_axis] + (size_t)p0 * strides[a0] +
+                                          (size_t)p1 * strides[a1]];
+        }
+    // 19-exchange median-of-9 network
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+    cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+    cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
+    cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
+    cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
+    cswap(v[4], v[2]);
+    out[i] = v[4];
+}
+
+extern "C" int boa_median3_inplane(boa_ctx* c, const int16_t* dev_in, int Z, int Y, int X, int flat_axis, int16_t* dev_out) {
+    BOA_REQUIRE(c && dev_in && dev_out && dev_in != dev_out && Z > 0 && Y > 0 && X > 0, "boa_median3_inplane: bad argument");
+    BOA_REQUIRE(flat_axis >= 0 && flat_axis <= 2, "boa_median3_inplane: flat_axis %d", flat_axis);
+    const size_t n = (size_t)Z * Y * X;
+    KernelTimer t(c, BOA_K_OTHER, 0, (double)n * 4.0);
+    hipLaunchKernelGGL(k_median3_inplane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_in, Z, Y, X, flat_axis,
+                       dev_out);
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+__global__ __launch_bounds__(256) void k_mask_assign(const unsigned char* __restrict__ mask, size_t n, int invert, int value,
+                                                     unsigned char* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool on = (mask[i] != 0) != (invert != 0);
+    if (on) out[i] = (unsigned char)value;
+}
+
+extern "C" int boa_mask_assign(boa_ctx* c, const uint8_t* dev_mask, size_t n, int invert, int value, uint8_t* dev_out) {
+    BOA_REQUIRE(c && dev_mask && dev_out, "boa_mask_assign: NULL argument");
+    if (n == 0) return BOA_OK;
+    hipLaunchKernelGGL(k_mask_assign, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_mask, n, invert, value,
+                       dev_out);
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}

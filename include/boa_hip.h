@@ -173,10 +173,14 @@ int boa_convtranspose_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, co
  * the slice-wise voxel counts of Builder.prepare (BCA/report/builder.py:403-444) and the per-slice HU sums that
  * `np.mean(image[tissue_mask])` (builder.py:284-305) needs.
  *   ct int16 [Z][Y][X], regions uint8, parts uint8 (may be NULL -> no torso counts), tissues_out uint8 (may be NULL)
+ *   ct_rules (may be NULL = ct): the HU the derivation rules look at -- the 3x3 in-plane median-filtered CT when
+ *           median_filtering is on (subclassification.py:21-36); HU sums always come from `ct` (builder.py gets the
+ *           unfiltered image)
  *   counts  dev uint32 [Z][2][8]   (index 0 unused; [0] = all voxels, [1] = body_parts == TORSO(1))
  *   hu_sums dev int64  [Z][2][8]
  * counts/hu_sums are overwritten. */
-int boa_tissue_aggregate(boa_ctx* ctx, const int16_t* dev_ct, const uint8_t* dev_regions, const uint8_t* dev_parts,
+int boa_tissue_aggregate(boa_ctx* ctx, const int16_t* dev_ct, const int16_t* dev_ct_rules, const uint8_t* dev_regions,
+                         const uint8_t* dev_parts,
                          uint8_t* dev_tissues_out, int Z, int Y, int X, uint32_t* dev_counts, int64_t* dev_hu_sums);
 
 /* Per-slice presence of each label value (np.where(mask.any(axis=(1,2))) in builder.py:56-100,170-199 and
@@ -222,6 +226,17 @@ int boa_ccl_remove_small(boa_ctx* ctx, const int32_t* dev_roots, const uint32_t*
 /* mask_out = (labels == value) [mode 0] | (lut-free) labels > 0 [mode 1] | labels in {a,b,c} [mode 2, vals[3]] */
 int boa_label_select(boa_ctx* ctx, const uint8_t* dev_labels, size_t n, int mode, const int vals[3],
                      uint8_t* dev_mask_out);
+
+/* remove_small_labeled_objects, slice-wise contour fill (BCA/body_parts/postprocess.py:31-39: per (y,x) slice
+ * cv2.findContours(RETR_EXTERNAL) + drawContours(FILLED)): out = mask != 0 OR background pixel that is not 4-connected
+ * to the slice border through background.  scratch_i32: dev int32 [n]; scratch_u8: dev uint8 [n]; out must not alias. */
+int boa_fill_holes_2d(boa_ctx* ctx, const uint8_t* dev_mask, int Z, int Y, int X, int32_t* dev_scratch_i32,
+                      uint8_t* dev_scratch_u8, uint8_t* dev_out);
+/* `out[filled] = label` (BCA/body_parts/postprocess.py:50): out[i] = value where (mask[i] != 0) != invert. */
+int boa_mask_assign(boa_ctx* ctx, const uint8_t* dev_mask, size_t n, int invert, int value, uint8_t* dev_out);
+/* subclassify_tissues(median_filtering=True) (BCA/tissue/subclassification.py:21-36): scipy.ndimage.median_filter
+ * with size 3 on two axes and 1 on `flat_axis` (0 = z, 1 = y, 2 = x of the [Z][Y][X] array), mode="reflect". */
+int boa_median3_inplane(boa_ctx* ctx, const int16_t* dev_in, int Z, int Y, int X, int flat_axis, int16_t* dev_out);
 
 /* ------------------------------------------------------------------ resampling (TS/resampling.py) --- */
 /* change_spacing / resample_img order 3 (TS/resampling.py:24-56,129-222): scipy.ndimage.zoom(data, zoom, order=3,

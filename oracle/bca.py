@@ -177,3 +177,41 @@ def postprocess_region_segmentation(seg):
     for r in (REGION["PERICARDIUM"], REGION["ABDOMINAL_CAVITY"]):
         filter_largest_unique_segment(seg, seg == r)
     return seg
+
+
+def remove_small_labeled_objects(mask: np.ndarray, threshold: int = 3000) -> np.ndarray:
+    """BCA/body_parts/postprocess.py:7-52.  cv2 and skimage are absent here (PARITY UNPINNED vs those libraries); restated
+    from their documented semantics with scipy:
+      * findContours(RETR_EXTERNAL) + drawContours(FILLED) per slice fills each outer contour of the 8-connected
+        foreground, i.e. foreground plus all background not 4-connected to the slice border
+        = scipy.ndimage.binary_fill_holes (default cross structuring element);
+      * remove_small_objects(max_size=threshold-1, connectivity=3) clears 26-connected components with
+        <= threshold-1 voxels."""
+    out = np.zeros(mask.shape, dtype=mask.dtype)
+    ones = np.ones((3, 3, 3))
+    for label in np.unique(mask):
+        if label <= 0:
+            continue
+        filled = np.stack([ndimage.binary_fill_holes(mask[i] == label) for i in range(mask.shape[0])])
+        for _ in range(2):  # objects, then (after inversion) holes
+            lab, n = ndimage.label(filled, structure=ones)
+            sizes = np.bincount(lab.ravel())
+            small = sizes <= threshold - 1
+            small[0] = False
+            filled[small[lab]] = False
+            filled = ~filled
+        out[filled] = label
+    return out
+
+
+def create_vertebrae_info(total_zyx: np.ndarray, vertebrae_map: dict, parts: dict) -> dict:
+    """BCA/commands.py:24-45.  vertebrae_map: {"C1": label, ...}; parts: {"abdomen","thorax","neck"} flags."""
+    info = {}
+    for vid, label in vertebrae_map.items():
+        idx = np.where((total_zyx == label).any(axis=(1, 2)))[0]
+        if len(idx) == 0:
+            continue
+        if ("C" in vid and not parts["neck"]) or ("T" in vid and not parts["thorax"]) or ("L" in vid and not parts["abdomen"]):
+            continue
+        info[vid] = (int(idx.min()), int(idx.max() + 1))
+    return info

@@ -172,3 +172,107 @@ def test_ccl_and_region_postprocess_vs_oracle(ctx):
     want = obca.postprocess_region_segmentation(seg)
     np.testing.assert_array_equal(got, want)
     assert (got == 255).sum() > 0
+
+
+def _blobs(rng, shape, n_blobs, rmax):
+    """random union of balls/holes: enough structure for nested contours, holes, small objects"""
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    m = np.zeros(shape, bool)
+    for _ in range(n_blobs):
+        c = [rng.integers(0, s) for s in shape]
+        r = rng.integers(1, rmax)
+        ball = (zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2 <= r * r
+        if rng.random() < 0.35:
+            m &= ~ball
+        else:
+            m |= ball
+    return m
+
+
+def test_fill_holes_2d_vs_scipy(ctx):
+    """Slice-wise external-contour fill == binary_fill_holes with the 4-connected (cross) background, incl. diagonal
+    8-connected rings (closed for the fill) and shapes touching the border."""
+    import ctypes as C
+    from scipy import ndimage
+    from boa_hip._lib import check
+    rng = np.random.default_rng(11)
+    shape = (9, 61, 53)
+    m = _blobs(rng, shape, 60, 12)
+    m[0] = False
+    m[0, 10, 10] = m[0, 11, 11] = m[0, 10, 12] = m[0, 9, 11] = True          # diamond ring: centre (10,11) is enclosed
+    m[1] = rng.random(shape[1:]) < 0.45                                        # noise
+    m[2] = True; m[2, 5:20, 0:7] = False; m[2, 30:40, 20:30] = False           # hole open to the border + closed hole
+    n = m.size
+    d_m = ctx.from_numpy(m.astype(np.uint8))
+    d_i, d_t, d_o = ctx.alloc(n * 4), ctx.alloc(n), ctx.alloc(n)
+    check(ctx.lib.boa_fill_holes_2d(ctx.h, d_m.vp, shape[0], shape[1], shape[2], d_i.vp, d_t.vp, d_o.vp))
+    out = d_o.download(shape, np.uint8).astype(bool)
+    ref = np.stack([ndimage.binary_fill_holes(m[i]) for i in range(shape[0])])
+    np.testing.assert_array_equal(out, ref)
+    assert out[0, 10, 11] and ref.sum() > m.sum()
+
+
+def test_postprocess_part_segmentation_vs_oracle(ctx):
+    from boa_hip import bca
+    from oracle import bca as obca
+    rng = np.random.default_rng(12)
+    shape = (24, 72, 64)
+    seg = np.zeros(shape, np.uint8)
+    for label in (1, 2, 3, 5):
+        seg[_blobs(rng, shape, 25, 14)] = label
+    seg[rng.random(shape) < 0.01] = 4                                           # specks: removed as small objects
+    for thr in (3000, 400):
+        out = bca.postprocess_part_segmentation(ctx, seg, threshold=thr)
+        ref = obca.remove_small_labeled_objects(seg, threshold=thr)
+        np.testing.assert_array_equal(out, ref)
+    assert (ref != seg).any() and (ref > 0).any()
+
+
+@pytest.mark.parametrize("flat_axis", [0, 1, 2])
+def test_median3_inplane_vs_scipy(ctx, flat_axis):
+    from scipy import ndimage
+    from boa_hip import bca
+    rng = np.random.default_rng(13)
+    shape = (6, 19, 23)
+    ct = rng.integers(-1024, 3071, size=shape).astype(np.int16)
+    d = ctx.from_numpy(ct)
+    o = bca.median_filter_inplane(ctx, d, shape, flat_axis)
+    size = [3, 3, 3]
+    size[flat_axis] = 1
+    np.testing.assert_array_equal(o.download(shape, np.int16), ndimage.median_filter(ct, size=size))
+
+
+def test_bca_median_filtering_vs_oracle(ctx):
+    """median_filtering=True: tissues from the filtered CT, mean HU from the unfiltered CT (run_pipeline hands the
+    original image to the Builder)."""
+    from boa_hip import bca
+    from oracle import bca as obca
+    z = _npz("g8_bca.npz")
+    ct = z["ct"].copy()
+    rng = np.random.default_rng(14)
+    ct = (ct + rng.integers(-60, 60, size=ct.shape)).astype(np.int16)            # noise so the filter matters
+    sp = tuple(z["spacing"])
+    js, tis = bca.bca_measurements(ctx, ct, z["regions"], z["parts"], sp, None, return_tissues=True,
+                                   median_filtering=True, orientation="LPS")
+    ref_t = obca.subclassify_tissues(ct, z["regions"], median_filtering=True, slice_axis=0)
+    np.testing.assert_array_equal(tis, ref_t)
+    assert (ref_t != obca.subclassify_tissues(ct, z["regions"])).any()
+    ref = obca.bca_measurements_json(ct, z["regions"], z["parts"], ref_t, sp, None)
+    _cmp(json.loads(json.dumps(js, default=float)), json.loads(json.dumps(ref, default=float)), 1e-9)
+
+
+def test_create_vertebrae_info_vs_oracle(ctx):
+    from boa_hip import bca, label_maps
+    from oracle import bca as obca
+    rng = np.random.default_rng(15)
+    cm = label_maps.CLASS_MAP_TOTAL
+    vmap = {v[len("vertebrae_"):]: k for k, v in cm.items() if v.startswith("vertebrae_")}
+    total = np.zeros((40, 16, 16), np.uint8)
+    for i, (vid, lab) in enumerate(sorted(vmap.items())):
+        if i % 3 == 2:
+            continue                                                           # absent vertebrae
+        z0 = rng.integers(0, 36)
+        total[z0:z0 + rng.integers(1, 4), 3:9, 4:8] = lab
+    for parts in (dict(abdomen=True, thorax=True, neck=True), dict(abdomen=True, thorax=False, neck=False),
+                  dict(abdomen=False, thorax=False, neck=False)):
+        assert bca.create_vertebrae_info(ctx, total, cm, parts) == obca.create_vertebrae_info(total, vmap, parts)
