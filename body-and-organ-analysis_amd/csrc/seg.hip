@@ -22,14 +22,17 @@ __global__ void k_ct_normalize(const T* __restrict__ in, float* __restrict__ out
 extern "C" int boa_ct_normalize(boa_ctx* c, const void* dev_in, int in_dtype, float* dev_out, size_t n, float mean,
                                 float sd, float lo, float hi) {
     BOA_REQUIRE(c && dev_in && dev_out, "boa_ct_normalize: NULL argument");
-    BOA_REQUIRE(in_dtype == 0 || in_dtype == 1, "boa_ct_normalize: in_dtype must be 0 (int16) or 1 (float32)");
+    BOA_REQUIRE(in_dtype >= 0 && in_dtype <= 2, "boa_ct_normalize: in_dtype must be 0 (int16), 1 (float32) or 2 (int32)");
     if (n == 0) return BOA_OK;
     sd = sd > 1e-8f ? sd : 1e-8f;
     int block = 256;
     int grid = (int)((n + block - 1) / block);
     if (grid > c->cu_count * 16) grid = c->cu_count * 16;
     KernelTimer t(c, BOA_K_OTHER, 0, (double)n * (in_dtype == 0 ? 6 : 8));
-    if (in_dtype == 0)
+    if (in_dtype == 2)
+        hipLaunchKernelGGL(k_ct_normalize<int32_t>, dim3(grid), dim3(block), 0, c->stream, (const int32_t*)dev_in,
+                           dev_out, n, mean, sd, lo, hi);
+    else if (in_dtype == 0)
         hipLaunchKernelGGL(k_ct_normalize<int16_t>, dim3(grid), dim3(block), 0, c->stream, (const int16_t*)dev_in,
                            dev_out, n, mean, sd, lo, hi);
     else

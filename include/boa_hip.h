@@ -72,7 +72,8 @@ int boa_prof_get(boa_ctx* ctx, int kclass, double* total_ms, long long* launches
 
 /* ------------------------------------------------------------------ sliding-window arithmetic seams -- */
 /* CTNormalization.run (NN/preprocessing/normalization/default_normalization_schemes.py:53-67):
- * out = ((float)clip(in, lo, hi) - mean) / max(std, 1e-8) in fp32.  in_dtype: 0 = int16, 1 = float32. */
+ * out = ((float)clip(in, lo, hi) - mean) / max(std, 1e-8) in fp32.  in_dtype: 0 = int16, 1 = float32, 2 = int32
+ * (the dtype TS/nnunet.py:472-474 resamples to; the nibabel reader casts it to float32). */
 int boa_ct_normalize(boa_ctx* ctx, const void* dev_in, int in_dtype, float* dev_out, size_t n,
                      float mean, float std, float lo, float hi);
 

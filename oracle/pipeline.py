@@ -27,3 +27,54 @@ def predict_total(ct_xyz, part_models, class_map_inv, step_size=0.8):
         maps.append(pmap)
     comb = labels.merge_parts(segs, maps, class_map_inv)
     return np.ascontiguousarray(comb.transpose(2, 1, 0))
+
+
+def predict_part(data_xyz, models, class_map_inv, step_size, multimodel):
+    """One s0k_0000 sub-volume through every model (TS/nnunet.py:536-559 or :566-573)."""
+    data = np.ascontiguousarray(data_xyz.transpose(2, 1, 0))[None].astype(np.float32)
+    bbox = labels.nonzero_bbox(data)
+    sl = tuple(slice(a, b) for a, b in bbox)
+    crop = data[(slice(None),) + sl]
+    segs, maps = [], []
+    for fns, patch, heads, ip, pmap in models:
+        fns = fns if isinstance(fns, (list, tuple)) else [fns]
+        x = labels.ct_normalize(crop[0], ip["mean"], ip["std"], ip["percentile_00_5"], ip["percentile_99_5"])[None]
+        lg = sw.ensemble_folds([sw.predict_sliding_window_return_logits(fn, x, list(patch), heads, step_size)
+                                for fn in fns])
+        seg = np.zeros(data.shape[1:], dtype=np.uint8)
+        seg[sl] = labels.argmax_labels(lg)
+        segs.append(seg)
+        maps.append(pmap)
+    comb = labels.merge_parts(segs, maps, class_map_inv) if multimodel else segs[0]
+    return np.ascontiguousarray(comb.transpose(2, 1, 0))
+
+
+def predict_image(ct_xyz, spacing_xyz, models, class_map_inv=None, task_name="total", resample=1.5,
+                  resample_only_thickness=False, multimodel=True, force_split=False):
+    """TS/nnunet.py:nnUNet_predict_image (:453-699) for an input that is already RAS-canonical: resample (order 3 ->
+    int32), optional triple z-split, predict, recombine, resample back (order 0)."""
+    from . import resample as orsp
+    spacing = np.array(spacing_xyz, dtype=np.float32)
+    rsp = None if resample is None else [float(resample)] * 3
+    if resample_only_thickness:
+        rsp = [spacing[0], spacing[1], rsp[0]]
+    if rsp is not None:
+        img, zoom = orsp.change_spacing_array(ct_xyz, spacing, rsp, order=3, dtype=np.int32)
+    else:
+        img, zoom = ct_xyz, None
+    step = 0.8 if (task_name == "total" and rsp is not None and rsp[0] < 3.0) else 0.5
+    ss = img.shape
+    if (np.prod(ss) > 512 * 512 * 900 and ss[2] > 200 and multimodel) or force_split:
+        third, margin = ss[2] // 3, 20
+        p1 = predict_part(img[:, :, :third + margin], models, class_map_inv, step, multimodel)
+        p2 = predict_part(img[:, :, third + 1 - margin:third * 2 + margin], models, class_map_inv, step, multimodel)
+        p3 = predict_part(img[:, :, third * 2 + 1 - margin:], models, class_map_inv, step, multimodel)
+        seg = np.zeros(ss, dtype=np.uint8)
+        seg[:, :, :third] = p1[:, :, :-margin]
+        seg[:, :, third:third * 2] = p2[:, :, margin - 1:-margin]
+        seg[:, :, third * 2:] = p3[:, :, margin - 1:]
+    else:
+        seg = predict_part(img, models, class_map_inv, step, multimodel)
+    if rsp is not None and zoom is not None:
+        seg, _ = orsp.change_spacing_array(seg, rsp, rsp, target_shape=ct_xyz.shape, order=0, dtype=np.uint8)
+    return seg

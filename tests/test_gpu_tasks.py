@@ -1,0 +1,116 @@
+"""End-to-end task driver on the GPU vs the oracle pipeline: canonicalisation, device resampling
+to the model spacing and back, triple z-split, multi-fold BCA nets at (sx, sy, 5 mm).
+
+Label agreement bar: the networks run in fp16 on the device and fp32 in the oracle, so argmax flips are possible at
+near-ties of random-weight logits; everything around the network (resampling, cropping, splitting, merging, restore)
+is integer-exact -- a structural error would show up as a large disagreement, the bars below only leave room for
+near-tie flips (>= 97 % agreement, same bar as the `total` pipeline test)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from boa_hip.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _model(tid, nc, seed, spacing_zyx, folds=1, patch=(32, 32, 32)):
+    import torch
+    from boa_hip import plans
+    from oracle.network import build_from_arch, network_fn_from_module
+    pj, dj = plans.synthetic_plans(patch=patch, features=(32, 64), num_classes=nc, spacing=spacing_zyx)
+    cfg = plans.model_config_from_plans(pj, dj)
+    blobs, fns = [], []
+    for f in range(folds):
+        sd = plans.synthetic_state_dict(cfg.geometry, seed=seed + 17 * f)
+        blobs.append(plans.weight_blob_from_state_dict(cfg.geometry, sd))
+        net = build_from_arch(pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"], 1, nc)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        fns.append(network_fn_from_module(net, 8))
+    return (tid, cfg, blobs), (fns, patch, nc, cfg.intensity_properties["0"])
+
+
+def _ct(shape, seed):
+    rng = np.random.default_rng(seed)
+    ct = rng.normal(0, 300, size=shape).astype(np.int16)
+    ct[ct == 0] = 1
+    return ct
+
+
+def test_total_resampled_lps_input(ctx):
+    """0.9 x 0.9 x 2.0 mm CT stored in LPS order: canonicalise (flip x, y), cubic resample to 1.5 mm, 5 part models,
+    merge, nearest resample back, flip back."""
+    from boa_hip import label_maps, totalseg
+    from oracle import pipeline as opipe
+    ct_ras = _ct((60, 52, 40), 1)
+    ct_ras[:4] = 0                                                  # nnU-Net crop_to_nonzero has something to crop
+    sp = (0.9, 0.9, 2.0)
+    models, omodels = [], []
+    for tid, nc in zip(label_maps.PART_TASK_IDS, (25, 27, 19, 24, 27)):
+        m, o = _model(tid, nc, tid, (1.5, 1.5, 1.5))
+        models.append(m)
+        omodels.append(o + (label_maps.CLASS_MAP_PARTS[tid],))
+    want_ras = opipe.predict_image(ct_ras, sp, omodels, label_maps.CLASS_MAP_TOTAL_INV, "total", 1.5)
+    # the same volume as an LPS file: array flipped along x and y, affine diag(-sx, -sy, sz) with the matching origin
+    ct_lps = np.ascontiguousarray(ct_ras[::-1, ::-1, :])
+    aff = np.diag([-sp[0], -sp[1], sp[2], 1.0])
+    aff[:3, 3] = [sp[0] * (ct_ras.shape[0] - 1), sp[1] * (ct_ras.shape[1] - 1), 0.0]
+    ts = totalseg.TotalSegmentatorHip(ctx, models, max_batch=4)
+    got = ts.predict(ct_lps, affine=aff)
+    ts.close()
+    assert got.shape == ct_lps.shape and got.dtype == np.uint8
+    agree = float((got[::-1, ::-1, :] == want_ras).mean())
+    print("total (resampled, LPS) agreement", agree, "labels", len(np.unique(got)))
+    assert agree >= 0.97
+
+
+def test_force_split_matches_oracle(ctx):
+    """Triple z-split bookkeeping (TS/nnunet.py:495-505, :583-586) with a single-model task at its own spacing."""
+    from boa_hip.task import SegmentationTask, split_bounds
+    from oracle import pipeline as opipe
+    parts, comb = split_bounds(1024)                                 # [:361], [322:702], [663:]
+    assert parts == [(0, 361), (322, 702), (663, 1024)]
+    assert [(d.start, d.stop) for d, _ in comb] == [(0, 341), (341, 682), (682, 1024)]
+    ct = _ct((36, 34, 150), 2)
+    m, o = _model(900, 5, 900, (1.5, 1.5, 1.5))
+    want = opipe.predict_image(ct, (1.5, 1.5, 1.5), [o + (None,)], None, "other", 1.5, multimodel=False, force_split=True)
+    t = SegmentationTask(ctx, "other", [m], resample=1.5, max_batch=4)
+    got = t.predict_image(ct, np.diag([1.5, 1.5, 1.5, 1.0]), force_split=True)
+    nosplit = t.predict_image(ct, np.diag([1.5, 1.5, 1.5, 1.0]))
+    t.close()
+    agree = float((got == want).mean())
+    print("force_split agreement", agree, "split vs unsplit", float((got == nosplit).mean()))
+    assert agree >= 0.97
+
+
+def test_bca_nets_thickness_resampling_5_folds(ctx):
+    """body_regions-like task: resample_only_thickness to 5 mm, 5 folds averaged in fp16, step 0.5, single model."""
+    from boa_hip.task import SegmentationTask
+    from oracle import pipeline as opipe
+    ct = _ct((40, 36, 90), 3)
+    sp = (0.8, 0.8, 2.0)
+    m, o = _model(542, 12, 542, (5.0, 0.8, 0.8), folds=5)
+    want = opipe.predict_image(ct, sp, [o + (None,)], None, "body_regions", 5.0, resample_only_thickness=True,
+                               multimodel=False)
+    t = SegmentationTask(ctx, "body_regions", [m], resample=5.0, resample_only_thickness=True, max_batch=4)
+    assert t.step_size == 0.5
+    got = t.predict_image(ct, np.diag([sp[0], sp[1], sp[2], 1.0]))
+    t.close()
+    assert got.shape == ct.shape
+    agree = float((got == want).mean())
+    print("BCA 5-fold thickness-resampled agreement", agree)
+    assert agree >= 0.97
+
+
+def test_plan_spacing_mismatch_raises(ctx):
+    from boa_hip.task import SegmentationTask
+    m, _ = _model(542, 4, 1, (5.0, 1.0, 1.0))
+    t = SegmentationTask(ctx, "body_regions", [m], resample=5.0, resample_only_thickness=True)
+    with pytest.raises(NotImplementedError):
+        t.predict_image(_ct((34, 34, 40), 4), np.diag([0.8, 0.8, 2.0, 1.0]))
+    t.close()
