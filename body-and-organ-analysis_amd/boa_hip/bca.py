@@ -168,12 +168,13 @@ def _descriptive(df, counts_a, sums_a, lo, hi):
     return m.replace({np.nan: None})
 
 
-def bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae=None) -> dict:
+def bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae=None, body_parts_override=None) -> dict:
     ml = np.prod(spacing_xyz) / 1000.0
     depth = counts.shape[0]
     df = _slicewise(counts[:, 0], ml)
     d2 = _slicewise(counts[:, 1], ml)
-    parts = examined_body_part(present, spacing_xyz)
+    # run_pipeline: `builder.examined_body_part` is the detected flag set unless examined_body_region is given (:150-165)
+    parts = dict(body_parts_override) if body_parts_override is not None else examined_body_part(present, spacing_xyz)
     groups = aggregation_groups(present, depth, parts, vertebrae)
     agg = {}
     for name, lo, hi in groups:
@@ -193,7 +194,8 @@ def bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebra
 
 
 def bca_measurements(ctx: Context, ct: np.ndarray, regions: np.ndarray, parts: np.ndarray, spacing_xyz,
-                     vertebrae=None, return_tissues: bool = False, median_filtering: bool = False, orientation="LPS"):
+                     vertebrae=None, return_tissues: bool = False, median_filtering: bool = False, orientation="LPS",
+                     body_parts_override=None):
     """CT (z,y,x) int16 + body_regions + body_parts -> bca-measurements dict (+ tissues array).
     median_filtering: subclassify on the 3x3 in-plane median of the CT (run_pipeline(median_filtering=True))."""
     if ct.shape != regions.shape or ct.shape != parts.shape:
@@ -208,7 +210,7 @@ def bca_measurements(ctx: Context, ct: np.ndarray, regions: np.ndarray, parts: n
             d_med = median_filter_inplane(ctx, d_ct, shape, slice_axis_from_orientation(orientation))
         tis, counts, hu_sums = tissue_aggregate(ctx, d_ct, d_rg, d_pt, shape, want_tissues=return_tissues, ct_rules=d_med)
         present = slice_label_presence(ctx, d_rg, shape)
-        out = bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae)
+        out = bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae, body_parts_override)
         if return_tissues:
             t = tis.download(shape, np.uint8)
             tis.free()

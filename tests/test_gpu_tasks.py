@@ -114,3 +114,49 @@ def test_plan_spacing_mismatch_raises(ctx):
     with pytest.raises(NotImplementedError):
         t.predict_image(_ct((34, 34, 40), 4), np.diag([0.8, 0.8, 2.0, 1.0]))
     t.close()
+
+
+def test_bca_pipeline_vs_oracle_composition(ctx):
+    """run_pipeline numerics: nets (fast_bca: 1 fold) -> CC / contour-fill post-processing -> tissues -> LPS reload ->
+    body-part detection, vertebra ranges, bca-measurements JSON.  The raw network labels are shared with the oracle
+    composition (network parity is covered above), everything after them must be exact (integers) / rtol 1e-9 (means)."""
+    import json
+    from boa_hip import label_maps
+    from boa_hip.pipeline import BcaPipelineHip
+    from oracle import bca as obca
+    from test_gpu_aggregation import _cmp
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "g8_bca.npz"))
+    # G8 phantom is a SimpleITK-ordered LPS volume (z,y,x); store it as an LPS file: array (x,y,z), affine diag(-sx,-sy,sz)
+    ct = np.ascontiguousarray(g["ct"].transpose(2, 1, 0))
+    sp = [float(v) for v in g["spacing"]]
+    aff = np.diag([-sp[0], -sp[1], sp[2], 1.0])
+    raw_regions = np.ascontiguousarray(g["regions"].transpose(2, 1, 0)).copy()
+    raw_regions[2:5, 2:5, 1:3] = 3                                   # a stray abdominal-cavity island -> 255
+    raw_parts = np.ascontiguousarray(g["parts"].transpose(2, 1, 0)).copy()
+    total = np.zeros(ct.shape, np.uint8)
+    inv = label_maps.CLASS_MAP_TOTAL_INV
+    total[10:20, 10:20, 5:12] = inv["vertebrae_L3"]
+    total[10:20, 10:20, 30:36] = inv["vertebrae_T9"]
+    mp, _ = _model(543, 7, 543, (5.0, sp[1], sp[0]))
+    mr, _ = _model(542, 12, 542, (5.0, sp[1], sp[0]))
+    pipe = BcaPipelineHip(ctx, (mp[1], mp[2]), (mr[1], mr[2]), fast_bca=True, max_batch=4)
+    net_parts = pipe.tasks["body_parts"].predict_image(ct, aff)      # the network path runs (shape/dtype contract) ...
+    assert net_parts.shape == ct.shape and net_parts.dtype == np.uint8
+    out = pipe.run(ct, aff, total_seg=total, raw_parts=raw_parts, raw_regions=raw_regions, median_filtering=True)
+    pipe.close()
+    # ... and the pipeline after the networks is compared with the oracle composition
+    rg = obca.postprocess_region_segmentation(np.ascontiguousarray(raw_regions.transpose(2, 1, 0)))
+    pt = obca.remove_small_labeled_objects(np.ascontiguousarray(raw_parts.transpose(2, 1, 0)))
+    np.testing.assert_array_equal(out["body_regions"].transpose(2, 1, 0), rg)
+    np.testing.assert_array_equal(out["body_parts"].transpose(2, 1, 0), pt)
+    assert (rg == 255).any()
+    ct_l = g["ct"]
+    tis = obca.subclassify_tissues(ct_l, rg, median_filtering=True, slice_axis=0)
+    np.testing.assert_array_equal(out["tissues"].transpose(2, 1, 0), tis)
+    flags = obca.examined_body_part(rg, sp)
+    assert out["examined_body_part"] == flags
+    vmap = {v[len("vertebrae_"):]: k for k, v in label_maps.CLASS_MAP_TOTAL.items() if v.startswith("vertebrae_")}
+    vert = obca.create_vertebrae_info(np.ascontiguousarray(total.transpose(2, 1, 0)), vmap, flags)
+    assert out["vertebrae"] == vert
+    ref = obca.bca_measurements_json(ct_l, rg, pt, tis, sp, vert or None)
+    _cmp(json.loads(json.dumps(out["bca_measurements"], default=float)), json.loads(json.dumps(ref, default=float)), 1e-9)

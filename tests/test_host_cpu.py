@@ -103,7 +103,8 @@ def test_every_product_module_imports():
     import importlib
     for m in ("boa_hip", "boa_hip._lib", "boa_hip.device", "boa_hip.sliding_window", "boa_hip.plans", "boa_hip.predictor",
               "boa_hip.synthetic", "boa_hip.label_maps", "boa_hip.bca", "boa_hip.measurements", "boa_hip.compute.config",
-              "boa_hip.compute.constants", "boa_hip.compute.util"):
+              "boa_hip.compute.constants", "boa_hip.compute.util", "boa_hip.totalseg", "boa_hip.task", "boa_hip.pipeline",
+              "boa_hip.resample", "boa_hip.orientation", "boa_hip.distributed"):
         importlib.import_module(m)
 
 
@@ -121,3 +122,54 @@ def test_stats_from_hist_matches_numpy():
         assert st["p25"] == float(np.percentile(x, 25)) and st["p75"] == float(np.percentile(x, 75))
         assert np.isclose(st["std"], float(np.std(x)), rtol=1e-12, atol=1e-12)
     assert M.stats_from_hist(np.zeros(M.NBINS, np.int64)) is None
+
+
+def test_orientation_restatement():
+    """nibabel.orientations restated (boa_hip/orientation.py): hand-checked affines, world-coordinate consistency of the
+    reoriented affine, undo_canonical round trip for every axis permutation x flip."""
+    import itertools
+    from boa_hip import orientation as o
+    assert o.aff2axcodes(np.diag([1.5, 1.5, 1.5, 1])) == ("R", "A", "S")
+    assert o.aff2axcodes(np.diag([-0.8, -0.8, 3.0, 1])) == ("L", "P", "S")
+    a = np.arange(2 * 3 * 4).reshape(2, 3, 4)
+    for perm in itertools.permutations(range(3)):
+        for flips in itertools.product([1, -1], repeat=3):
+            aff = np.zeros((4, 4))
+            for in_ax, (out_ax, f) in enumerate(zip(perm, flips)):
+                aff[out_ax, in_ax] = f * (0.7 + 0.4 * in_ax)
+            aff[:3, 3] = [11.0, -7.0, 3.0]
+            aff[3, 3] = 1
+            # slightly oblique: the closest axis still wins
+            aff[:3, :3] += 0.01
+            c, caff, ornt = o.as_closest_canonical(a, aff)
+            assert o.aff2axcodes(caff) == ("R", "A", "S")
+            assert [int(v) for v in ornt[:, 0]] == list(perm)
+            for idx in [(0, 0, 0), (1, 2, 3), (1, 0, 2)]:
+                pos = np.argwhere(c == a[idx])[0]
+                assert np.allclose(caff @ np.append(pos, 1.0), aff @ np.append(idx, 1.0))
+            assert np.array_equal(o.undo_canonical(c, aff), a)
+            l, laff = o.with_axcodes(a, aff, "LPS")
+            assert o.aff2axcodes(laff) == ("L", "P", "S")
+            pos = np.argwhere(l == a[1, 2, 3])[0]
+            assert np.allclose(laff @ np.append(pos, 1.0), aff @ np.array([1, 2, 3, 1.0]))
+
+
+def test_task_bookkeeping():
+    from boa_hip.task import get_bbox_from_mask, nonzero_bbox, split_bounds
+    parts, comb = split_bounds(1024)       # SURVEY 8b / TS/nnunet.py:496-505,583-586
+    assert parts == [(0, 361), (322, 702), (663, 1024)]
+    full = np.zeros(1024, int)
+    for (lo, hi), (dst, src) in zip(parts, comb):
+        full[dst] = np.arange(lo, hi)[src]
+    assert np.array_equal(full, np.arange(1024))      # every slice comes from the part where it is >= 19 slices from a cut
+    for nz in (201, 230, 599, 768):
+        parts, comb = split_bounds(nz)
+        full = np.full(nz, -1)
+        for (lo, hi), (dst, src) in zip(parts, comb):
+            full[dst] = np.arange(lo, hi)[src]
+        assert np.array_equal(full, np.arange(nz))
+    m = np.zeros((10, 12, 14))
+    m[3:6, 4:5, 7:12] = 1
+    assert get_bbox_from_mask(m, 0, [2, 2, 3]) == [[1, 8], [2, 7], [4, 14]]
+    assert get_bbox_from_mask(np.zeros((3, 4, 5)), 0, 1) == [[0, 3], [0, 4], [0, 5]]
+    assert nonzero_bbox(m) == [[3, 6], [4, 5], [7, 12]]
