@@ -1,0 +1,157 @@
+"""File-level mirror of BOA/compute/inference.py: `compute_all_models` (:50-144) with the reference's signature,
+outputs and folder contract, on the device engine.
+
+Supported models: `total`, `bca`, `body_parts`, `body_regions` (the hot path of BASELINE.json's configs 1-4).  The
+crop-cascade models of `--models all` (lung_vessels, cerebral_bleed, ...) raise NotImplementedError
+-- they are not silently skipped.  Weights come from `$nnUNet_results` (boa_hip/model_store.py); nothing is downloaded.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import pathlib
+from typing import Any, Dict, Iterable, Optional, Union
+
+import numpy as np
+
+from .. import label_maps, model_store, nifti, orientation
+from ..device import Context
+from ..pipeline import BcaPipelineHip
+from ..task import SegmentationTask
+from .config import resolve_device
+from .constants import BASE_MODELS
+from .measurements import compute_measurements
+from .util import convert_resampling_slices
+
+logger = logging.getLogger(__name__)
+
+_CTX: Dict[int, Context] = {}
+BODY_PARTS_MAP = {1: "torso", 2: "head", 3: "arms", 4: "legs", 5: "others", 6: "breasts"}   # BCA/body_parts/definition.py
+
+
+def get_context(device: Optional[str] = None) -> Context:
+    """One Context per GPU per process.  device: the reference's `device` parameter ("gpu", "gpu:1", "hip", ...)."""
+    dev = resolve_device(device)
+    if dev in ("cpu", "mps"):
+        raise RuntimeError(f"device {dev!r} requested: this engine only runs on an MI355X (no CPU fallback)")
+    idx = int(dev.split(":")[1]) if ":" in dev else 0
+    if idx not in _CTX or _CTX[idx].h is None:
+        _CTX[idx] = Context(idx)
+    return _CTX[idx]
+
+
+def range_warning(ct_image_data: np.ndarray) -> None:
+    if np.any(ct_image_data < -1024) or np.any(ct_image_data > 3071):
+        logger.warning("Unexpected CT values found in input image: got %s-%s, expected -1024-3071. The values have been "
+                       "clipped to the expected range. Please check the segmentations to ensure that everything is correct.",
+                       np.min(ct_image_data), np.max(ct_image_data))
+
+
+def print_and_collect_image_info(ct_path: pathlib.Path):
+    data, affine, hdr = nifti.load(ct_path)
+    if data.ndim != 3:
+        raise ValueError(f"Only 3D CT scans are supported not {data.ndim}D.")
+    logger.info("Input image:   %s", ct_path)
+    logger.info("Image size:    %s", hdr.get_data_shape())
+    logger.info("Image dtype:   %s", hdr.get_data_dtype())
+    logger.info("Voxel spacing: %s", hdr.get_zooms())
+    logger.info("Input Axcodes: %s", orientation.aff2axcodes(affine))
+    lps, laff = orientation.with_axcodes(data, affine, "LPS")
+    range_warning(nifti.fdata(data, hdr))
+    return lps.shape, tuple(orientation.zooms_from_affine(laff))
+
+
+def _ct_array(data, hdr):
+    """What the segmentation tasks see: get_fdata() values; integer-valued unscaled files stay int16 (same values)."""
+    f = nifti.fdata(data, hdr)
+    if data.dtype == np.int16 and np.array_equal(f, data):
+        return data
+    return f
+
+
+def compute_all_models(
+    ct_path: pathlib.Path,
+    segmentation_folder: pathlib.Path,
+    models_to_compute: Union[Iterable[str], str],
+    totalsegmentator_params: Dict[str, Any],
+    fast_bca: bool = False,
+    bca_params: Optional[Dict[str, Any]] = None,
+    force_split_threshold: int = 400,
+    recompute: bool = True,
+    cnr_adjustment: bool = True,
+) -> Dict[str, int]:
+    ct_path, segmentation_folder = pathlib.Path(ct_path), pathlib.Path(segmentation_folder)
+    totalsegmentator_params = dict(totalsegmentator_params or {})
+    bca_params = dict(bca_params or {})
+    totalsegmentator_params.pop("preview", None)   # previews are rendering, not on this path
+    models_to_compute = [models_to_compute] if isinstance(models_to_compute, str) else list(models_to_compute)
+    shape, spacing = print_and_collect_image_info(ct_path)
+    measurement_models = [m for m in models_to_compute if m not in BASE_MODELS]
+    stats = {
+        "num_voxels": int(shape[0] * shape[1] * shape[2]),
+        "num_slices": int(shape[2]),
+        "num_slices_resampled": convert_resampling_slices(slices=shape[-1], current_sampling=spacing[-1], target_resampling=1.5),
+    }
+    unsupported = [m for m in measurement_models if m != "total"]
+    if unsupported:
+        raise NotImplementedError(f"models {unsupported} (crop-cascade tasks of `--models all`) are not implemented on the device yet")
+    segmentation_folder.mkdir(parents=True, exist_ok=True)
+    ctx = get_context(totalsegmentator_params.get("device"))
+    data, affine, hdr = nifti.load(ct_path)
+    ct = _ct_array(data, hdr)
+
+    for chosen_task in measurement_models:
+        logger.info("Computing model %s...", chosen_task)
+        seg_file = segmentation_folder / f"{chosen_task}.nii.gz"
+        if not recompute and seg_file.is_file():
+            logger.info("The model was already computed, skipping...")
+            continue
+        fast = bool(totalsegmentator_params.get("fast", False))
+        key = "total_fast" if fast else "total"
+        info = model_store.TASKS[key]
+        task = SegmentationTask(ctx, "total", model_store.load_task_models(key), resample=info["resample"],
+                                multimodel=not fast)
+        try:
+            seg = task.predict_image(ct, affine)
+        finally:
+            task.close()
+        nifti.save(seg_file, seg, affine, like=hdr, extensions=[(0, nifti.label_xml(label_maps.CLASS_MAP_TOTAL))])
+
+    measurement_file = segmentation_folder / "total-measurements.json"
+    if measurement_models and (recompute or not measurement_file.is_file()):
+        json_data = compute_measurements(ct_path=ct_path, segmentation_folder=segmentation_folder,
+                                         models=measurement_models, cnr_adjustment=cnr_adjustment, ctx=ctx)
+        with measurement_file.open("w") as ofile:
+            json.dump(json_data, ofile, indent=2)
+    else:
+        logger.info("The total measurements were already computed, skipping...")
+
+    for boa_task in sorted(BASE_MODELS & set(models_to_compute)):
+        resampling_bca = convert_resampling_slices(slices=shape[-1], current_sampling=spacing[-1], target_resampling=5.0)
+        force_split = resampling_bca > force_split_threshold
+        if force_split:
+            logger.info("Splitting the image into parts as the number of slices %s is more than %s", resampling_bca,
+                        force_split_threshold)
+        pm = model_store.load_task_models("body_parts", fast_bca)[0]
+        rm = model_store.load_task_models("body_regions", fast_bca)[0]
+        pipe = BcaPipelineHip(ctx, (pm[1], pm[2]), (rm[1], rm[2]), fast_bca=fast_bca)
+        try:
+            if boa_task == "bca":
+                total_file = segmentation_folder / "total.nii.gz"
+                total = nifti.load(total_file)[0] if total_file.is_file() else None
+                out = pipe.run(ct, affine, total_seg=total, force_split=force_split,
+                               median_filtering=bool(bca_params.get("median_filtering", False)),
+                               examined_body_region=bca_params.get("examined_body_region"))
+                for name in ("body_parts", "body_regions", "tissues"):
+                    nifti.save(segmentation_folder / f"{name}.nii.gz", out[name], affine, like=hdr)
+                if out["vertebrae"]:
+                    with (segmentation_folder / "vertebrae.json").open("w") as ofile:
+                        json.dump(out["vertebrae"], ofile, indent=2)
+                with (segmentation_folder / "bca-measurements.json").open("w") as ofile:
+                    json.dump(out["bca_measurements"], ofile, indent=2, default=float)
+            else:
+                seg = pipe.inference(boa_task, ct, affine, force_split=force_split)
+                nifti.save(segmentation_folder / f"{boa_task}.nii.gz", seg, affine, like=hdr)
+        finally:
+            pipe.close()
+    return stats

@@ -1,0 +1,52 @@
+"""File-level mirror of BOA/compute/measurements.py:compute_measurements (:244-343): reads the CT and the
+segmentation NIfTIs of the output folder, runs the per-label HU statistics on the device (boa_hip/measurements.py)
+and writes ct_pfav.nii.gz as `ct_pfav` does (:196-198)."""
+from __future__ import annotations
+
+import logging
+import pathlib
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from .. import label_maps, nifti
+from .. import measurements as M
+from ..device import Context
+
+logger = logging.getLogger(__name__)
+
+
+def compute_measurements(ct_path: pathlib.Path, segmentation_folder: pathlib.Path, models: List[str],
+                         cnr_adjustment: bool, ctx: Optional[Context] = None) -> Dict[str, Any]:
+    measurements: Dict[str, Any] = {"segmentations": {}, "info": {}}
+    if len(models) == 0:
+        return measurements
+    logger.info("Computing measurements for the computed segmentations: %s", models)
+    if ctx is None:
+        from .inference import get_context
+        ctx = get_context(None)
+    segmentation_folder = pathlib.Path(segmentation_folder)
+    data, _, hdr = nifti.load(ct_path)
+    ct = np.ascontiguousarray(nifti.fdata(data, hdr).transpose(2, 1, 0))       # SimpleITK view (z,y,x)
+    spacing = tuple(float(v) for v in hdr.get_zooms())
+    am = asd = None
+    for model_name in sorted(models, key=lambda m: m != "total"):
+        model_path = segmentation_folder / f"{model_name}.nii.gz"
+        if not model_path.exists():
+            continue
+        if model_name != "total":
+            raise NotImplementedError(f"measurements for model {model_name!r} are not implemented on the device yet")
+        seg, saff, shdr = nifti.load(model_path)
+        if not np.isclose(spacing, tuple(float(v) for v in shdr.get_zooms())).all():
+            raise ValueError("The spacing of the image and of the segmentation should be the same")
+        label_map = {name: k for k, name in label_maps.CLASS_MAP_TOTAL.items()}
+        meas, fat_mask = M.total_measurements(ctx, ct.astype(np.int16), np.ascontiguousarray(seg.transpose(2, 1, 0)),
+                                              label_map, spacing, cnr_adjustment=cnr_adjustment)
+        measurements["segmentations"].update(meas["segmentations"])
+        if "cnr_adjusted" in meas:
+            measurements["cnr_adjusted"] = meas["cnr_adjusted"]
+        am, asd = meas["info"].get("autochthon_mean"), meas["info"].get("autochthon_std")
+        nifti.save(segmentation_folder / "ct_pfav.nii.gz", np.ascontiguousarray(fat_mask.transpose(2, 1, 0)), saff, like=shdr)
+    measurements["info"]["autochthon_mean"] = am
+    measurements["info"]["autochthon_std"] = asd
+    return measurements

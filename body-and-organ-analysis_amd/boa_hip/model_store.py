@@ -1,0 +1,78 @@
+"""Model-folder contract (SURVEY 8b "Model-folder contract"): find and load nnU-Net v2 model folders below
+`$nnUNet_results` (= TOTALSEG_WEIGHTS_PATH, or ~/.totalsegmentator/nnunet/results; TS/config.py:26-51):
+    DatasetNNN_<name>/<trainer>__nnUNetPlans__<config>/{dataset.json, plans.json, fold_k/checkpoint_final.pth}
+(NN/utilities/file_path_utilities.py:19-26; dataset dir found by its `DatasetNNN` prefix,
+NN/utilities/dataset_name_id_conversion.py:21-35).  Nothing is downloaded: a missing folder raises."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from . import plans as P
+
+# task tables: TS/python_api.py:168-189 (`total`, fast variant), BCA/tasks.py:15-48
+TASKS: Dict[str, dict] = {
+    "total": {"task_id": [291, 292, 293, 294, 295], "resample": 1.5, "trainer": "nnUNetTrainerNoMirroring", "folds": [0]},
+    "total_fast": {"task_id": [297], "resample": 3.0, "trainer": "nnUNetTrainer_4000epochs_NoMirroring", "folds": [0]},
+    "body_parts": {"task_id": [543], "resample": 5.0, "trainer": "nnUNetTrainer_1500epochs_NoMirroring",
+                   "folds": [0, 1, 2, 3, 4], "resample_only_thickness": True},
+    "body_regions": {"task_id": [542], "resample": 5.0, "trainer": "nnUNetTrainerNoMirroring", "folds": [0, 1, 2, 3, 4],
+                     "resample_only_thickness": True},
+}
+
+
+def results_dir() -> str:
+    for var in ("nnUNet_results", "TOTALSEG_WEIGHTS_PATH"):
+        if os.environ.get(var):
+            return os.environ[var]
+    return os.path.join(os.path.expanduser("~"), ".totalsegmentator", "nnunet", "results")
+
+
+def find_dataset_dir(dataset_id: int, root: str = None) -> str:
+    root = root or results_dir()
+    prefix = "Dataset%03d" % dataset_id
+    if not os.path.isdir(root):
+        raise FileNotFoundError(f"nnUNet_results folder {root!r} does not exist (weights are never downloaded here)")
+    hits = sorted(d for d in os.listdir(root) if d.startswith(prefix) and os.path.isdir(os.path.join(root, d)))
+    if len(hits) != 1:
+        raise RuntimeError(f"Found {'no' if not hits else 'more than one'} dataset folder for {prefix} in {root}: {hits}")
+    return os.path.join(root, hits[0])
+
+
+def load_task_models(task: str, fast_bca: bool = False, root: str = None, configuration: str = "3d_fullres"
+                     ) -> List[Tuple[int, P.ModelConfig, List[np.ndarray]]]:
+    """-> [(task_id, ModelConfig, [weight blob per fold])] for SegmentationTask."""
+    info = TASKS[task]
+    folds: Sequence[int] = [0] if (fast_bca and task in ("body_parts", "body_regions")) else info["folds"]
+    out = []
+    for tid in info["task_id"]:
+        folder = os.path.join(find_dataset_dir(tid, root), f"{info['trainer']}__nnUNetPlans__{configuration}")
+        cfg = P.load_model_folder(folder, configuration)
+        blobs = []
+        for f in folds:
+            ck = os.path.join(folder, f"fold_{f}", "checkpoint_final.pth")
+            blobs.append(P.weight_blob_from_state_dict(cfg.geometry, P.load_checkpoint(ck)))
+        out.append((tid, cfg, blobs))
+    return out
+
+
+def write_model_folder(root: str, dataset_id: int, name: str, trainer: str, plans: dict, dataset_json: dict,
+                       state_dicts: Sequence[Dict[str, np.ndarray]], configuration: str = "3d_fullres") -> str:
+    """Write a model folder in the layout above (used for synthetic weights in tests / benchmarks)."""
+    import json
+    import torch
+    folder = os.path.join(root, "Dataset%03d_%s" % (dataset_id, name), f"{trainer}__nnUNetPlans__{configuration}")
+    os.makedirs(folder, exist_ok=True)
+    with open(os.path.join(folder, "plans.json"), "w") as f:
+        json.dump(plans, f)
+    with open(os.path.join(folder, "dataset.json"), "w") as f:
+        json.dump(dataset_json, f)
+    for k, sd in enumerate(state_dicts):
+        os.makedirs(os.path.join(folder, f"fold_{k}"), exist_ok=True)
+        torch.save({"network_weights": {n: torch.from_numpy(np.asarray(v)) for n, v in sd.items()},
+                    "trainer_name": trainer, "init_args": {"configuration": configuration},
+                    "inference_allowed_mirroring_axes": None},
+                   os.path.join(folder, f"fold_{k}", "checkpoint_final.pth"))
+    return folder

@@ -1,0 +1,195 @@
+"""Minimal NIfTI-1 single-file (.nii / .nii.gz) reader and writer for the folder contract of the path (SURVEY 8b
+"File contract"; 8f rank 3).  Implements the published NIfTI-1.1 header layout (348-byte header, 4-byte extender,
+extensions, data at vox_offset) -- enough for what the reference does with nibabel on this path:
+  * `nib.load(p).get_fdata()` / `.affine` / `.header.get_zooms()`: data scaled by scl_slope/scl_inter, best affine =
+    sform (sform_code > 0) else qform (qform_code > 0) else pixdim-only;
+  * `new_header = img_in_orig.header.copy(); new_header.set_data_dtype(np.uint8)` + label-table XML extension
+    (ecode 0) + `nib.save` (TS/nnunet.py:723-726; TS/nifti_ext_header.py:12-42).
+nibabel itself is absent in this image; files written here were round-tripped through this reader only (PARITY
+UNPINNED vs nibabel's byte-level output; the header fields follow the standard)."""
+from __future__ import annotations
+
+import gzip
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+_DT = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64, 256: np.int8, 512: np.uint16,
+       768: np.uint32, 1024: np.int64, 1280: np.uint64}
+_DT_INV = {np.dtype(v): k for k, v in _DT.items()}
+_HDR = "<i10s18sihcB8h3f4h8f3fhBB4f2i80s24s2h3f3f12f16s4s"   # little-endian layout, 348 bytes
+assert struct.calcsize(_HDR) == 348
+
+
+@dataclass
+class NiftiHeader:
+    raw: bytes                                   # the 348 header bytes as read (little-endian normalised)
+    dim: Tuple[int, ...]
+    datatype: int
+    pixdim: Tuple[float, ...]
+    vox_offset: float
+    scl_slope: float
+    scl_inter: float
+    qform_code: int
+    sform_code: int
+    quatern: Tuple[float, float, float]
+    qoffset: Tuple[float, float, float]
+    srow: np.ndarray
+    extensions: List[Tuple[int, bytes]] = field(default_factory=list)
+
+    def get_zooms(self) -> Tuple[float, ...]:
+        return tuple(np.float32(v) for v in self.pixdim[1:1 + self.dim[0]])
+
+    def get_data_shape(self) -> Tuple[int, ...]:
+        return tuple(self.dim[1:1 + self.dim[0]])
+
+    def get_data_dtype(self):
+        return np.dtype(_DT[self.datatype])
+
+
+def _qform(h: NiftiHeader) -> np.ndarray:
+    b, c, d = (float(v) for v in h.quatern)
+    a2 = 1.0 - (b * b + c * c + d * d)
+    a = np.sqrt(a2) if a2 > 0 else 0.0
+    R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                  [2 * (b * c + a * d), a * a + c * c - b * b - d * d, 2 * (c * d - a * b)],
+                  [2 * (b * d - a * c), 2 * (c * d + a * b), a * a + d * d - b * b - c * c]])
+    qfac = -1.0 if h.pixdim[0] < 0 else 1.0
+    zooms = np.array([h.pixdim[1], h.pixdim[2], h.pixdim[3] * qfac], dtype=np.float64)
+    aff = np.eye(4)
+    aff[:3, :3] = R * zooms
+    aff[:3, 3] = h.qoffset
+    return aff
+
+
+def best_affine(h: NiftiHeader) -> np.ndarray:
+    if h.sform_code > 0:
+        aff = np.eye(4)
+        aff[:3, :] = h.srow
+        return aff
+    if h.qform_code > 0:
+        return _qform(h)
+    aff = np.diag([h.pixdim[1], h.pixdim[2], h.pixdim[3], 1.0]).astype(np.float64)
+    shape = np.array(h.dim[1:4], dtype=np.float64)
+    aff[:3, 3] = -(shape - 1) / 2.0 * np.array(h.pixdim[1:4])
+    return aff
+
+
+def _open(path, mode):
+    return gzip.open(path, mode) if str(path).endswith(".gz") else open(path, mode)
+
+
+def load(path) -> Tuple[np.ndarray, np.ndarray, NiftiHeader]:
+    """-> (raw data array in file axis order and dtype, affine (4,4) float64, header).  `get_fdata` = fdata(...)."""
+    with _open(path, "rb") as f:
+        blob = f.read()
+    if len(blob) < 352:
+        raise ValueError(f"{path}: not a NIfTI-1 file")
+    endian = "<"
+    if struct.unpack("<i", blob[:4])[0] != 348:
+        if struct.unpack(">i", blob[:4])[0] != 348:
+            raise ValueError(f"{path}: sizeof_hdr != 348")
+        endian = ">"
+    v = struct.unpack(endian + _HDR[1:], blob[:348])
+    magic = v[-1]
+    if magic[:3] not in (b"n+1", b"ni1"):
+        raise ValueError(f"{path}: bad magic {magic!r}")
+    if magic[:3] == b"ni1":
+        raise ValueError(f"{path}: two-file NIfTI (.hdr/.img) is not supported")
+    dim = v[7:15]
+    datatype = v[19]
+    pixdim = v[22:30]
+    vox_offset, scl_slope, scl_inter = v[30], v[31], v[32]
+    qform_code, sform_code = v[44], v[45]
+    quatern, qoffset = v[46:49], v[49:52]
+    srow = np.array(v[52:64], dtype=np.float64).reshape(3, 4)
+    if datatype not in _DT:
+        raise TypeError(f"{path}: unsupported NIfTI datatype code {datatype}")
+    raw_le = struct.pack(_HDR, *v)
+    h = NiftiHeader(raw_le, tuple(int(d) for d in dim), int(datatype), tuple(float(p) for p in pixdim), float(vox_offset),
+                    float(scl_slope), float(scl_inter), int(qform_code), int(sform_code), tuple(quatern), tuple(qoffset), srow)
+    off = 352
+    if blob[348] != 0:                       # extensions present
+        while off + 8 <= int(vox_offset):
+            esize, ecode = struct.unpack(endian + "ii", blob[off:off + 8])
+            if esize < 8:
+                break
+            h.extensions.append((ecode, blob[off + 8:off + esize]))
+            off += esize
+    shape = h.get_data_shape()
+    dt = np.dtype(_DT[datatype]).newbyteorder(endian)
+    n = int(np.prod(shape))
+    data = np.frombuffer(blob, dtype=dt, count=n, offset=int(vox_offset)).reshape(shape, order="F")
+    return data.astype(dt.newbyteorder("=")), best_affine(h), h
+
+
+def fdata(data: np.ndarray, h: NiftiHeader) -> np.ndarray:
+    """nibabel's get_fdata(): float64 with scl_slope / scl_inter applied when they are set."""
+    out = data.astype(np.float64)
+    s, i = h.scl_slope, h.scl_inter
+    if np.isfinite(s) and s != 0 and not (s == 1.0 and (i == 0 or not np.isfinite(i))):
+        out = out * s + (i if np.isfinite(i) else 0.0)
+    return out
+
+
+def label_xml(label_map: Dict[int, str]) -> bytes:
+    """TS/nifti_ext_header.py:12-42 (the CaretExtension label table written into the extended header)."""
+    colors = [[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [255, 0, 255], [0, 255, 255], [255, 128, 0],
+              [255, 0, 128], [128, 255, 128], [0, 128, 255], [128, 128, 128], [185, 170, 155]]
+    pre = ('<?xml version="1.0" encoding="UTF-8"?> <CaretExtension>  <Date><![CDATA[2013-07-14T05:45:09]]></Date>   '
+           '<VolumeInformation Index="0">   <LabelTable>')
+    body = ""
+    for k, name in label_map.items():
+        r, g, b = colors[k % len(colors)]
+        body += f'<Label Key="{k}" Red="{r / 255}" Green="{g / 255}" Blue="{b / 255}" Alpha="1"><![CDATA[{name}]]></Label>\n'
+    post = ('  </LabelTable>  <StudyMetaDataLinkSet>  </StudyMetaDataLinkSet>  <VolumeType><![CDATA[Label]]></VolumeType>   '
+            '</VolumeInformation></CaretExtension>')
+    return bytes(pre + "\n" + body + "\n" + post + "\n              ", "utf-8")
+
+
+def parse_label_xml(content: bytes) -> Dict[int, str]:
+    import re
+    return {int(k): v for k, v in re.findall(r'<Label Key="(\d+)"[^>]*><!\[CDATA\[(.*?)\]\]></Label>',
+                                             content.decode("utf-8", "replace"))}
+
+
+def save(path, data: np.ndarray, affine: np.ndarray, like: Optional[NiftiHeader] = None,
+         extensions: Optional[List[Tuple[int, bytes]]] = None, compresslevel: int = 1):
+    """Write `data` (file axis order).  `like`: header to copy (pixdim units, descrip, q/s-form codes ... as
+    `img_in_orig.header.copy()` keeps them); datatype/bitpix/dim/vox_offset and the affine fields are set from the
+    arguments; scl_slope/inter are reset (label volumes are stored unscaled)."""
+    data = np.asarray(data)
+    if data.dtype not in _DT_INV:
+        raise TypeError(f"unsupported dtype {data.dtype}")
+    affine = np.asarray(affine, dtype=np.float64)
+    v = list(struct.unpack(_HDR, like.raw)) if like is not None else list(struct.unpack(_HDR, b"\0" * 348))
+    v[0] = 348
+    dim = [data.ndim] + list(data.shape) + [1] * (7 - data.ndim)
+    v[7:15] = dim
+    v[19] = _DT_INV[data.dtype]
+    v[20] = data.dtype.itemsize * 8
+    zooms = np.sqrt(np.sum(affine[:3, :3] ** 2, axis=0))
+    if like is None:
+        v[22:30] = [1.0, float(zooms[0]), float(zooms[1]), float(zooms[2]), 1.0, 1.0, 1.0, 1.0]
+        v[35] = 2 | 8                          # xyzt_units: mm, sec
+        v[44], v[45] = 0, 2                    # qform unknown, sform aligned (what nibabel writes for a bare affine)
+    v[31], v[32] = float("nan"), float("nan")   # nibabel writes nan slope/inter for unscaled data
+    v[52:64] = [float(x) for x in affine[:3, :].reshape(-1)]
+    if like is not None and like.sform_code == 0:
+        v[45] = 2
+    exts = list(extensions or [])
+    ext_blob = b""
+    for ecode, content in exts:
+        esize = 8 + len(content)
+        pad = (-esize) % 16
+        ext_blob += struct.pack("<ii", esize + pad, ecode) + content + b"\0" * pad
+    v[30] = float(352 + len(ext_blob))
+    v[-1] = b"n+1\0"
+    hdr = struct.pack(_HDR, *v)
+    with _open(path, "wb") if not str(path).endswith(".gz") else gzip.open(path, "wb", compresslevel=compresslevel) as f:
+        f.write(hdr)
+        f.write(bytes([1 if exts else 0, 0, 0, 0]))
+        f.write(ext_blob)
+        f.write(np.asfortranarray(data).tobytes(order="F"))

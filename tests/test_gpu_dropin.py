@@ -1,0 +1,81 @@
+"""File-level drop-in: `compute_all_models` with the reference's signature on a synthetic CT NIfTI and
+synthetic model folders in the `$nnUNet_results` layout; checks the folder contract and that the files carry exactly
+what the array-level pipelines (tested against the oracle elsewhere) produce."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_models(root, sp_zyx_total, sp_zyx_bca):
+    from boa_hip import label_maps, model_store, plans
+    for tid, nc in zip(label_maps.PART_TASK_IDS, (25, 27, 19, 24, 27)):
+        pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc, spacing=sp_zyx_total)
+        geom = plans.model_config_from_plans(pj, dj).geometry
+        model_store.write_model_folder(root, tid, f"TotalSegmentator_part{tid - 290}", "nnUNetTrainerNoMirroring", pj, dj,
+                                       [plans.synthetic_state_dict(geom, seed=tid)])
+    for tid, nc, name, trainer in ((543, 7, "BCA_body_parts", "nnUNetTrainer_1500epochs_NoMirroring"),
+                                   (542, 12, "BCA_inference", "nnUNetTrainerNoMirroring")):
+        pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc, spacing=sp_zyx_bca)
+        geom = plans.model_config_from_plans(pj, dj).geometry
+        model_store.write_model_folder(root, tid, name, trainer, pj, dj,
+                                       [plans.synthetic_state_dict(geom, seed=tid + f) for f in range(5)])
+
+
+def test_compute_all_models_total_bca(tmp_path, monkeypatch):
+    from boa_hip import label_maps, model_store, nifti
+    from boa_hip.compute.inference import compute_all_models, get_context
+    from boa_hip.pipeline import BcaPipelineHip
+    from boa_hip.synthetic import ct_phantom
+    from boa_hip.task import SegmentationTask
+    root = tmp_path / "results"
+    _write_models(str(root), (1.5, 1.5, 1.5), (5.0, 1.5, 1.5))
+    monkeypatch.setenv("nnUNet_results", str(root))
+    ct = ct_phantom((48, 40, 56), seed=5)
+    aff = np.diag([-1.5, -1.5, 1.5, 1.0])                       # LPS file
+    aff[:3, 3] = [30.0, 40.0, -100.0]
+    ct_path = tmp_path / "ct.nii.gz"
+    nifti.save(ct_path, ct, aff)
+    out = tmp_path / "seg"
+    params = {"preview": False, "fast": False, "ml": True, "nr_thr_resamp": 1, "nr_thr_saving": 1, "quiet": True,
+              "verbose": False, "device": "gpu", "license_number": None}
+    stats = compute_all_models(ct_path, out, ["total", "bca"], params, fast_bca=True,
+                               bca_params={"median_filtering": False, "examined_body_region": None, "save_pdf": False,
+                                           "theme": "light"})
+    assert stats == {"num_voxels": 48 * 40 * 56, "num_slices": 56, "num_slices_resampled": 56}
+    for f in ("total.nii.gz", "total-measurements.json", "ct_pfav.nii.gz", "body_parts.nii.gz", "body_regions.nii.gz",
+              "tissues.nii.gz", "bca-measurements.json"):
+        assert (out / f).is_file(), f
+    total, taff, th = nifti.load(out / "total.nii.gz")
+    assert total.dtype == np.uint8 and total.shape == ct.shape and np.allclose(taff, aff)
+    assert nifti.parse_label_xml(th.extensions[0][1]) == label_maps.CLASS_MAP_TOTAL
+    # same numbers as the array-level pipelines
+    ctx = get_context("gpu")
+    t = SegmentationTask(ctx, "total", model_store.load_task_models("total"), resample=1.5, multimodel=True)
+    np.testing.assert_array_equal(total, t.predict_image(ct, aff))
+    t.close()
+    pm = model_store.load_task_models("body_parts", True)[0]
+    rm = model_store.load_task_models("body_regions", True)[0]
+    pipe = BcaPipelineHip(ctx, (pm[1], pm[2]), (rm[1], rm[2]), fast_bca=True)
+    ref = pipe.run(ct, aff, total_seg=total)
+    pipe.close()
+    for name in ("body_parts", "body_regions", "tissues"):
+        np.testing.assert_array_equal(nifti.load(out / f"{name}.nii.gz")[0], ref[name])
+    with open(out / "bca-measurements.json") as f:
+        js = json.load(f)
+    assert js == json.loads(json.dumps(ref["bca_measurements"], default=float))
+    with open(out / "total-measurements.json") as f:
+        tm = json.load(f)
+    assert set(tm) >= {"segmentations", "info"} and "total" in tm["segmentations"]
+    present = [v for v in tm["segmentations"]["total"].values() if v["present"]]
+    assert present and set(present[0]) == {"present", "volume_ml", "mean_hu", "std_hu", "min_hu", "median_hu", "max_hu",
+                                           "25th_percentile_hu", "75th_percentile_hu", "cnr"}
+    # recompute=False keeps existing outputs; unknown cascade models are refused, not skipped
+    before = os.path.getmtime(out / "total.nii.gz")
+    compute_all_models(ct_path, out, ["total"], params, recompute=False)
+    assert os.path.getmtime(out / "total.nii.gz") == before
+    with pytest.raises(NotImplementedError):
+        compute_all_models(ct_path, out, ["lung_vessels"], params)

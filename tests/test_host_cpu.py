@@ -6,6 +6,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN, ROOT
 
@@ -173,3 +174,36 @@ def test_task_bookkeeping():
     assert get_bbox_from_mask(m, 0, [2, 2, 3]) == [[1, 8], [2, 7], [4, 14]]
     assert get_bbox_from_mask(np.zeros((3, 4, 5)), 0, 1) == [[0, 3], [0, 4], [0, 5]]
     assert nonzero_bbox(m) == [[3, 6], [4, 5], [7, 12]]
+
+
+def test_nifti_roundtrip_and_label_extension(tmp_path):
+    from boa_hip import nifti
+    rng = np.random.default_rng(0)
+    ct = rng.integers(-1024, 3000, size=(7, 9, 5)).astype(np.int16)
+    aff = np.array([[-0.8, 0, 0, 100], [0, -0.8, 0.01, 50], [0, 0, 3.0, -20], [0, 0, 0, 1.0]])
+    for name in ("a.nii", "a.nii.gz"):
+        nifti.save(tmp_path / name, ct, aff)
+        x, a, h = nifti.load(tmp_path / name)
+        assert np.array_equal(x, ct) and np.allclose(a, aff, atol=1e-6)
+        assert h.get_data_shape() == (7, 9, 5) and h.get_data_dtype() == np.int16
+        assert np.allclose(h.get_zooms(), (0.8, 0.8, 3.0), atol=1e-4)
+    lab = (ct > 0).astype(np.uint8)
+    nifti.save(tmp_path / "l.nii.gz", lab, a, like=h, extensions=[(0, nifti.label_xml({1: "spleen", 2: "kidney_right"}))])
+    y, a2, h2 = nifti.load(tmp_path / "l.nii.gz")
+    assert np.array_equal(y, lab) and np.allclose(a2, aff, atol=1e-6) and h2.get_data_dtype() == np.uint8
+    assert nifti.parse_label_xml(h2.extensions[0][1]) == {1: "spleen", 2: "kidney_right"}
+    assert int(h2.vox_offset) % 16 == 0
+
+
+def test_model_store_folder_contract(tmp_path):
+    from boa_hip import model_store, plans
+    pj, dj = plans.synthetic_plans(patch=(16, 16, 16), features=(8, 16), num_classes=3)
+    geom = plans.model_config_from_plans(pj, dj).geometry
+    sds = [plans.synthetic_state_dict(geom, seed=s) for s in range(5)]
+    model_store.write_model_folder(str(tmp_path), 542, "BCA_inference", "nnUNetTrainerNoMirroring", pj, dj, sds)
+    with pytest.raises(RuntimeError):
+        model_store.find_dataset_dir(543, str(tmp_path))
+    (tid, cfg, blobs), = model_store.load_task_models("body_regions", root=str(tmp_path))
+    assert tid == 542 and len(blobs) == 5 and cfg.geometry.num_classes == 3
+    np.testing.assert_array_equal(blobs[3], plans.weight_blob_from_state_dict(geom, sds[3]))
+    assert len(model_store.load_task_models("body_regions", fast_bca=True, root=str(tmp_path))[0][2]) == 1
