@@ -42,7 +42,8 @@ void pack_convt_weights(const float* w /*[Cin][Cout][s0][s1][s2]*/, int Cin, int
 // sums of (x, x^2) per (n, cout) into partials[N][Cout][2][nblk]; returns nblk through *nblk_out.
 int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const ConvGeom& g, const ConvTile& t,
                      const __half* wpk, const float* bias, float slope, __half* out, float* partials);
-int conv_nblk(const ConvTile& t);
+int conv_nblk(const ConvTile& t, int cu_count);
+int conv_ws_nslots(int cu_count);
 
 // First conv: reads tiles straight out of the resident fp32 volume [Cin][V0][V1][V2] (zero outside the volume
 // and outside the tile), fp32 VALU, stride 1.  w: dev fp32 [Cin][taps][Cout].
@@ -87,6 +88,8 @@ struct ConvArgs {
     __half* out;
     float* partials;
     float slope;
+    int nslots;                 // k_conv_ws: statistics slots per (n, cout) in `partials`
+    unsigned long long* trace;  // debug (BOA_WS_TRACE): per-chunk s_memtime stamps of block 0, else nullptr
 };
 
 __device__ __forceinline__ uint4 norm_act8(uint4 raw, const float* sc, const float* sh, float slope) {

@@ -21,6 +21,15 @@
 #include "conv.h"
 
 #define WS_THREADS 512
+#define WS_TRACE_SLOTS 4096
+// timeline stamps (debug only): slot = event counter of the calling wave; wave 0 (consumer) and wave 4 (producer) of block 0
+#define WS_STAMP(code)                                                                          \
+    do {                                                                                        \
+        if (p.trace && blockIdx.x == 0 && lane == 0 && ((wave & 3) == 0) && tr_n < WS_TRACE_SLOTS / 2) { \
+            p.trace[(producer ? WS_TRACE_SLOTS / 2 : 0) + tr_n] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
+            ++tr_n;                                                                             \
+        }                                                                                       \
+    } while (0)
 
 __device__ __forceinline__ int ws_plane_bytes(int HV) { return ((HV * 16 + 127) / 128) * 128 + 64; }
 
@@ -50,40 +59,56 @@ __device__ __forceinline__ TileCoord decode_tile(const ConvArgs& p, int t) {
     return c;
 }
 
+// next tile of a contiguous walk (tile index + 1) without divisions: x, then z, then y, then cout chunk, then n
+__device__ __forceinline__ void next_tile(const ConvArgs& p, TileCoord& c) {
+    const int e0 = p.b0 * p.w0, e1 = p.b1 * p.w1, e2 = p.b2 * p.w2;
+    ++c.sp;
+    c.ox0 += e0;
+    if (c.ox0 >= p.t0 * e0) {
+        c.ox0 = 0;
+        c.oz0 += e2;
+        if (c.oz0 >= p.t2 * e2) {
+            c.oz0 = 0;
+            c.oy0 += e1;
+            if (c.oy0 >= p.t1 * e1) {
+                c.oy0 = 0;
+                c.sp = 0;
+                if (++c.cy >= p.Cout / 32) {
+                    c.cy = 0;
+                    ++c.n;
+                }
+            }
+        }
+    }
+}
+
 // Tile sequence of a workgroup.  Workgroup b is observed to run on XCD b % 8 (each XCD has a private 4 MiB L2):
 // the tile list is cut into 8 contiguous ranges, one per XCD, and the 32 workgroups of an XCD walk their range
 // together (stride = workgroups per XCD), so the halos an XCD re-reads are the ones its own L2 just fetched.
 // Placement only changes speed, never results.
 struct TileWalk {
-    int first, stride, count;
+    int first, count;  // a contiguous run of tile indices
 };
 
-__device__ __forceinline__ TileWalk tile_walk(int total_tiles, bool getenv_free_walk_contiguous) {
+__device__ __forceinline__ TileWalk tile_walk(int total_tiles) {
     TileWalk w;
     const int G = (int)gridDim.x, b = (int)blockIdx.x;
-    if (G % 8 != 0 || total_tiles < G) {
-        w.first = b;
-        w.stride = G;
-        w.count = b < total_tiles ? (total_tiles - b + G - 1) / G : 0;
+    if (G % 8 != 0) {
+        const int q = total_tiles / G, r = total_tiles % G;
+        w.first = b * q + min(b, r);
+        w.count = q + (b < r ? 1 : 0);
         return w;
     }
     const int xcd = b & 7, slot = b >> 3, per = G >> 3;  // per = workgroups per XCD
     const int q = total_tiles / 8, rem = total_tiles % 8;
     const int lo = xcd * q + min(xcd, rem);
     const int len = q + (xcd < rem ? 1 : 0);
-    if (getenv_free_walk_contiguous) {
-        // contiguous run per workgroup: consecutive tiles of a workgroup are neighbours along x (x-fastest tile order),
-        // so the x-halo planes a tile re-reads were fetched by the same CU one tile earlier; neighbouring workgroups of
-        // the XCD walk neighbouring lines
-        const int cq = len / per, cr = len % per;
-        w.first = lo + slot * cq + min(slot, cr);
-        w.stride = 1;
-        w.count = cq + (slot < cr ? 1 : 0);
-        return w;
-    }
-    w.first = lo + slot;
-    w.stride = per;
-    w.count = slot < len ? (len - slot + per - 1) / per : 0;
+    // contiguous run per workgroup: consecutive tiles of a workgroup are neighbours along x (x-fastest tile order),
+    // so the x-halo planes a tile re-reads were fetched by the same CU one tile earlier; neighbouring workgroups of
+    // the XCD walk neighbouring lines
+    const int cq = len / per, cr = len % per;
+    w.first = lo + slot * cq + min(slot, cr);
+    w.count = cq + (slot < cr ? 1 : 0);
     return w;
 }
 
@@ -93,22 +118,26 @@ __device__ __forceinline__ TileWalk tile_walk(int total_tiles, bool getenv_free_
 // (kept in SGPRs).
 #define WS_MAXV 6  // halo voxels per producer thread (HV <= 256 * WS_MAXV)
 
-struct HaloStep {
-    int hx0, hy0, hz0;  // halo coordinates of this thread's first voxel
-    int dx, dy, dz;     // mixed-radix representation of the 256-voxel stride
+struct ProdConst {
+    int rel[WS_MAXV];  // input voxel index of halo voxel j relative to the tile's halo origin
+    int hc[WS_MAXV];   // packed halo coordinates hx | hy << 10 | hz << 20
+    unsigned in_halo;  // bit j: v = q + 256 j < HV
 };
 
-__device__ __forceinline__ HaloStep halo_step(const ConvArgs& p, int q) {
-    HaloStep h;
-    h.hz0 = q % p.h2;
-    const int t = q / p.h2;
-    h.hy0 = t % p.h1;
-    h.hx0 = t / p.h1;
-    h.dz = 256 % p.h2;
-    const int t2 = 256 / p.h2;
-    h.dy = t2 % p.h1;
-    h.dx = t2 / p.h1;
-    return h;
+__device__ __forceinline__ ProdConst prod_const(const ConvArgs& p, int q, int HV) {
+    ProdConst k;
+    k.in_halo = 0;
+#pragma unroll
+    for (int j = 0; j < WS_MAXV; ++j) {
+        const int v = q + 256 * j;
+        const int hz = v % p.h2, t = v / p.h2;
+        const int hy = t % p.h1, hx = t / p.h1;
+        const bool in = v < HV;
+        k.rel[j] = in ? (hx * p.Hi + hy) * p.Wi + hz : 0;
+        k.hc[j] = in ? (hx | (hy << 10) | (hz << 20)) : 0;
+        k.in_halo |= in ? (1u << j) : 0u;
+    }
+    return k;
 }
 
 struct ProdItems {
@@ -116,26 +145,27 @@ struct ProdItems {
     unsigned ok;      // bit j: voxel j is inside the input tensor
 };
 
-__device__ __forceinline__ void prod_setup(const ConvArgs& p, const TileCoord& tc, int q, int HV, const HaloStep& hs,
-                                           ProdItems& it) {
+__device__ __forceinline__ void prod_setup(const ConvArgs& p, const TileCoord& tc, const ProdConst& k, ProdItems& it) {
     const int ix0 = tc.ox0 * p.s0 - p.p0, iy0 = tc.oy0 * p.s1 - p.p1, iz0 = tc.oz0 * p.s2 - p.p2;
-    int v = q;
-    int hz = hs.hz0, hy = hs.hy0, hx = hs.hx0;
-    it.ok = 0;
+    const int base = (ix0 * p.Hi + iy0) * p.Wi + iz0;
+    const bool interior = ix0 >= 0 && iy0 >= 0 && iz0 >= 0 && ix0 + p.h0 <= p.Di && iy0 + p.h1 <= p.Hi && iz0 + p.h2 <= p.Wi;
+    if (interior) {  // wave-uniform: the whole halo lies inside the tensor (lanes beyond the halo have rel == 0)
+        it.ok = k.in_halo;
 #pragma unroll
-    for (int j = 0; j < WS_MAXV; ++j) {
-        const int ix = ix0 + hx, iy = iy0 + hy, iz = iz0 + hz;
-        const bool ok = v < HV && ix >= 0 && ix < p.Di && iy >= 0 && iy < p.Hi && iz >= 0 && iz < p.Wi;
-        it.gi[j] = ok ? (ix * p.Hi + iy) * p.Wi + iz : 0;
-        it.ok |= ok ? (1u << j) : 0u;
-        v += 256;
-        hz += hs.dz;
-        const int cz = hz >= p.h2 ? 1 : 0;
-        hz -= cz * p.h2;
-        hy += hs.dy + cz;
-        const int cy_ = hy >= p.h1 ? 1 : 0;
-        hy -= cy_ * p.h1;
-        hx += hs.dx + cy_;
+        for (int j = 0; j < WS_MAXV; ++j) it.gi[j] = base + k.rel[j];
+    } else {
+        // straight-line (no short-circuit branches): unsigned compares fold the two-sided range checks
+        unsigned okm = 0;
+#pragma unroll
+        for (int j = 0; j < WS_MAXV; ++j) {
+            const unsigned ix = (unsigned)(ix0 + (k.hc[j] & 1023)), iy = (unsigned)(iy0 + ((k.hc[j] >> 10) & 1023)),
+                           iz = (unsigned)(iz0 + (k.hc[j] >> 20));
+            const unsigned ok = (unsigned)(ix < (unsigned)p.Di) & (unsigned)(iy < (unsigned)p.Hi) & (unsigned)(iz < (unsigned)p.Wi) &
+                                ((k.in_halo >> j) & 1u);
+            it.gi[j] = ok ? base + k.rel[j] : 0;
+            okm |= ok << j;
+        }
+        it.ok = okm;
     }
 }
 
@@ -167,9 +197,20 @@ __device__ __forceinline__ uint4 norm_act8_pk(uint4 raw, const unsigned* w /* 4 
     return x.u;
 }
 
-__device__ __forceinline__ void prod_stage(const ConvArgs& p, const TileCoord& tc, const ProdItems& it, int cc,
-                                           unsigned char* dst_in, unsigned char* dst_w, int q, int HV, int plane,
-                                           int taps, int dbg) {
+// Registers of one chunk in flight between its global loads (prod_issue) and its LDS stores (prod_commit).  The two
+// halves run one chunk-barrier apart, so the HBM/L2 round trip overlaps the consumers' work on the previous chunk
+// instead of sitting on the producer's own critical path.
+struct ChunkRegs {
+    uint4 lo[WS_MAXV], hi[WS_MAXV];  // halo voxels: channel octets 0 and 1 of the chunk
+    uint4 wv[7];                      // weight items (taps * 64 / 256 <= 6.75 for 27 taps), streamed-weights layers only
+    unsigned ssw[16];                 // 8 channel pairs x {packed scales, packed shifts}
+    unsigned ok;                      // bit j: voxel j is inside the input tensor
+    unsigned live;                    // bit j: voxel j belongs to the halo (v < HV)
+    int has_ss;
+};
+
+__device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& tc, const ProdItems& it, unsigned live, int cc,
+                                           bool want_w, int q, int taps, int dbg, ChunkRegs& rg) {
     int cg = cc * 16;
     const size_t in_vox = (size_t)p.Di * p.Hi * p.Wi;
     const __half* base;
@@ -185,49 +226,47 @@ __device__ __forceinline__ void prod_stage(const ConvArgs& p, const TileCoord& t
         ss = p.ss16_1 ? p.ss16_1 + ((size_t)tc.n * p.C1 + cg) : nullptr;
         C = p.C1;
     }
-    // Every global load of the chunk (scale/shift, weights, halo) is issued before any result is consumed: the
-    // producer is bound by memory round trips, not by instructions -- one round trip per chunk instead of five.
-    const int nv = (dbg & 32) ? 0 : (HV + 255) >> 8;
     if (dbg & 64) ss = nullptr;
-    uint4 lo[WS_MAXV], hi[WS_MAXV];
+    rg.ok = it.ok;
+    rg.live = live;
+    rg.has_ss = ss != nullptr;
+    const unsigned cb2 = (unsigned)C * 2u;  // bytes per voxel record; per-sample offsets fit 32 bits (checked on the host)
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
-        // unconditional: voxels beyond the halo have gi == 0 (a valid address whose data is discarded)
-        const __half* src = base + (size_t)it.gi[j] * C;
-        lo[j] = *(const uint4*)src;
-        hi[j] = *(const uint4*)(src + 8);
+        // unconditional: voxels beyond the halo / outside the tensor have gi == 0 (a valid address, data discarded)
+        const unsigned char* src = (const unsigned char*)base + (unsigned)it.gi[j] * cb2;
+        rg.lo[j] = *(const uint4*)src;
+        rg.hi[j] = *(const uint4*)(src + 16);
     }
-    constexpr int WB = 7;  // weight items per thread: taps * 64 / 256 <= 6.75 for 27 taps
-    uint4 wv[WB];
-    const int nw = taps * 64;
-    if (dst_w) {
+    if (want_w) {
+        const int nw = taps * 64;
         const __half* wsrc = p.wpk + ((size_t)cc * taps * 2) * p.Cout * 8 + (size_t)tc.cy * 32 * 8;
 #pragma unroll
-        for (int b = 0; b < WB; ++b) {
+        for (int b = 0; b < 7; ++b) {
             const int i = min(q + b * 256, nw - 1);
-            wv[b] = *(const uint4*)(wsrc + ((size_t)(i >> 5) * p.Cout + (i & 31)) * 8);
+            rg.wv[b] = *(const uint4*)(wsrc + ((size_t)(i >> 5) * p.Cout + (i & 31)) * 8);
         }
     }
-    unsigned ssw[16];
     if (ss) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) ssw[j] = ss[j];
+        for (int j = 0; j < 16; ++j) rg.ssw[j] = ss[j];
     }
-    // ---- consume ----
+}
+
+__device__ __forceinline__ void prod_commit(const ConvArgs& p, ChunkRegs& rg, unsigned char* dst_in, unsigned char* dst_w, int q,
+                                            int HV, int plane, int taps, int dbg) {
+    const int nv = (dbg & 32) ? 0 : (HV + 255) >> 8;
     if (dst_w) {
-        asm volatile("" : OPAQUE4(wv[0]), OPAQUE4(wv[1]), OPAQUE4(wv[2]), OPAQUE4(wv[3]), OPAQUE4(wv[4]), OPAQUE4(wv[5]),
-                     OPAQUE4(wv[6]));
+        const int nw = taps * 64;
 #pragma unroll
-        for (int b = 0; b < WB; ++b) {
+        for (int b = 0; b < 7; ++b) {
             const int i = min(q + b * 256, nw - 1);  // clamped lanes rewrite item nw-1 with identical data
-            *(uint4*)(dst_w + i * 16) = wv[b];
+            *(uint4*)(dst_w + i * 16) = rg.wv[b];
         }
     }
-    // the chunk's 16 (scale, shift) values are the same for every thread: keep them scalar
-    if (ss) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) ssw[j] = __builtin_amdgcn_readfirstlane(ssw[j]);
-    }
+    // the chunk's 16 (scale, shift) words stay in VGPRs: a packed fp16 fma takes at most one scalar operand, so SGPR
+    // copies cost a v_mov (+ hazard nops) per use -- more instructions than the transform itself
+    const unsigned* ssw = rg.ssw;
     union {
         unsigned u;
         h2_t v;
@@ -235,25 +274,20 @@ __device__ __forceinline__ void prod_stage(const ConvArgs& p, const TileCoord& t
     sl2.v = h2_t{(_Float16)p.slope, (_Float16)p.slope};
     unsigned char* d0 = dst_in + q * 16;
     unsigned char* d1 = d0 + plane;
+    // padding voxels (outside the tensor) must read as zero AFTER the transform; tiles whose halo lies inside the tensor
+    // (rg.ok == rg.live for every lane, decided per wave) skip the per-voxel selects
+    const bool edge = __builtin_amdgcn_ballot_w64(rg.ok != rg.live) != 0;
 #pragma unroll
-    for (int j0 = 0; j0 < WS_MAXV; j0 += 3) {
-        if (j0 < nv) {
-            asm volatile("" : OPAQUE4(lo[j0]), OPAQUE4(hi[j0]), OPAQUE4(lo[j0 + 1]), OPAQUE4(hi[j0 + 1]), OPAQUE4(lo[j0 + 2]),
-                         OPAQUE4(hi[j0 + 2]));
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int j = j0 + b;
-                if (q + 256 * j < HV) {
-                    uint4 o0 = lo[j], o1 = hi[j];
-                    if (ss) {
-                        o0 = norm_act8_pk(o0, ssw, sl2.u);
-                        o1 = norm_act8_pk(o1, ssw + 8, sl2.u);
-                    }
-                    if (!((it.ok >> j) & 1u)) o0 = o1 = make_uint4(0, 0, 0, 0);
-                    *(uint4*)(d0 + j * 4096) = o0;
-                    *(uint4*)(d1 + j * 4096) = o1;
-                }
+    for (int j = 0; j < WS_MAXV; ++j) {
+        if (j < nv && ((rg.live >> j) & 1u)) {
+            uint4 o0 = rg.lo[j], o1 = rg.hi[j];
+            if (rg.has_ss) {
+                o0 = norm_act8_pk(o0, ssw, sl2.u);
+                o1 = norm_act8_pk(o1, ssw + 8, sl2.u);
             }
+            if (edge && !((rg.ok >> j) & 1u)) o0 = o1 = make_uint4(0, 0, 0, 0);
+            *(uint4*)(d0 + j * 4096) = o0;
+            *(uint4*)(d1 + j * 4096) = o1;
         }
     }
 }
@@ -261,39 +295,40 @@ __device__ __forceinline__ void prod_stage(const ConvArgs& p, const TileCoord& t
 // ---- consumer ----------------------------------------------------------------------------------------
 // One 16-channel chunk: acc[r] += W[tap] x X[tap][r] for all taps.  bp[r]: LDS address of this lane's voxel of
 // M-tile r in this lane's k-half plane; ap: LDS address of this lane's row of the first A fragment.
+#ifndef WS_PF
+#define WS_PF 1  // fragment prefetch distance in taps (2 measured slower: 610 vs 664 TFLOP/s on 32->32 @128^3, batch 8)
+#endif
+
 template <int R, int K0, int K1, int K2>
 __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R], const unsigned char* ap, int h1, int h2,
                                               f32x16 (&acc)[R]) {
-    // Prefetch distance is one tap.  (Distance 2 with the pipeline pinned by sched_barrier(0) was measured slower:
-    // 1558 vs 1405 us on the 32->32 @128^3 layer at batch 8 -- 13 spilled VGPRs and a stiffer schedule.)
+    // Software pipeline over the (compile-time) taps: the A/B fragments of tap t + WS_PF are read while the MFMAs of
+    // tap t issue.  The sched_group_barrier sequence pins that order: [PF x (R+1) reads] then per tap
+    // [(R+1) reads][R MFMAs].  The prologue groups matter: without them the per-tap groups are filled one tap late
+    // and every tap waits for reads it has just issued.
     constexpr int T = K0 * K1 * K2;
-    f16x8 a[2];
-    f16x8 b[2][R];
-    const unsigned char* rb[R];
+    constexpr int NS = WS_PF + 1;
+    f16x8 a[NS];
+    f16x8 b[NS][R];
+    auto fetch = [&](int tn, int slot) {
+        const int dzn = tn % K2, dyn = (tn / K2) % K1, dxn = tn / (K2 * K1);
+        const int off = ((dxn * h1 + dyn) * h2 + dzn) * 16;
+        a[slot] = *(const f16x8*)(ap + tn * 1024);
 #pragma unroll
-    for (int r = 0; r < R; ++r) rb[r] = bp[r];
-    a[0] = *(const f16x8*)ap;
+        for (int r = 0; r < R; ++r) b[slot][r] = *(const f16x8*)(bp[r] + off);
+    };
 #pragma unroll
-    for (int r = 0; r < R; ++r) b[0][r] = *(const f16x8*)rb[r];
+    for (int t = 0; t < WS_PF && t < T; ++t) {
+        fetch(t, t % NS);
+        __builtin_amdgcn_sched_group_barrier(0x100, R + 1, 0);
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const int cb = t & 1, nb = cb ^ 1;
-        if (t + 1 < T) {
-            const int tn = t + 1;
-            const int dzn = tn % K2, dyn = (tn / K2) % K1, dxn = tn / (K2 * K1);
-            if (dzn == 0) {
-                const int rowoff = (dxn * h1 + dyn) * h2 * 16;
-#pragma unroll
-                for (int r = 0; r < R; ++r) rb[r] = bp[r] + rowoff;
-            }
-            a[nb] = *(const f16x8*)(ap + tn * 1024);
-#pragma unroll
-            for (int r = 0; r < R; ++r) b[nb][r] = *(const f16x8*)(rb[r] + dzn * 16);
-        }
+        const int cb = t % NS;
+        if (t + WS_PF < T) fetch(t + WS_PF, (t + WS_PF) % NS);
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb], b[cb][r], acc[r], 0, 0, 0);
-        // scheduling hint: the next tap's R+1 fragment reads go out before this tap's R MFMAs
-        if (t + 1 < T) __builtin_amdgcn_sched_group_barrier(0x100, R + 1, 0);
+        if (t + WS_PF < T) __builtin_amdgcn_sched_group_barrier(0x100, R + 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, R, 0);
     }
 }
@@ -304,21 +339,20 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave >= 4;
+    const bool producer = (wave >= 4) != ((dbg & 1024) != 0);  // dbg 1024: swap roles (producers = older waves 0-3)
     const int l31 = lane & 31;
     const int kh = lane >> 5;
     constexpr int taps = K0 * K1 * K2;
     const int HV = p.h0 * p.h1 * p.h2;
     const int plane = ws_plane_bytes(HV);
     const int ncc = (p.C0 + p.C1) / 16;
-    const int nsp = p.t0 * p.t1 * p.t2;
     // LDS map.  resident: [all weights: ncc * taps KiB][halo buf 0][halo buf 1]
     //           streamed: [halo 0 | w 0][halo 1 | w 1]
     const int wres_bytes = resident_w ? ncc * taps * 1024 : 0;
     const int buf_bytes = resident_w ? 2 * plane : 2 * plane + taps * 1024;
     unsigned char* bufs = smem + wres_bytes;
 
-    const TileWalk walk = tile_walk(total_tiles, !(dbg & 128));
+    const TileWalk walk = tile_walk(total_tiles);
     const int my_chunks = walk.count * ncc;
 
     if (resident_w) {
@@ -328,63 +362,144 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             *(uint4*)(smem + i * 16) = *(const uint4*)(p.wpk + ((size_t)(i >> 5) * p.Cout + (i & 31)) * 8);
         // visibility to the consumers is ordered by the first chunk barrier below
     }
+    int tr_n = 0;
 
-    // consumer per-lane constants (tile independent)
-    const int cw = wave & 3;
-    const int lz = l31 & (p.w2 - 1);
-    const int ly = (l31 >> p.lw2) & (p.w1 - 1);
-    const int lx = l31 >> (p.lw2 + p.lw1);
-    int hoff[R];
+    if (producer) {
+        // ---- producer waves: chunk g + 1 is committed to LDS while the consumers work on chunk g; its global loads
+        // were issued one barrier earlier (prod_issue), those of chunk g + 2 are issued right after the commit.
+        const int q = tid & 255;
+        if (dbg & 256) __builtin_amdgcn_s_setprio(1);
+        if (dbg & 512) __builtin_amdgcn_s_setprio(3);
+        const ProdConst pc = prod_const(p, q, HV);
+        TileCoord ptc;
+        ptc.n = ptc.cy = ptc.ox0 = ptc.oy0 = ptc.oz0 = ptc.sp = 0;
+        ProdItems items;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int m = cw * R + r;
-        const int mz = m & (p.b2 - 1);
-        const int my = (m >> p.lb2) & (p.b1 - 1);
-        const int mx = m >> (p.lb2 + p.lb1);
-        const int tx = mx * p.w0 + lx, ty = my * p.w1 + ly, tz = mz * p.w2 + lz;
-        hoff[r] = (((tx * p.s0) * p.h1 + ty * p.s1) * p.h2 + tz * p.s2) * 16 + kh * plane;
-    }
-    f32x16 acc[R];
-    const HaloStep hstep = halo_step(p, tid & 255);
-
-    // producer state (valid across the chunks of one tile) and chunk counters of both roles
-    TileCoord ptc;
-    ptc.n = ptc.cy = ptc.ox0 = ptc.oy0 = ptc.oz0 = ptc.sp = 0;
-    ProdItems items;
+        for (int j = 0; j < WS_MAXV; ++j) items.gi[j] = 0;
+        items.ok = 0;
+        ChunkRegs rg;
 #pragma unroll
-    for (int j = 0; j < WS_MAXV; ++j) items.gi[j] = 0;
-    items.ok = 0;
-    int pk = 0, pcc = 0;  // producer: tile counter, chunk within tile (of chunk g + 1)
-    int ck = 0, ccc = 0;  // consumer: the same for chunk g
-
-    for (int g = -1; g < my_chunks; ++g) {
-        if (producer) {
-            if (g + 1 < my_chunks && !(dbg & 2)) {
-                if (pcc == 0) {
-                    ptc = decode_tile(p, walk.first + pk * walk.stride);
-                    prod_setup(p, ptc, tid - 256, HV, hstep, items);
-                }
+        for (int j = 0; j < WS_MAXV; ++j) rg.lo[j] = rg.hi[j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) rg.wv[j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rg.ssw[j] = 0;
+        rg.ok = rg.live = 0;
+        rg.has_ss = 0;
+        const bool want_w = !(resident_w || (dbg & 16));
+        int pcc = 0;  // chunk within the tile of the next chunk to issue
+        const bool live = !(dbg & 2);
+        if (live && my_chunks > 0) {
+            ptc = decode_tile(p, walk.first);
+            prod_setup(p, ptc, pc, items);
+            prod_issue(p, ptc, items, pc.in_halo, 0, want_w, q, taps, dbg, rg);
+            if (++pcc == ncc) pcc = 0;
+        }
+        for (int g = -1; g < my_chunks; ++g) {
+            if (live && g + 1 < my_chunks) {
                 unsigned char* nxt = bufs + ((g + 1) & 1) * buf_bytes;
-                prod_stage(p, ptc, items, pcc, nxt, (resident_w || (dbg & 16)) ? nullptr : nxt + 2 * plane, tid - 256, HV,
-                           plane, taps, dbg);
-                if (++pcc == ncc) {
-                    pcc = 0;
-                    ++pk;
+                WS_STAMP(1);
+                prod_commit(p, rg, nxt, want_w ? nxt + 2 * plane : nullptr, q, HV, plane, taps, dbg);
+                WS_STAMP(2);
+                if (g + 2 < my_chunks) {
+                    if (pcc == 0) {
+                        next_tile(p, ptc);
+                        prod_setup(p, ptc, pc, items);
+                    }
+                    prod_issue(p, ptc, items, pc.in_halo, pcc, want_w, q, taps, dbg, rg);
+                    if (++pcc == ncc) pcc = 0;
                 }
+                WS_STAMP(3);
             }
-        } else if (g >= 0) {
-            const int k = ck, cc = ccc;
-            if (++ccc == ncc) {
-                ccc = 0;
-                ++ck;
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- consumer waves --------------------------------------------------------------------------------
+    // per-lane constants (tile independent)
+    const int cw = wave & 3;
+    int hoff[R];
+    {
+        const int lz = l31 & (p.w2 - 1);
+        const int ly = (l31 >> p.lw2) & (p.w1 - 1);
+        const int lx = l31 >> (p.lw2 + p.lw1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int m = cw * R + r;
+            const int mz = m & (p.b2 - 1);
+            const int my = (m >> p.lb2) & (p.b1 - 1);
+            const int mx = m >> (p.lb2 + p.lb1);
+            const int tx = mx * p.w0 + lx, ty = my * p.w1 + ly, tz = mz * p.w2 + lz;
+            hoff[r] = (((tx * p.s0) * p.h1 + ty * p.s1) * p.h2 + tz * p.s2) * 16 + kh * plane;
+        }
+    }
+    // epilogue constants.  After the LDS transpose this lane owns couts [8 sq, 8 sq + 8) of voxels sv and sv + 16 of
+    // each M-tile.  Output voxel index relative to the tile origin = srel0 (lane part: voxel sv of M-tile 0 of wave 0)
+    // + half * srel16 (voxel sv + 16) + the M-tile's own offset (wave-uniform, recomputed from cw, r when needed).
+    const int sv = lane >> 2, sq = lane & 3;
+    auto vox_rel = [&](int v, int& x, int& y, int& z) {
+        x = v >> (p.lw2 + p.lw1);
+        y = (v >> p.lw2) & (p.w1 - 1);
+        z = v & (p.w2 - 1);
+    };
+    int srel0, srel16;
+    {
+        int x, y, z;
+        vox_rel(sv, x, y, z);
+        srel0 = (x * p.Ho + y) * p.Wo + z;
+        vox_rel(sv + 16, x, y, z);
+        srel16 = (x * p.Ho + y) * p.Wo + z - srel0;
+    }
+    const size_t out_vox = (size_t)p.Do * p.Ho * p.Wo;
+    const int nslots = p.nslots;
+    const int slot = (int)blockIdx.x * 4 + cw;
+    unsigned char* slab = bufs + 2 * buf_bytes + cw * (32 * 80);
+    // InstanceNorm partial sums of this wave over the couts [8 sq, 8 sq + 8) of the voxels this lane stored since the
+    // last flush (values as stored, i.e. after the fp16 rounding); one flush per (n, cout chunk) the wave works on
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st_s[i] = st_q[i] = 0.f;
+    int st_n = -1, st_cy = 0;
+    auto flush_stats = [&]() {
+        if (st_n < 0) return;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int mm = 4; mm < 64; mm <<= 1) {  // the 16 lanes that share sq (lane bits 2..5)
+                st_s[i] += __shfl_xor(st_s[i], mm);
+                st_q[i] += __shfl_xor(st_q[i], mm);
             }
+        }
+        if (lane < 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = st_cy * 32 + sq * 8 + i;
+                float* pp = p.partials + (((size_t)st_n * p.Cout + row) * 2) * nslots + slot;
+                pp[0] = st_s[i];
+                pp[nslots] = st_q[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st_s[i] = st_q[i] = 0.f;
+    };
+
+    TileCoord tc;
+    tc.n = tc.cy = tc.ox0 = tc.oy0 = tc.oz0 = tc.sp = 0;
+    __syncthreads();  // chunk 0 staged (pairs with the producers' g = -1 barrier)
+    for (int k = 0; k < walk.count; ++k) {
+        if (k == 0)
+            tc = decode_tile(p, walk.first);
+        else
+            next_tile(p, tc);
+        f32x16 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+        for (int cc = 0; cc < ncc; ++cc) {
+            const int g = k * ncc + cc;
             const unsigned char* cur = bufs + (g & 1) * buf_bytes;
-            if (cc == 0) {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
-            }
             const unsigned char* bp[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -394,31 +509,31 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 bp[r] = cur + ho;
             }
             const unsigned char* ap = (resident_w ? smem + cc * taps * 1024 : cur + 2 * plane) + (kh * 32 + l31) * 16;
+            WS_STAMP(4);
             if (!(dbg & 1)) consume_chunk<R, K0, K1, K2>(bp, ap, p.h1, p.h2, acc);
+            WS_STAMP(5);
             if (cc == ncc - 1 && !(dbg & 8)) {
-                // ---- epilogue: + bias, fp16 convert, InstanceNorm partials, LDS transpose, 16-byte coalesced stores
-                // (D fragment = 4 couts per lane at a 64-byte voxel pitch: stored directly that is 16 strided 8-byte
-                //  store instructions per wave and tile, which are store-issue bound -- ~600 cycles each; through a
-                //  per-wave LDS slab each store instruction writes 1 KiB of whole 64-byte voxel records)
-                const TileCoord tc = decode_tile(p, walk.first + k * walk.stride);
+                // ---- epilogue: + bias, InstanceNorm partial sums (fp32 values, before rounding), fp16 convert, LDS
+                // transpose, 16-byte coalesced stores.  (D fragment = 4 couts per lane at a 64-byte voxel pitch: stored
+                // directly that is 16 strided 8-byte store instructions per wave and tile, which are store-issue bound;
+                // through a per-wave LDS slab each store instruction writes 1 KiB of whole 64-byte voxel records.)
+                if (tc.n != st_n || tc.cy != st_cy) {
+                    flush_stats();
+                    st_n = tc.n;
+                    st_cy = tc.cy;
+                }
                 const int cout0 = tc.cy * 32;
-                const size_t out_vox = (size_t)p.Do * p.Ho * p.Wo;
-                const int npart = nsp * 4;
-                unsigned char* slab = bufs + 2 * buf_bytes + cw * (32 * 80);
-                // after the transpose this lane owns couts [8 sq, 8 sq + 8) of voxels sv and sv + 16 of each M-tile
-                const int sv = lane >> 2, sq = lane & 3;
-                float s[8], q[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+                const bool full = tc.ox0 + p.b0 * p.w0 <= p.Do && tc.oy0 + p.b1 * p.w1 <= p.Ho && tc.oz0 + p.b2 * p.w2 <= p.Wo;
+                __half* obase = p.out + ((size_t)tc.n * out_vox + ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0 + srel0) * p.Cout + cout0 + sq * 8;
                 // the tile's 16 bias values of this lane (4 independent loads, one wait)
                 float4 bq[4];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) bq[gq] = *(const float4*)(p.bias + cout0 + 8 * gq + 4 * kh);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int m = cw * R + r;
-                    const int mx0 = tc.ox0 + (m >> (p.lb2 + p.lb1)) * p.w0, my0 = tc.oy0 + ((m >> p.lb2) & (p.b1 - 1)) * p.w1,
-                              mz0 = tc.oz0 + (m & (p.b2 - 1)) * p.w2;
+                    const int m = cw * R + r;  // wave-uniform M-tile origin within the block tile
+                    const int mx = (m >> (p.lb2 + p.lb1)) * p.w0, my = ((m >> p.lb2) & (p.b1 - 1)) * p.w1, mz = (m & (p.b2 - 1)) * p.w2;
+                    const int mrel = (mx * p.Ho + my) * p.Wo + mz;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         union {
@@ -434,49 +549,35 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
-                        const int v = sv + 16 * half;  // voxel of the M-tile
                         union {
                             uint4 u;
                             __half h[8];
                         } d;
-                        d.u = *(const uint4*)(slab + v * 80 + sq * 16);
-                        const int vz = v & (p.w2 - 1), vy = (v >> p.lw2) & (p.w1 - 1), vx = v >> (p.lw2 + p.lw1);
-                        const int ox = mx0 + vx, oy = my0 + vy, oz = mz0 + vz;
-                        if (ox < p.Do && oy < p.Ho && oz < p.Wo) {
-                            if (!(dbg & 4)) *(uint4*)(p.out + ((size_t)tc.n * out_vox + ((size_t)ox * p.Ho + oy) * p.Wo + oz) * p.Cout +
-                                      cout0 + sq * 8) = d.u;
+                        d.u = *(const uint4*)(slab + (sv + 16 * half) * 80 + sq * 16);
+                        bool ok = true;
+                        if (!full) {  // wave-uniform: only tiles that stick out of the tensor
+                            int x, y, z;
+                            vox_rel(sv + 16 * half, x, y, z);
+                            ok = tc.ox0 + mx + x < p.Do && tc.oy0 + my + y < p.Ho && tc.oz0 + mz + z < p.Wo;
+                        }
+                        if (ok) {
+                            if (!(dbg & 4)) *(uint4*)(obase + (size_t)(mrel + half * srel16) * p.Cout) = d.u;
 #pragma unroll
                             for (int i = 0; i < 8; ++i) {
                                 const float vr = __half2float(d.h[i]);
-                                s[i] += vr;
-                                q[i] = __builtin_fmaf(vr, vr, q[i]);
+                                st_s[i] += vr;
+                                st_q[i] = __builtin_fmaf(vr, vr, st_q[i]);
                             }
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-                // reduce over the 16 lanes that share sq (lane bits 2..5)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                    for (int mm = 4; mm < 64; mm <<= 1) {
-                        s[i] += __shfl_xor(s[i], mm);
-                        q[i] += __shfl_xor(q[i], mm);
-                    }
-                }
-                if (lane < 4) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int row = sq * 8 + i;
-                        float* pp = p.partials + (((size_t)tc.n * p.Cout + cout0 + row) * 2) * npart + tc.sp * 4 + cw;
-                        pp[0] = s[i];
-                        pp[npart] = q[i];
-                    }
-                }
             }
+            WS_STAMP(6);
+            __syncthreads();
         }
-        __syncthreads();
     }
+    flush_stats();
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -492,6 +593,8 @@ size_t conv_ws_lds_bytes(int HV, int taps, int ncc, int Cout) {
     if (conv_ws_resident(HV, taps, ncc, Cout)) return (size_t)ncc * taps * 1024 + 4 * ws_plane_host(HV) + slabs;
     return 2 * (2 * ws_plane_host(HV) + (size_t)taps * 1024) + slabs;
 }
+
+int conv_ws_nslots(int cu_count) { return cu_count * 4; }
 
 bool conv_ws_supported(const int k[3], int HV) {
     const bool k333 = k[0] == 3 && k[1] == 3 && k[2] == 3;
@@ -520,12 +623,25 @@ static int launch_ws_r(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int t
     return BOA_OK;
 }
 
-int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double flops, double bytes) {
-    const int total = t.tiles[0] * t.tiles[1] * t.tiles[2] * (a.Cout / 32) * a.N;
+int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes) {
+    const ConvArgs& a0 = a_in;
+    const int total = t.tiles[0] * t.tiles[1] * t.tiles[2] * (a0.Cout / 32) * a0.N;
     const int grid = std::min(total, ctx->cu_count);
-    const int taps = a.k0 * a.k1 * a.k2;
+    const int taps = a0.k0 * a0.k1 * a0.k2;
     const int HV = t.h[0] * t.h[1] * t.h[2];
-    const int resident = conv_ws_resident(HV, taps, (a.C0 + a.C1) / 16, a.Cout) ? 1 : 0;
+    const int resident = conv_ws_resident(HV, taps, (a0.C0 + a0.C1) / 16, a0.Cout) ? 1 : 0;
+    BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi * std::max(a0.C0, a0.C1) * 2.0 < 4294967296.0,
+                "conv_ws: one sample of the input exceeds 4 GiB (32-bit voxel offsets)");
+    static const bool want_trace = getenv("BOA_WS_TRACE") != nullptr;
+    ConvArgs a = a_in;
+    a.trace = nullptr;
+    // statistics slots: one per (workgroup, consumer wave); waves that never touch an (n, cout chunk) leave zeros
+    a.nslots = conv_ws_nslots(ctx->cu_count);
+    BOA_HIP_TRY(hipMemsetAsync(a.partials, 0, (size_t)a.N * a.Cout * 2 * a.nslots * sizeof(float), ctx->stream));
+    if (want_trace) {
+        hipMalloc(&a.trace, WS_TRACE_SLOTS * 8);
+        hipMemsetAsync(a.trace, 0, WS_TRACE_SLOTS * 8, ctx->stream);
+    }
     KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);
     int rc;
     switch (t.R) {
@@ -537,6 +653,21 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double fl
             rc = BOA_EINVAL;
     }
     tm.stop();
+    if (want_trace && a.trace) {
+        // debug: print the per-event deltas (cycles) of block 0: consumer wave 0 then producer wave 4
+        static unsigned long long host[WS_TRACE_SLOTS];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpy(host, a.trace, sizeof(host), hipMemcpyDeviceToHost);
+        hipFree(a.trace);
+        for (int role = 0; role < 2; ++role) {
+            const unsigned long long* h = host + role * (WS_TRACE_SLOTS / 2);
+            fprintf(stderr, "[ws-trace] %s Cin=%d Cout=%d in=%d R=%d:", role ? "producer" : "consumer", a0.C0 + a0.C1, a0.Cout, a0.Di, t.R);
+            const int lo = 40, hi = 40 + (role ? 36 : 36);
+            for (int i = lo; i < hi && h[i]; ++i)
+                fprintf(stderr, " %d:%llu", (int)(h[i] >> 56), (h[i] & 0x00ffffffffffffffull) - (h[i - 1] & 0x00ffffffffffffffull));
+            fprintf(stderr, "\n");
+        }
+    }
     if (rc) return rc;
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

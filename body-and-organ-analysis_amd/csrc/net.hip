@@ -128,7 +128,7 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
                     "conv %d+%d -> %d: channel counts must be multiples of 16 (in) / 32 (out)", cin0, cin1, cout);
         BOA_REQUIRE(choose_conv_tile(L.g, net->ctx->cu_count, &L.t), "no tile configuration fits conv %dx%dx%d", din[0],
                     din[1], din[2]);
-        L.nblk = conv_nblk(L.t);
+        L.nblk = conv_nblk(L.t, net->ctx->cu_count);
         BOA_TRY(net_alloc(net, conv_wpk_halves(cin0 + cin1, cout, k) * sizeof(__half), (void**)&L.wpk));
     }
     BOA_TRY(net_alloc(net, cout * sizeof(float), (void**)&L.bias));
@@ -442,7 +442,7 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     size_t vin = (size_t)dims[0] * dims[1] * dims[2], vout = (size_t)dout[0] * dout[1] * dout[2];
     __half *in16 = nullptr, *out16 = nullptr, *wpk = nullptr;
     float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *partials = nullptr, *ss = nullptr;
-    int nblk = conv_nblk(t);
+    int nblk = conv_nblk(t, ctx->cu_count);
     std::vector<__half> tmp(conv_wpk_halves(Cin, Cout, kernel));
     pack_conv_weights(host_w, Cin, Cout, kernel, tmp.data());
     std::vector<float> ones(Cout, 1.f), zeros(Cout, 0.f);
