@@ -20,7 +20,11 @@
 
 #include "conv.h"
 
-#define WS_THREADS 512
+#ifndef WS_THREADS
+#define WS_THREADS 512  // 256 consumer threads (4 waves) + WS_PROD producer threads
+#endif
+#define WS_PROD (WS_THREADS - 256)
+#define WS_WB ((27 * 64 + WS_PROD - 1) / WS_PROD)  // weight items per producer thread (taps * 64 items, <= 27 taps)
 #define WS_TRACE_SLOTS 4096
 // timeline stamps (debug only): slot = event counter of the calling wave; wave 0 (consumer) and wave 4 (producer) of block 0
 #define WS_STAMP(code)                                                                          \
@@ -113,15 +117,17 @@ __device__ __forceinline__ TileWalk tile_walk(int total_tiles) {
 }
 
 // ---- producer ----------------------------------------------------------------------------------------
-// Producer thread q (0..255) owns halo voxels v = q + 256 * j and stages BOTH channel octets of the chunk for them,
-// so the voxel bookkeeping is paid once per 32 bytes and the chunk's 16 (scale, shift) pairs are wave-uniform
-// (kept in SGPRs).
-#define WS_MAXV 6  // halo voxels per producer thread (HV <= 256 * WS_MAXV)
+// Lane pairing: producer thread q stages channel octet (q & 1) of the halo voxels v = (q >> 1) + (WS_PROD / 2) * j.
+// Two neighbouring lanes read the two 16-byte octets of the same voxel record (32 contiguous bytes) and neighbouring
+// lane pairs read neighbouring voxels, so a wave-wide load touches each cache line it needs once.  (One lane per voxel
+// with separate "low octet" / "high octet" instructions touches every line twice: the L1 tag pipeline, not HBM, was
+// the producers' limit.)
+#define WS_MAXV (2 * 1536 / WS_PROD)  // (voxel, octet) items per producer thread (HV <= 1536)
 
 struct ProdConst {
     int rel[WS_MAXV];  // input voxel index of halo voxel j relative to the tile's halo origin
     int hc[WS_MAXV];   // packed halo coordinates hx | hy << 10 | hz << 20
-    unsigned in_halo;  // bit j: v = q + 256 j < HV
+    unsigned in_halo;  // bit j: v < HV
 };
 
 __device__ __forceinline__ ProdConst prod_const(const ConvArgs& p, int q, int HV) {
@@ -129,7 +135,7 @@ __device__ __forceinline__ ProdConst prod_const(const ConvArgs& p, int q, int HV
     k.in_halo = 0;
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
-        const int v = q + 256 * j;
+        const int v = (q >> 1) + (WS_PROD / 2) * j;
         const int hz = v % p.h2, t = v / p.h2;
         const int hy = t % p.h1, hx = t / p.h1;
         const bool in = v < HV;
@@ -201,11 +207,11 @@ __device__ __forceinline__ uint4 norm_act8_pk(uint4 raw, const unsigned* w /* 4 
 // halves run one chunk-barrier apart, so the HBM/L2 round trip overlaps the consumers' work on the previous chunk
 // instead of sitting on the producer's own critical path.
 struct ChunkRegs {
-    uint4 lo[WS_MAXV], hi[WS_MAXV];  // halo voxels: channel octets 0 and 1 of the chunk
-    uint4 wv[7];                      // weight items (taps * 64 / 256 <= 6.75 for 27 taps), streamed-weights layers only
-    unsigned ssw[16];                 // 8 channel pairs x {packed scales, packed shifts}
-    unsigned ok;                      // bit j: voxel j is inside the input tensor
-    unsigned live;                    // bit j: voxel j belongs to the halo (v < HV)
+    uint4 d[WS_MAXV];     // this lane's channel octet of its halo voxels
+    uint4 wv[WS_WB];      // weight items (taps * 64 items per chunk), streamed-weights layers only
+    unsigned ssw[8];      // this lane's octet: 4 channel pairs x {packed scales, packed shifts}
+    unsigned ok;          // bit j: voxel j is inside the input tensor
+    unsigned live;        // bit j: voxel j belongs to the halo (v < HV)
     int has_ss;
 };
 
@@ -214,7 +220,7 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
     int cg = cc * 16;
     const size_t in_vox = (size_t)p.Di * p.Hi * p.Wi;
     const __half* base;
-    const unsigned* ss;  // 16 words: 8 channel pairs x {packed scales, packed shifts}
+    const unsigned* ss;  // 16 words per chunk: 8 channel pairs x {packed scales, packed shifts}
     int C;
     if (cg < p.C0) {
         base = p.src0 + (size_t)tc.n * in_vox * p.C0 + cg;
@@ -231,63 +237,57 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
     rg.live = live;
     rg.has_ss = ss != nullptr;
     const unsigned cb2 = (unsigned)C * 2u;  // bytes per voxel record; per-sample offsets fit 32 bits (checked on the host)
+    const unsigned char* lbase = (const unsigned char*)base + (q & 1) * 16;
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
         // unconditional: voxels beyond the halo / outside the tensor have gi == 0 (a valid address, data discarded)
-        const unsigned char* src = (const unsigned char*)base + (unsigned)it.gi[j] * cb2;
-        rg.lo[j] = *(const uint4*)src;
-        rg.hi[j] = *(const uint4*)(src + 16);
+        rg.d[j] = *(const uint4*)(lbase + (unsigned)it.gi[j] * cb2);
     }
     if (want_w) {
         const int nw = taps * 64;
         const __half* wsrc = p.wpk + ((size_t)cc * taps * 2) * p.Cout * 8 + (size_t)tc.cy * 32 * 8;
 #pragma unroll
-        for (int b = 0; b < 7; ++b) {
-            const int i = min(q + b * 256, nw - 1);
+        for (int b = 0; b < WS_WB; ++b) {
+            const int i = min(q + b * WS_PROD, nw - 1);
             rg.wv[b] = *(const uint4*)(wsrc + ((size_t)(i >> 5) * p.Cout + (i & 31)) * 8);
         }
     }
     if (ss) {
+        const unsigned* sl = ss + (q & 1) * 8;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) rg.ssw[j] = ss[j];
+        for (int j = 0; j < 8; ++j) rg.ssw[j] = sl[j];
     }
 }
 
 __device__ __forceinline__ void prod_commit(const ConvArgs& p, ChunkRegs& rg, unsigned char* dst_in, unsigned char* dst_w, int q,
                                             int HV, int plane, int taps, int dbg) {
-    const int nv = (dbg & 32) ? 0 : (HV + 255) >> 8;
+    const int nv = (dbg & 32) ? 0 : (HV + WS_PROD / 2 - 1) / (WS_PROD / 2);
     if (dst_w) {
         const int nw = taps * 64;
 #pragma unroll
-        for (int b = 0; b < 7; ++b) {
-            const int i = min(q + b * 256, nw - 1);  // clamped lanes rewrite item nw-1 with identical data
+        for (int b = 0; b < WS_WB; ++b) {
+            const int i = min(q + b * WS_PROD, nw - 1);  // clamped lanes rewrite item nw-1 with identical data
             *(uint4*)(dst_w + i * 16) = rg.wv[b];
         }
     }
-    // the chunk's 16 (scale, shift) words stay in VGPRs: a packed fp16 fma takes at most one scalar operand, so SGPR
-    // copies cost a v_mov (+ hazard nops) per use -- more instructions than the transform itself
-    const unsigned* ssw = rg.ssw;
+    // the (scale, shift) words stay in VGPRs: a packed fp16 fma takes at most one scalar operand, so SGPR copies cost
+    // a v_mov (+ hazard nops) per use -- more instructions than the transform itself
     union {
         unsigned u;
         h2_t v;
     } sl2;
     sl2.v = h2_t{(_Float16)p.slope, (_Float16)p.slope};
-    unsigned char* d0 = dst_in + q * 16;
-    unsigned char* d1 = d0 + plane;
+    unsigned char* d0 = dst_in + (q & 1) * plane + (q >> 1) * 16;
     // padding voxels (outside the tensor) must read as zero AFTER the transform; tiles whose halo lies inside the tensor
     // (rg.ok == rg.live for every lane, decided per wave) skip the per-voxel selects
     const bool edge = __builtin_amdgcn_ballot_w64(rg.ok != rg.live) != 0;
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
         if (j < nv && ((rg.live >> j) & 1u)) {
-            uint4 o0 = rg.lo[j], o1 = rg.hi[j];
-            if (rg.has_ss) {
-                o0 = norm_act8_pk(o0, ssw, sl2.u);
-                o1 = norm_act8_pk(o1, ssw + 8, sl2.u);
-            }
-            if (edge && !((rg.ok >> j) & 1u)) o0 = o1 = make_uint4(0, 0, 0, 0);
-            *(uint4*)(d0 + j * 4096) = o0;
-            *(uint4*)(d1 + j * 4096) = o1;
+            uint4 o = rg.d[j];
+            if (rg.has_ss) o = norm_act8_pk(o, rg.ssw, sl2.u);
+            if (edge && !((rg.ok >> j) & 1u)) o = make_uint4(0, 0, 0, 0);
+            *(uint4*)(d0 + j * (WS_PROD / 2 * 16)) = o;
         }
     }
 }
@@ -299,7 +299,7 @@ __device__ __forceinline__ void prod_commit(const ConvArgs& p, ChunkRegs& rg, un
 #define WS_PF 1  // fragment prefetch distance in taps (2 measured slower: 610 vs 664 TFLOP/s on 32->32 @128^3, batch 8)
 #endif
 
-template <int R, int K0, int K1, int K2>
+template <int R, int K0, int K1, int K2, bool FIRST>
 __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R], const unsigned char* ap, int h1, int h2,
                                               f32x16 (&acc)[R]) {
     // Software pipeline over the (compile-time) taps: the A/B fragments of tap t + WS_PF are read while the MFMAs of
@@ -326,8 +326,15 @@ __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R
     for (int t = 0; t < T; ++t) {
         const int cb = t % NS;
         if (t + WS_PF < T) fetch(t + WS_PF, (t + WS_PF) % NS);
+        if (FIRST && t == 0) {
+            // first tap of a tile: C = 0 as an inline constant instead of 16 R zeroed accumulator registers
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb], b[cb][r], acc[r], 0, 0, 0);
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb], b[cb][r], zero, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb], b[cb][r], acc[r], 0, 0, 0);
+        }
         if (t + WS_PF < T) __builtin_amdgcn_sched_group_barrier(0x100, R + 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, R, 0);
     }
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = (wave >= 4) != ((dbg & 1024) != 0);  // dbg 1024: swap roles (producers = older waves 0-3)
+    const bool producer = wave >= 4;
     const int l31 = lane & 31;
     const int kh = lane >> 5;
     constexpr int taps = K0 * K1 * K2;
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     if (producer) {
         // ---- producer waves: chunk g + 1 is committed to LDS while the consumers work on chunk g; its global loads
         // were issued one barrier earlier (prod_issue), those of chunk g + 2 are issued right after the commit.
-        const int q = tid & 255;
+        const int q = tid - 256;
         if (dbg & 256) __builtin_amdgcn_s_setprio(1);
         if (dbg & 512) __builtin_amdgcn_s_setprio(3);
         const ProdConst pc = prod_const(p, q, HV);
@@ -379,11 +386,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         items.ok = 0;
         ChunkRegs rg;
 #pragma unroll
-        for (int j = 0; j < WS_MAXV; ++j) rg.lo[j] = rg.hi[j] = make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < WS_MAXV; ++j) rg.d[j] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) rg.wv[j] = make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < WS_WB; ++j) rg.wv[j] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) rg.ssw[j] = 0;
+        for (int j = 0; j < 8; ++j) rg.ssw[j] = 0;
         rg.ok = rg.live = 0;
         rg.has_ss = 0;
         const bool want_w = !(resident_w || (dbg & 16));
@@ -399,12 +406,17 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             if (live && g + 1 < my_chunks) {
                 unsigned char* nxt = bufs + ((g + 1) & 1) * buf_bytes;
                 WS_STAMP(1);
+                if (p.trace) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    WS_STAMP(7);
+                }
                 prod_commit(p, rg, nxt, want_w ? nxt + 2 * plane : nullptr, q, HV, plane, taps, dbg);
                 WS_STAMP(2);
                 if (g + 2 < my_chunks) {
                     if (pcc == 0) {
                         next_tile(p, ptc);
                         prod_setup(p, ptc, pc, items);
+                        WS_STAMP(8);
                     }
                     prod_issue(p, ptc, items, pc.in_halo, pcc, want_w, q, taps, dbg, rg);
                     if (++pcc == ncc) pcc = 0;
@@ -434,54 +446,52 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             hoff[r] = (((tx * p.s0) * p.h1 + ty * p.s1) * p.h2 + tz * p.s2) * 16 + kh * plane;
         }
     }
-    // epilogue constants.  After the LDS transpose this lane owns couts [8 sq, 8 sq + 8) of voxels sv and sv + 16 of
-    // each M-tile.  Output voxel index relative to the tile origin = srel0 (lane part: voxel sv of M-tile 0 of wave 0)
-    // + half * srel16 (voxel sv + 16) + the M-tile's own offset (wave-uniform, recomputed from cw, r when needed).
-    const int sv = lane >> 2, sq = lane & 3;
+    // epilogue constants: output voxel index relative to the tile origin = srel0 (this lane's voxel l31 within an
+    // M-tile) + the M-tile's own offset (wave-uniform, recomputed from cw, r).
     auto vox_rel = [&](int v, int& x, int& y, int& z) {
         x = v >> (p.lw2 + p.lw1);
         y = (v >> p.lw2) & (p.w1 - 1);
         z = v & (p.w2 - 1);
     };
-    int srel0, srel16;
+    int srel0;
     {
         int x, y, z;
-        vox_rel(sv, x, y, z);
+        vox_rel(l31, x, y, z);
         srel0 = (x * p.Ho + y) * p.Wo + z;
-        vox_rel(sv + 16, x, y, z);
-        srel16 = (x * p.Ho + y) * p.Wo + z - srel0;
     }
     const size_t out_vox = (size_t)p.Do * p.Ho * p.Wo;
     const int nslots = p.nslots;
     const int slot = (int)blockIdx.x * 4 + cw;
-    unsigned char* slab = bufs + 2 * buf_bytes + cw * (32 * 80);
-    // InstanceNorm partial sums of this wave over the couts [8 sq, 8 sq + 8) of the voxels this lane stored since the
-    // last flush (values as stored, i.e. after the fp16 rounding); one flush per (n, cout chunk) the wave works on
-    float st_s[8], st_q[8];
+    // InstanceNorm partial sums of this wave in the D-fragment layout: entry gq * 4 + e <-> cout 8 gq + 4 kh + e, summed
+    // over the voxels (lane l31 of every M-tile) this lane produced since the last flush, from the fp32 accumulators;
+    // one flush per (n, cout chunk) the wave works on.
+    // The conv bias is NOT added: every conv this kernel runs is followed by InstanceNorm, which removes any per-channel
+    // constant exactly ((x + b) - mean(x + b) = x - mean(x)); storing x keeps one fp16 rounding of a smaller magnitude.
+    float st_s[16], st_q[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st_s[i] = st_q[i] = 0.f;
+    for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
     int st_n = -1, st_cy = 0;
     auto flush_stats = [&]() {
         if (st_n < 0) return;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 16; ++i) {
 #pragma unroll
-            for (int mm = 4; mm < 64; mm <<= 1) {  // the 16 lanes that share sq (lane bits 2..5)
+            for (int mm = 1; mm < 32; mm <<= 1) {  // the 32 lanes that share kh
                 st_s[i] += __shfl_xor(st_s[i], mm);
                 st_q[i] += __shfl_xor(st_q[i], mm);
             }
         }
-        if (lane < 4) {
+        if (l31 == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = st_cy * 32 + sq * 8 + i;
+            for (int i = 0; i < 16; ++i) {
+                const int row = st_cy * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
                 float* pp = p.partials + (((size_t)st_n * p.Cout + row) * 2) * nslots + slot;
                 pp[0] = st_s[i];
                 pp[nslots] = st_q[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) st_s[i] = st_q[i] = 0.f;
+        for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
     };
 
     TileCoord tc;
@@ -493,10 +503,6 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         else
             next_tile(p, tc);
         f32x16 acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
         for (int cc = 0; cc < ncc; ++cc) {
             const int g = k * ncc + cc;
             const unsigned char* cur = bufs + (g & 1) * buf_bytes;
@@ -510,13 +516,14 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             }
             const unsigned char* ap = (resident_w ? smem + cc * taps * 1024 : cur + 2 * plane) + (kh * 32 + l31) * 16;
             WS_STAMP(4);
-            if (!(dbg & 1)) consume_chunk<R, K0, K1, K2>(bp, ap, p.h1, p.h2, acc);
+            if (cc == 0)
+                consume_chunk<R, K0, K1, K2, true>(bp, ap, p.h1, p.h2, acc);
+            else
+                consume_chunk<R, K0, K1, K2, false>(bp, ap, p.h1, p.h2, acc);
             WS_STAMP(5);
             if (cc == ncc - 1 && !(dbg & 8)) {
-                // ---- epilogue: + bias, InstanceNorm partial sums (fp32 values, before rounding), fp16 convert, LDS
-                // transpose, 16-byte coalesced stores.  (D fragment = 4 couts per lane at a 64-byte voxel pitch: stored
-                // directly that is 16 strided 8-byte store instructions per wave and tile, which are store-issue bound;
-                // through a per-wave LDS slab each store instruction writes 1 KiB of whole 64-byte voxel records.)
+                // ---- epilogue: + bias, InstanceNorm partial sums (fp32), register transpose (v_permlane32_swap), fp16
+                // convert, two 16-byte stores per lane (32 contiguous bytes of the voxel's record)
                 if (tc.n != st_n || tc.cy != st_cy) {
                     flush_stats();
                     st_n = tc.n;
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 }
                 const int cout0 = tc.cy * 32;
                 const bool full = tc.ox0 + p.b0 * p.w0 <= p.Do && tc.oy0 + p.b1 * p.w1 <= p.Ho && tc.oz0 + p.b2 * p.w2 <= p.Wo;
-                __half* obase = p.out + ((size_t)tc.n * out_vox + ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0 + srel0) * p.Cout + cout0 + sq * 8;
+                __half* obase = p.out + ((size_t)tc.n * out_vox + ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0 + srel0) * p.Cout + cout0 + kh * 16;
                 // the tile's 16 bias values of this lane (4 independent loads, one wait)
                 float4 bq[4];
 #pragma unroll
@@ -534,43 +541,55 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     const int m = cw * R + r;  // wave-uniform M-tile origin within the block tile
                     const int mx = (m >> (p.lb2 + p.lb1)) * p.w0, my = ((m >> p.lb2) & (p.b1 - 1)) * p.w1, mz = (m & (p.b2 - 1)) * p.w2;
                     const int mrel = (mx * p.Ho + my) * p.Wo + mz;
+                    bool ok = true;
+                    if (!full) {  // wave-uniform: only tiles that stick out of the tensor mask statistics and stores
+                        int x, y, z;
+                        vox_rel(l31, x, y, z);
+                        ok = tc.ox0 + mx + x < p.Do && tc.oy0 + my + y < p.Ho && tc.oz0 + mz + z < p.Wo;
+                    }
+                    const float dm = ok ? 1.f : 0.f;
+                    float v[16];
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
-                        union {
-                            uint2 u;
-                            __half h[4];
-                        } pk;
-                        pk.h[0] = __float2half_rn(acc[r][gq * 4 + 0] + bq[gq].x);
-                        pk.h[1] = __float2half_rn(acc[r][gq * 4 + 1] + bq[gq].y);
-                        pk.h[2] = __float2half_rn(acc[r][gq * 4 + 2] + bq[gq].z);
-                        pk.h[3] = __float2half_rn(acc[r][gq * 4 + 3] + bq[gq].w);
-                        *(uint2*)(slab + l31 * 80 + (8 * gq + 4 * kh) * 2) = pk.u;
+                        v[gq * 4 + 0] = acc[r][gq * 4 + 0] + bq[gq].x;
+                        v[gq * 4 + 1] = acc[r][gq * 4 + 1] + bq[gq].y;
+                        v[gq * 4 + 2] = acc[r][gq * 4 + 2] + bq[gq].z;
+                        v[gq * 4 + 3] = acc[r][gq * 4 + 3] + bq[gq].w;
                     }
-                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        union {
-                            uint4 u;
-                            __half h[8];
-                        } d;
-                        d.u = *(const uint4*)(slab + (sv + 16 * half) * 80 + sq * 16);
-                        bool ok = true;
-                        if (!full) {  // wave-uniform: only tiles that stick out of the tensor
-                            int x, y, z;
-                            vox_rel(sv + 16 * half, x, y, z);
-                            ok = tc.ox0 + mx + x < p.Do && tc.oy0 + my + y < p.Ho && tc.oz0 + mz + z < p.Wo;
-                        }
-                        if (ok) {
-                            if (!(dbg & 4)) *(uint4*)(obase + (size_t)(mrel + half * srel16) * p.Cout) = d.u;
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const float vr = __half2float(d.h[i]);
-                                st_s[i] += vr;
-                                st_q[i] = __builtin_fmaf(vr, vr, st_q[i]);
-                            }
-                        }
+                    for (int i = 0; i < 16; ++i) {
+                        const float vm = full ? v[i] : v[i] * dm;
+                        st_s[i] += vm;
+                        st_q[i] = __builtin_fmaf(vm, vm, st_q[i]);
                     }
-                    __builtin_amdgcn_wave_barrier();
+                    // D fragment -> voxel records without LDS: v_permlane32_swap exchanges the upper half of one register
+                    // with the lower half of another.  Lane (kh, voxel) holds couts 8 gq + 4 kh + e; swapping group gq with
+                    // group gq + 2 leaves the kh = 0 lane with couts [0, 16) and the kh = 1 lane with couts [16, 32) of its
+                    // voxel: 32 contiguous bytes each.
+                    unsigned w[8];
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {  // pr 0: groups (0, 2) -> couts 0-7 | 16-23; pr 1: groups (1, 3) -> 8-15 | 24-31
+                        float lo4[4], hi4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[pr * 4 + e]), __float_as_uint(v[(pr + 2) * 4 + e]), false, false);
+                            lo4[e] = __uint_as_float(sw[0]);  // kh 0: cout 8 pr + e      | kh 1: cout 16 + 8 pr + e
+                            hi4[e] = __uint_as_float(sw[1]);  // kh 0: cout 8 pr + 4 + e  | kh 1: cout 16 + 8 pr + 4 + e
+                        }
+                        union {
+                            unsigned u;
+                            __half h[2];
+                        } c;
+                        c.h[0] = __float2half_rn(lo4[0]); c.h[1] = __float2half_rn(lo4[1]); w[pr * 4 + 0] = c.u;
+                        c.h[0] = __float2half_rn(lo4[2]); c.h[1] = __float2half_rn(lo4[3]); w[pr * 4 + 1] = c.u;
+                        c.h[0] = __float2half_rn(hi4[0]); c.h[1] = __float2half_rn(hi4[1]); w[pr * 4 + 2] = c.u;
+                        c.h[0] = __float2half_rn(hi4[2]); c.h[1] = __float2half_rn(hi4[3]); w[pr * 4 + 3] = c.u;
+                    }
+                    if (ok && !(dbg & 4)) {
+                        __half* dst = obase + (size_t)mrel * p.Cout;
+                        *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
+                        *(uint4*)(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+                    }
                 }
             }
             WS_STAMP(6);
@@ -599,7 +618,7 @@ int conv_ws_nslots(int cu_count) { return cu_count * 4; }
 bool conv_ws_supported(const int k[3], int HV) {
     const bool k333 = k[0] == 3 && k[1] == 3 && k[2] == 3;
     const bool k133 = k[0] == 1 && k[1] == 3 && k[2] == 3;
-    return (k333 || k133) && HV <= 256 * WS_MAXV;
+    return (k333 || k133) && 2 * HV <= WS_PROD * WS_MAXV;
 }
 
 template <int R, int K0, int K1, int K2>
@@ -662,7 +681,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
         for (int role = 0; role < 2; ++role) {
             const unsigned long long* h = host + role * (WS_TRACE_SLOTS / 2);
             fprintf(stderr, "[ws-trace] %s Cin=%d Cout=%d in=%d R=%d:", role ? "producer" : "consumer", a0.C0 + a0.C1, a0.Cout, a0.Di, t.R);
-            const int lo = 40, hi = 40 + (role ? 36 : 36);
+            const int lo = 40, hi = 40 + (role ? 50 : 36);
             for (int i = lo; i < hi && h[i]; ++i)
                 fprintf(stderr, " %d:%llu", (int)(h[i] >> 56), (h[i] & 0x00ffffffffffffffull) - (h[i - 1] & 0x00ffffffffffffffull));
             fprintf(stderr, "\n");
