@@ -43,15 +43,24 @@ struct TileCoord {
 };
 
 __device__ __forceinline__ TileCoord decode_tile(const ConvArgs& p, int t) {
-    // order: spatial tiles fastest (x fastest, then z, then y), then cout chunk, then n.  With the dominant halo
+    // default order: spatial tiles fastest (x fastest, then z, then y), then cout chunk, then n.  With the dominant halo
     // overlap along x (thin tiles in x), consecutive tiles share their x-halo planes.
+    // p.cy_fast (2-chunk inputs with several cout chunks): cout chunk fastest -- consecutive tiles of a workgroup then
+    // need the SAME staged halo (both 16-channel chunks stay in the two LDS buffers), only the weights change.
     TileCoord c;
     const int nsp = p.t0 * p.t1 * p.t2;
     const int ncy = p.Cout / 32;
-    c.sp = t % nsp;
-    int r = t / nsp;
-    c.cy = r % ncy;
-    c.n = r / ncy;
+    if (p.cy_fast) {
+        c.cy = t % ncy;
+        const int r = t / ncy;
+        c.sp = r % nsp;
+        c.n = r / nsp;
+    } else {
+        c.sp = t % nsp;
+        const int r = t / nsp;
+        c.cy = r % ncy;
+        c.n = r / ncy;
+    }
     int bt = c.sp;
     const int tx = bt % p.t0;
     bt /= p.t0;
@@ -63,9 +72,14 @@ __device__ __forceinline__ TileCoord decode_tile(const ConvArgs& p, int t) {
     return c;
 }
 
-// next tile of a contiguous walk (tile index + 1) without divisions: x, then z, then y, then cout chunk, then n
+// next tile of a contiguous walk (tile index + 1) without divisions
 __device__ __forceinline__ void next_tile(const ConvArgs& p, TileCoord& c) {
     const int e0 = p.b0 * p.w0, e1 = p.b1 * p.w1, e2 = p.b2 * p.w2;
+    const int ncy = p.Cout / 32;
+    if (p.cy_fast) {
+        if (++c.cy < ncy) return;
+        c.cy = 0;
+    }
     ++c.sp;
     c.ox0 += e0;
     if (c.ox0 >= p.t0 * e0) {
@@ -77,7 +91,9 @@ __device__ __forceinline__ void next_tile(const ConvArgs& p, TileCoord& c) {
             if (c.oy0 >= p.t1 * e1) {
                 c.oy0 = 0;
                 c.sp = 0;
-                if (++c.cy >= p.Cout / 32) {
+                if (p.cy_fast) {
+                    ++c.n;
+                } else if (++c.cy >= ncy) {
                     c.cy = 0;
                     ++c.n;
                 }
@@ -213,10 +229,11 @@ struct ChunkRegs {
     unsigned ok;          // bit j: voxel j is inside the input tensor
     unsigned live;        // bit j: voxel j belongs to the halo (v < HV)
     int has_ss;
+    int skip_halo;        // the LDS buffer already holds this chunk's halo (previous tile = same spatial tile, other couts)
 };
 
 __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& tc, const ProdItems& it, unsigned live, int cc,
-                                           bool want_w, int q, int taps, int dbg, ChunkRegs& rg) {
+                                           bool want_w, bool skip_halo, int q, int taps, int dbg, ChunkRegs& rg) {
     int cg = cc * 16;
     const size_t in_vox = (size_t)p.Di * p.Hi * p.Wi;
     const __half* base;
@@ -233,6 +250,17 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
         C = p.C1;
     }
     if (dbg & 64) ss = nullptr;
+    rg.skip_halo = skip_halo;
+    if (want_w) {
+        const int nw = taps * 64;
+        const __half* wsrc = p.wpk + ((size_t)cc * taps * 2) * p.Cout * 8 + (size_t)tc.cy * 32 * 8;
+#pragma unroll
+        for (int b = 0; b < WS_WB; ++b) {
+            const int i = min(q + b * WS_PROD, nw - 1);
+            rg.wv[b] = *(const uint4*)(wsrc + ((size_t)(i >> 5) * p.Cout + (i & 31)) * 8);
+        }
+    }
+    if (skip_halo) return;
     rg.ok = it.ok;
     rg.live = live;
     rg.has_ss = ss != nullptr;
@@ -242,15 +270,6 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
     for (int j = 0; j < WS_MAXV; ++j) {
         // unconditional: voxels beyond the halo / outside the tensor have gi == 0 (a valid address, data discarded)
         rg.d[j] = *(const uint4*)(lbase + (unsigned)it.gi[j] * cb2);
-    }
-    if (want_w) {
-        const int nw = taps * 64;
-        const __half* wsrc = p.wpk + ((size_t)cc * taps * 2) * p.Cout * 8 + (size_t)tc.cy * 32 * 8;
-#pragma unroll
-        for (int b = 0; b < WS_WB; ++b) {
-            const int i = min(q + b * WS_PROD, nw - 1);
-            rg.wv[b] = *(const uint4*)(wsrc + ((size_t)(i >> 5) * p.Cout + (i & 31)) * 8);
-        }
     }
     if (ss) {
         const unsigned* sl = ss + (q & 1) * 8;
@@ -270,6 +289,7 @@ __device__ __forceinline__ void prod_commit(const ConvArgs& p, ChunkRegs& rg, un
             *(uint4*)(dst_w + i * 16) = rg.wv[b];
         }
     }
+    if (rg.skip_halo) return;
     // the (scale, shift) words stay in VGPRs: a packed fp16 fma takes at most one scalar operand, so SGPR copies cost
     // a v_mov (+ hazard nops) per use -- more instructions than the transform itself
     union {
@@ -393,13 +413,16 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         for (int j = 0; j < 8; ++j) rg.ssw[j] = 0;
         rg.ok = rg.live = 0;
         rg.has_ss = 0;
+        rg.skip_halo = 0;
+        // halo reuse across the cout chunks of one spatial tile (cy-fast order, 2 chunks = both stay resident)
+        bool reuse = false;
         const bool want_w = !(resident_w || (dbg & 16));
         int pcc = 0;  // chunk within the tile of the next chunk to issue
         const bool live = !(dbg & 2);
         if (live && my_chunks > 0) {
             ptc = decode_tile(p, walk.first);
             prod_setup(p, ptc, pc, items);
-            prod_issue(p, ptc, items, pc.in_halo, 0, want_w, q, taps, dbg, rg);
+            prod_issue(p, ptc, items, pc.in_halo, 0, want_w, false, q, taps, dbg, rg);
             if (++pcc == ncc) pcc = 0;
         }
         for (int g = -1; g < my_chunks; ++g) {
@@ -415,10 +438,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 if (g + 2 < my_chunks) {
                     if (pcc == 0) {
                         next_tile(p, ptc);
-                        prod_setup(p, ptc, pc, items);
+                        reuse = p.cy_fast && ptc.cy != 0;  // same spatial tile as the previous tile of this run
+                        if (!reuse) prod_setup(p, ptc, pc, items);
                         WS_STAMP(8);
                     }
-                    prod_issue(p, ptc, items, pc.in_halo, pcc, want_w, q, taps, dbg, rg);
+                    prod_issue(p, ptc, items, pc.in_halo, pcc, want_w, reuse, q, taps, dbg, rg);
                     if (++pcc == ncc) pcc = 0;
                 }
                 WS_STAMP(3);
@@ -467,31 +491,45 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     // one flush per (n, cout chunk) the wave works on.
     // The conv bias is NOT added: every conv this kernel runs is followed by InstanceNorm, which removes any per-channel
     // constant exactly ((x + b) - mean(x + b) = x - mean(x)); storing x keeps one fp16 rounding of a smaller magnitude.
-    float st_s[16], st_q[16];
+    // Two sets: with the cout-chunk-fastest tile order (p.cy_fast, 2 cout chunks, R == 1 kernels only) consecutive tiles
+    // alternate between cout chunk 0 (set A) and 1 (set B); otherwise only set A is used.
+    constexpr bool TWO_SETS = (R == 1);
+    struct StatSet {
+        float s[16], q[16];
+    };
+    StatSet stA, stB;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
+    for (int i = 0; i < 16; ++i) stA.s[i] = stA.q[i] = stB.s[i] = stB.q[i] = 0.f;
     int st_n = -1, st_cy = 0;
-    auto flush_stats = [&]() {
-        if (st_n < 0) return;
+    auto flush_set = [&](StatSet& st, int cy) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
 #pragma unroll
             for (int mm = 1; mm < 32; mm <<= 1) {  // the 32 lanes that share kh
-                st_s[i] += __shfl_xor(st_s[i], mm);
-                st_q[i] += __shfl_xor(st_q[i], mm);
+                st.s[i] += __shfl_xor(st.s[i], mm);
+                st.q[i] += __shfl_xor(st.q[i], mm);
             }
         }
         if (l31 == 0) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int row = st_cy * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
+                const int row = cy * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
                 float* pp = p.partials + (((size_t)st_n * p.Cout + row) * 2) * nslots + slot;
-                pp[0] = st_s[i];
-                pp[nslots] = st_q[i];
+                pp[0] = st.s[i];
+                pp[nslots] = st.q[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
+        for (int i = 0; i < 16; ++i) st.s[i] = st.q[i] = 0.f;
+    };
+    auto flush_stats = [&]() {
+        if (st_n < 0) return;
+        if (TWO_SETS && p.cy_fast) {
+            flush_set(stA, 0);
+            flush_set(stB, 1);
+        } else {
+            flush_set(stA, st_cy);
+        }
     };
 
     TileCoord tc;
@@ -524,7 +562,8 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             if (cc == ncc - 1 && !(dbg & 8)) {
                 // ---- epilogue: + bias, InstanceNorm partial sums (fp32), register transpose (v_permlane32_swap), fp16
                 // convert, two 16-byte stores per lane (32 contiguous bytes of the voxel's record)
-                if (tc.n != st_n || tc.cy != st_cy) {
+                const bool two = TWO_SETS && p.cy_fast;
+                if (tc.n != st_n || (!two && tc.cy != st_cy)) {
                     flush_stats();
                     st_n = tc.n;
                     st_cy = tc.cy;
@@ -556,11 +595,20 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                         v[gq * 4 + 2] = acc[r][gq * 4 + 2] + bq[gq].z;
                         v[gq * 4 + 3] = acc[r][gq * 4 + 3] + bq[gq].w;
                     }
+                    if (TWO_SETS && two && tc.cy != 0) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float vm = full ? v[i] : v[i] * dm;
-                        st_s[i] += vm;
-                        st_q[i] = __builtin_fmaf(vm, vm, st_q[i]);
+                        for (int i = 0; i < 16; ++i) {
+                            const float vm = full ? v[i] : v[i] * dm;
+                            stB.s[i] += vm;
+                            stB.q[i] = __builtin_fmaf(vm, vm, stB.q[i]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float vm = full ? v[i] : v[i] * dm;
+                            stA.s[i] += vm;
+                            stA.q[i] = __builtin_fmaf(vm, vm, stA.q[i]);
+                        }
                     }
                     // D fragment -> voxel records without LDS: v_permlane32_swap exchanges the upper half of one register
                     // with the lower half of another.  Lane (kh, voxel) holds couts 8 gq + 4 kh + e; swapping group gq with
@@ -656,6 +704,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     a.trace = nullptr;
     // statistics slots: one per (workgroup, consumer wave); waves that never touch an (n, cout chunk) leave zeros
     a.nslots = conv_ws_nslots(ctx->cu_count);
+    a.cy_fast = ((a.C0 + a.C1) == 32 && a.Cout == 64 && t.R == 1 && !getenv("BOA_WS_NO_CYFAST")) ? 1 : 0;
     BOA_HIP_TRY(hipMemsetAsync(a.partials, 0, (size_t)a.N * a.Cout * 2 * a.nslots * sizeof(float), ctx->stream));
     if (want_trace) {
         hipMalloc(&a.trace, WS_TRACE_SLOTS * 8);
