@@ -171,13 +171,18 @@ def main():
                        "tiles_per_volume": tiles_per_volume, "tile_batch": args.batch,
                        "tflop_per_volume": flops_per_volume / 1e12,
                        "precision": "fp16 activations/weights, fp32 MFMA accumulate, fp16 logit accumulators (reference semantics)"},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_mfma (implicit-GEMM 3x3x3 conv, v_mfma_f32_32x32x16_f16)",
+            "roofline": {"bound": "mfma", "kernel": "k_conv_ws<R,3,3,3> (all MFMA 3x3x3 conv launches: wave-specialised implicit GEMM, v_mfma_f32_32x32x16_f16)",
                          "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
                          "launches": conv["launches"], "avg_launch_ms": conv_ms / max(conv["launches"], 1),
                          "flops_per_launch": conv["flops"] / max(conv["launches"], 1),
                          "share_of_kernel_time": conv_ms / max(total_ms, 1e-9)},
             "end_to_end_tflops": flops_per_volume * args.steps / elapsed / 1e12,
+            # the HBM-bound stages of the same run (algorithmic bytes / event time, peak 8 TB/s): BASELINE.json's "% HBM roofline"
+            "hbm_stages": {k: {"achieved_GBps": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6,
+                               "frac": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6 / 8000.0, "ms": prof[k]["ms"],
+                               "launches": prof[k]["launches"]}
+                           for k in ("head_accum", "finalize_argmax", "convT_mfma", "conv_first") if prof[k]["launches"]},
         }
         if not args.no_cpu and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(models[0][3], args.cpu_tiles, tiles_per_volume, log)

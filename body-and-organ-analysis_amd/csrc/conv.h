@@ -54,8 +54,10 @@ int conv_first_nblk(const int P[3]);
 void conv_first_padded_dims(const int P[3], const int k[3], int out[3]);
 
 // InstanceNorm statistics -> (scale, shift) per (n, c):  scale = gamma * rsqrt(var + eps), shift = beta - mean * scale
-int launch_norm_finalize(boa_ctx* ctx, const float* partials, int nblk, int N, int C, double count,
-                         const float* gamma, const float* beta, float eps, float* ss_out, unsigned* ss16_out);
+// clear != 0: zero the partials after reading them (k_conv_ws expects a zeroed table: it only writes the slots of waves
+// that worked on an (n, cout) -- the table is zeroed once at allocation and kept zeroed by the finalize).
+int launch_norm_finalize(boa_ctx* ctx, float* partials, int nblk, int N, int C, double count,
+                         const float* gamma, const float* beta, float eps, float* ss_out, unsigned* ss16_out, int clear);
 
 // ConvTranspose3d with kernel == stride, + bias; input source with deferred norm; out fp16 raw.
 int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], const int s[3], int Cout,

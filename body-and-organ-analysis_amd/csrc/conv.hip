@@ -633,18 +633,22 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
 
 // ======================================================================================================
 // InstanceNorm finalize: deterministic fp64 reduction of the per-block partials
-__global__ __launch_bounds__(256) void k_norm_finalize(const float* __restrict__ partials, int nblk, int C, double count,
+__global__ __launch_bounds__(256) void k_norm_finalize(float* __restrict__ partials, int nblk, int C, double count, int clear,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, float* __restrict__ ss,
                                                       unsigned short* __restrict__ ss16) {
     const int c = blockIdx.x, n = blockIdx.y;
-    const float* ps = partials + (((size_t)n * C + c) * 2 + 0) * nblk;
-    const float* pq = partials + (((size_t)n * C + c) * 2 + 1) * nblk;
+    float* ps = partials + (((size_t)n * C + c) * 2 + 0) * nblk;
+    float* pq = partials + (((size_t)n * C + c) * 2 + 1) * nblk;
     __shared__ double red[8];
     double s = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 256) {
         s += (double)ps[i];
         q += (double)pq[i];
+        if (clear) {  // k_conv_ws only writes the slots of waves that worked on (n, c): leave the table zeroed for the next launch
+            ps[i] = 0.f;
+            pq[i] = 0.f;
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -675,11 +679,11 @@ __global__ __launch_bounds__(256) void k_norm_finalize(const float* __restrict__
     }
 }
 
-int launch_norm_finalize(boa_ctx* ctx, const float* partials, int nblk, int N, int C, double count,
-                         const float* gamma, const float* beta, float eps, float* ss_out, unsigned* ss16_out) {
+int launch_norm_finalize(boa_ctx* ctx, float* partials, int nblk, int N, int C, double count,
+                         const float* gamma, const float* beta, float eps, float* ss_out, unsigned* ss16_out, int clear) {
     KernelTimer tm(ctx, BOA_K_NORM_FINALIZE, 0, (double)N * C * nblk * 8.0);
-    hipLaunchKernelGGL(k_norm_finalize, dim3(C, N), dim3(256), 0, ctx->stream, partials, nblk, C, count, gamma, beta,
-                       eps, ss_out, (unsigned short*)ss16_out);
+    hipLaunchKernelGGL(k_norm_finalize, dim3(C, N), dim3(256), 0, ctx->stream, partials, nblk, C, count, clear, gamma,
+                       beta, eps, ss_out, (unsigned short*)ss16_out);
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

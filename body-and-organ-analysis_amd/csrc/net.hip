@@ -137,6 +137,7 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
     size_t vox = (size_t)dout[0] * dout[1] * dout[2];
     BOA_TRY(net_alloc(net, (size_t)N * vox * cout * sizeof(__half), (void**)&L.out));
     BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * L.nblk * sizeof(float), (void**)&L.partials));
+    BOA_HIP_TRY(hipMemsetAsync(L.partials, 0, (size_t)N * cout * 2 * L.nblk * sizeof(float), net->ctx->stream));
     BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * sizeof(float), (void**)&L.ss));
     BOA_TRY(net_alloc(net, (size_t)N * cout * sizeof(unsigned), (void**)&L.ss16));
     return BOA_OK;
@@ -334,7 +335,7 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
             prof_end(L.first ? "first" : "conv", din, L.Cin0 + L.Cin1, g.Cout, g.k, g.s, fl, L.first ? nullptr : &L.t);
         }
         double count = (double)g.Do * g.Ho * g.Wo;
-        BOA_TRY(launch_norm_finalize(c, L.partials, L.nblk, N, g.Cout, count, L.gamma, L.beta, d.norm_eps, L.ss, L.ss16));
+        BOA_TRY(launch_norm_finalize(c, L.partials, L.nblk, N, g.Cout, count, L.gamma, L.beta, d.norm_eps, L.ss, L.ss16, 1));
         return BOA_OK;
     };
     ActSrc cur, none;
@@ -455,6 +456,7 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     T_(boa_malloc(ctx, Cout * 4, (void**)&gamma));
     T_(boa_malloc(ctx, Cout * 4, (void**)&beta));
     T_(boa_malloc(ctx, (size_t)N * Cout * 2 * nblk * 4, (void**)&partials));
+    T_(boa_memset(ctx, partials, 0, (size_t)N * Cout * 2 * nblk * 4));
     T_(boa_malloc(ctx, (size_t)N * Cout * 2 * 4, (void**)&ss));
     T_(boa_h2d(ctx, wpk, tmp.data(), tmp.size() * 2));
     T_(boa_h2d(ctx, bias, host_b, Cout * 4));
@@ -464,7 +466,7 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     ActSrc a, none;
     a.data = in16; a.ss = nullptr; a.C = Cin;
     T_(launch_conv_mfma(ctx, a, none, g, t, wpk, bias, 0.01f, out16, partials));
-    T_(launch_norm_finalize(ctx, partials, nblk, N, Cout, (double)vout, gamma, beta, 1e-5f, ss, nullptr));
+    T_(launch_norm_finalize(ctx, partials, nblk, N, Cout, (double)vout, gamma, beta, 1e-5f, ss, nullptr, 1));
     T_(launch_ndhwc_to_nchw_f32(ctx, out16, with_norm_act ? ss : nullptr, 0.01f, N, Cout, vout, dev_out));
     if (rc == BOA_OK) rc = boa_sync(ctx);
 #undef T_
