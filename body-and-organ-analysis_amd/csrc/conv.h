@@ -50,7 +50,7 @@ int conv_ws_nslots(int cu_count);
 int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins,
                       int N, int Cin, const int P[3], const int k[3], int Cout, const float* w, const float* bias,
                       float* padded_scratch, __half* out, float* partials, int* nblk_out);
-int conv_first_nblk(const int P[3]);
+int conv_first_nblk(const int P[3], int cu_count);
 void conv_first_padded_dims(const int P[3], const int k[3], int out[3]);
 
 // InstanceNorm statistics -> (scale, shift) per (n, c):  scale = gamma * rsqrt(var + eps), shift = beta - mean * scale

@@ -449,6 +449,7 @@ struct FirstArgs {
     __half* out;
     float* partials;
     int t0, t1, t2;
+    int nblk;  // stride of the partials table (>= number of entries a launch writes)
 };
 
 template <int K0, int K1, int K2>
@@ -585,11 +586,194 @@ __global__ __launch_bounds__(256) void k_conv_first(FirstArgs p) {
         float v = lds_red[(0 * 32 + row) * 2 + j] + lds_red[(1 * 32 + row) * 2 + j];
         v += lds_red[(2 * 32 + row) * 2 + j];
         v += lds_red[(3 * 32 + row) * 2 + j];
-        p.partials[(((size_t)n * p.Cout + cout0 + row) * 2 + j) * gridDim.x + blockIdx.x] = v;
+        p.partials[(((size_t)n * p.Cout + cout0 + row) * 2 + j) * p.nblk + blockIdx.x] = v;
     }
 }
 
-int conv_first_nblk(const int P[3]) { return ceil_div(P[0], FT0) * ceil_div(P[1], FT1) * ceil_div(P[2], FT2); }
+// ------------------------------------------------------------------------------------------------------
+// First conv on the matrix cores (Cin == 1, 3x3x3, Cout == 32): the 27 taps are the K dimension (padded to 32 = two
+// v_mfma_f32_32x32x16_f16 steps).  A = weights [cout][k] in registers for the whole kernel, B = im2col fragment gathered
+// from an fp16 halo tile in LDS (lane (voxel z, k-half) reads its 8 taps with 2-byte LDS loads), D[cout][voxel] goes
+// through the same epilogue as k_conv_ws (bias, fp32 InstanceNorm partial sums, v_permlane32_swap transpose, two 16-byte
+// stores per lane).  864 fp32 FMAs per voxel become 2 MFMAs per 32 voxels: the kernel is bound by the 64 B/voxel store.
+// Persistent blocks walk block tiles of MF0 x MF1 x 32 voxels; M-tile = 32 consecutive z at fixed (x, y).
+#define MF0 4
+#define MF1 8
+#define MF2 32
+
+struct FirstMfmaArgs {
+    const float* padded;  // [N][PX][PY][PZ] fp32, conv padding included
+    int PX, PY, PZ;
+    int N, P0, P1, P2;
+    const float* w;  // [27][32] fp32
+    const float* bias;
+    __half* out;      // [N][P0][P1][P2][32]
+    float* partials;  // [N][32][2][nslots]
+    int nslots;
+    int t0, t1, t2;  // block tiles per axis
+};
+
+__global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
+    constexpr int H0 = MF0 + 2, H1 = MF1 + 2, H2 = MF2 + 2, HV = H0 * H1 * H2;
+    __shared__ _Float16 halo[2][HV + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    // A fragments: lane (cout = l31, kh) holds k = 8 kh + i (step 0) and 16 + 8 kh + i (step 1); taps >= 27 are zero
+    f16x8 a0, a1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k0 = 8 * kh + i, k1 = 16 + 8 * kh + i;
+        a0[i] = (_Float16)p.w[k0 * 32 + l31];
+        a1[i] = k1 < 27 ? (_Float16)p.w[k1 * 32 + l31] : (_Float16)0.f;
+    }
+    // LDS offsets (in halves) of this lane's 16 taps relative to the M-tile's first halo voxel
+    int toff[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int t = (i < 8 ? 8 * kh + i : 16 + 8 * kh + (i - 8));
+        t = t < 27 ? t : 26;  // padded taps: any finite value (their weights are zero)
+        toff[i] = ((t / 9) * H1 + (t / 3) % 3) * H2 + t % 3 + l31;
+    }
+    float4 bq[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) bq[gq] = *(const float4*)(p.bias + 8 * gq + 4 * kh);
+    float st_s[16], st_q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
+    int st_n = -1;
+    const int slot = (int)blockIdx.x * 4 + wave;
+    auto flush = [&]() {
+        if (st_n < 0) return;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int mm = 1; mm < 32; mm <<= 1) {
+                st_s[i] += __shfl_xor(st_s[i], mm);
+                st_q[i] += __shfl_xor(st_q[i], mm);
+            }
+        }
+        if (l31 == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 8 * (i >> 2) + 4 * kh + (i & 3);
+                float* pp = p.partials + (((size_t)st_n * 32 + row) * 2) * p.nslots + slot;
+                pp[0] = st_s[i];
+                pp[p.nslots] = st_q[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
+    };
+    const int nsp = p.t0 * p.t1 * p.t2, total = nsp * p.N;
+    const size_t pvol = (size_t)p.PX * p.PY * p.PZ, ovox = (size_t)p.P0 * p.P1 * p.P2;
+    // halo staging is split in two halves so that the global round trip of the NEXT tile overlaps this tile's compute:
+    // fetch() issues the loads into registers, commit() converts and writes them to the other LDS buffer afterwards
+    constexpr int NPRE = (HV + 255) / 256;
+    float pre[NPRE];
+    auto fetch = [&](int t) {
+        const int n = t / nsp;
+        int sp = t % nsp;
+        const int tz = sp % p.t2;
+        sp /= p.t2;
+        const int ty = sp % p.t1, tx = sp / p.t1;
+        const float* src = p.padded + (size_t)n * pvol + ((size_t)(tx * MF0) * p.PY + ty * MF1) * p.PZ + tz * MF2;
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = min(tid + 256 * j, HV - 1);
+            const int z = i % H2, r = i / H2, y = r % H1, x = r / H1;
+            pre[j] = src[((size_t)x * p.PY + y) * p.PZ + z];
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int i = tid + 256 * j;
+            if (i < HV) halo[buf][i] = (_Float16)pre[j];
+        }
+    };
+    int t = blockIdx.x;
+    if (t < total) {
+        fetch(t);
+        commit(0);
+    }
+    __syncthreads();
+    for (int it = 0; t < total; t += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const bool more = t + (int)gridDim.x < total;
+        if (more) fetch(t + gridDim.x);
+        const int n = t / nsp;
+        int sp = t % nsp;
+        const int tz = sp % p.t2;
+        sp /= p.t2;
+        const int ty = sp % p.t1, tx = sp / p.t1;
+        if (n != st_n) {
+            flush();
+            st_n = n;
+        }
+        const _Float16* hb = halo[buf];
+#pragma unroll 2
+        for (int r = 0; r < (MF0 * MF1) / 4; ++r) {
+            const int row = wave * ((MF0 * MF1) / 4) + r;  // (x, y) row of the block tile
+            const int x = row / MF1, y = row % MF1;
+            const _Float16* hr = hb + (x * H1 + y) * H2;
+            f16x8 b0, b1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                b0[i] = hr[toff[i]];
+                b1[i] = hr[toff[8 + i]];
+            }
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+            float v[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                v[gq * 4 + 0] = acc[gq * 4 + 0] + bq[gq].x;
+                v[gq * 4 + 1] = acc[gq * 4 + 1] + bq[gq].y;
+                v[gq * 4 + 2] = acc[gq * 4 + 2] + bq[gq].z;
+                v[gq * 4 + 3] = acc[gq * 4 + 3] + bq[gq].w;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                st_s[i] += v[i];
+                st_q[i] = __builtin_fmaf(v[i], v[i], st_q[i]);
+            }
+            unsigned w8[8];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float lo4[4], hi4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[pr * 4 + e]), __float_as_uint(v[(pr + 2) * 4 + e]), false, false);
+                    lo4[e] = __uint_as_float(sw[0]);
+                    hi4[e] = __uint_as_float(sw[1]);
+                }
+                union {
+                    unsigned u;
+                    __half h[2];
+                } c;
+                c.h[0] = __float2half_rn(lo4[0]); c.h[1] = __float2half_rn(lo4[1]); w8[pr * 4 + 0] = c.u;
+                c.h[0] = __float2half_rn(lo4[2]); c.h[1] = __float2half_rn(lo4[3]); w8[pr * 4 + 1] = c.u;
+                c.h[0] = __float2half_rn(hi4[0]); c.h[1] = __float2half_rn(hi4[1]); w8[pr * 4 + 2] = c.u;
+                c.h[0] = __float2half_rn(hi4[2]); c.h[1] = __float2half_rn(hi4[3]); w8[pr * 4 + 3] = c.u;
+            }
+            __half* dst = p.out + ((size_t)n * ovox + ((size_t)(tx * MF0 + x) * p.P1 + ty * MF1 + y) * p.P2 + tz * MF2 + l31) * 32 + kh * 16;
+            *(uint4*)dst = make_uint4(w8[0], w8[1], w8[2], w8[3]);
+            *(uint4*)(dst + 8) = make_uint4(w8[4], w8[5], w8[6], w8[7]);
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+    }
+    flush();
+}
+
+static bool first_mfma_ok(int Cin, const int P[3], const int k[3], int Cout) {
+    static const bool off = getenv("BOA_FIRST_MFMA") && atoi(getenv("BOA_FIRST_MFMA")) == 0;
+    return !off && Cin == 1 && Cout == 32 && k[0] == 3 && k[1] == 3 && k[2] == 3 && P[0] % MF0 == 0 && P[1] % MF1 == 0 && P[2] % MF2 == 0;
+}
+
+int conv_first_nblk(const int P[3], int cu_count) {
+    return std::max(ceil_div(P[0], FT0) * ceil_div(P[1], FT1) * ceil_div(P[2], FT2), cu_count * 4);
+}
 
 // dims of the zero-padded gather buffer for a patch P and kernel k
 void conv_first_padded_dims(const int P[3], const int k[3], int out[3]) {
@@ -613,13 +797,27 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
                        dev_origins, V[0], V[1], V[2], vol_off ? vol_off[0] : 0, vol_off ? vol_off[1] : 0,
                        vol_off ? vol_off[2] : 0, Cin, P[0], P[1], P[2], (k[0] - 1) / 2, (k[1] - 1) / 2, (k[2] - 1) / 2, PD[0],
                        PD[1], PD[2], padded_scratch);
+    const int nblk_tab = conv_first_nblk(P, ctx->cu_count);
+    if (nblk_out) *nblk_out = nblk_tab;
+    if (first_mfma_ok(Cin, P, k, Cout)) {
+        FirstMfmaArgs m;
+        m.padded = padded_scratch; m.PX = PD[0]; m.PY = PD[1]; m.PZ = PD[2];
+        m.N = N; m.P0 = P[0]; m.P1 = P[1]; m.P2 = P[2];
+        m.w = w; m.bias = bias; m.out = out; m.partials = partials; m.nslots = nblk_tab;
+        m.t0 = P[0] / MF0; m.t1 = P[1] / MF1; m.t2 = P[2] / MF2;
+        const int total = m.t0 * m.t1 * m.t2 * N;
+        hipLaunchKernelGGL(k_conv_first_mfma, dim3(std::min(total, ctx->cu_count)), dim3(256), 0, ctx->stream, m);
+        tm.stop();
+        BOA_HIP_TRY(hipGetLastError());
+        return BOA_OK;
+    }
     FirstArgs a;
+    a.nblk = nblk_tab;
     a.padded = padded_scratch; a.PX = PD[0]; a.PY = PD[1]; a.PZ = PD[2];
     a.N = N; a.Cin = Cin; a.P0 = P[0]; a.P1 = P[1]; a.P2 = P[2]; a.Cout = Cout;
     a.w = w; a.bias = bias; a.out = out; a.partials = partials;
     a.t0 = ceil_div(P[0], FT0); a.t1 = ceil_div(P[1], FT1); a.t2 = ceil_div(P[2], FT2);
     const int nblk = a.t0 * a.t1 * a.t2;
-    if (nblk_out) *nblk_out = nblk;
     const int HV = (FT0 + k[0] - 1) * (FT1 + k[1] - 1) * (FT2 + k[2] - 1);
     const size_t lds = ((size_t)Cin * k[0] * k[1] * k[2] * 32 + (((size_t)Cin * HV + 3) & ~(size_t)3)) * 4 + 1024;
     if (k333)

@@ -121,7 +121,7 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
     L.w_elems = (size_t)cout * (cin0 + cin1) * taps;
     if (first) {
         BOA_REQUIRE(s[0] == 1 && s[1] == 1 && s[2] == 1, "first conv must have stride 1");
-        L.nblk = conv_first_nblk(dout);
+        L.nblk = conv_first_nblk(dout, net->ctx->cu_count);
         BOA_TRY(net_alloc(net, L.w_elems * sizeof(float), (void**)&L.wfirst));
     } else {
         BOA_REQUIRE((cin0 % 16) == 0 && (cin1 % 16) == 0 && (cout % 32) == 0,
