@@ -1128,6 +1128,117 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
     for (int u = 0; u < VPT; ++u) p.nacc[vi + u] = f2us(us2f(p.nacc[vi + u]) + g[u]);
 }
 
+// Head on the matrix cores (F0 == 32, C <= 32, accumulate mode): per 32 consecutive z voxels two
+// v_mfma_f32_32x32x16_f16 (K = 32 channels) replace 32 x C fp32 FMAs per voxel.  B fragments are the voxels' channel
+// records straight from global memory (16 B per lane and step) with the deferred InstanceNorm + LeakyReLU applied in
+// packed fp16, A = the head weights in registers.  D[class][voxel] -> + bias, x Gaussian (fp32), fp16 `+=` into the
+// accumulators exactly as k_head does it (fp32 add, one RTNE rounding): lanes 0-31 / 32-63 update two classes of the
+// same 32 voxels per instruction (64 contiguous bytes each).
+typedef _Float16 hh2_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_head_mfma(HeadArgs p) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    f16x8 a0, a1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a0[i] = l31 < p.C ? (_Float16)p.w[l31 * 32 + 8 * kh + i] : (_Float16)0.f;
+        a1[i] = l31 < p.C ? (_Float16)p.w[l31 * 32 + 16 + 8 * kh + i] : (_Float16)0.f;
+    }
+    hh2_t sc0[4], sh0[4], sc1[4], sh1[4];  // packed (scale, shift) of this lane's channels, steps 0 and 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c0 = 8 * kh + 2 * i, c1 = 16 + 8 * kh + 2 * i;
+        sc0[i] = hh2_t{(_Float16)p.ss[2 * c0], (_Float16)p.ss[2 * c0 + 2]};
+        sh0[i] = hh2_t{(_Float16)p.ss[2 * c0 + 1], (_Float16)p.ss[2 * c0 + 3]};
+        sc1[i] = hh2_t{(_Float16)p.ss[2 * c1], (_Float16)p.ss[2 * c1 + 2]};
+        sh1[i] = hh2_t{(_Float16)p.ss[2 * c1 + 1], (_Float16)p.ss[2 * c1 + 3]};
+    }
+    const hh2_t sl = hh2_t{(_Float16)p.slope, (_Float16)p.slope};
+    float bz[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
+        bz[i] = c < p.C ? p.bias[c] : 0.f;
+    }
+    auto xform = [&](uint4 raw, const hh2_t* sc, const hh2_t* sh) {
+        union {
+            uint4 u;
+            hh2_t v[4];
+            f16x8 f;
+        } x;
+        x.u = raw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const hh2_t y = __builtin_elementwise_fma(x.v[i], sc[i], sh[i]);
+            x.v[i] = __builtin_elementwise_max(y, y * sl);
+        }
+        return x.f;
+    };
+    // per-wave LDS slab for the [class][voxel] transpose: 33 rows (32 classes + pad) x 36 floats (16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) float slab_all[4][32 * 36];
+    float* slab = slab_all[threadIdx.x >> 6];
+    const int mpr = p.P2 / 32;                     // M-tiles per (x, y) row
+    const int n_mt = p.P0 * p.P1 * mpr;
+    const size_t vv = (size_t)p.V0 * p.V1 * p.V2;
+    const int gw = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), nw = (int)(gridDim.x * 4);
+    const int n_items = (p.C + 1) * 4;             // (class, group of 8 voxels); class index C = the n_predictions row
+    for (int mt = gw; mt < n_mt; mt += nw) {
+        const int zb = (mt % mpr) * 32, row = mt / mpr, p1 = row % p.P1, p0 = row / p.P1;
+        const size_t t0 = ((size_t)p0 * p.P1 + p1) * p.P2 + zb;       // first voxel of the M-tile within the tile
+        const size_t v0 = ((size_t)(p.s0 + p0) * p.V1 + (p.s1 + p1)) * p.V2 + (p.s2 + zb);  // ... within the volume
+        const uint4* rec = (const uint4*)(p.act + (t0 + l31) * 32);
+        const uint4 r0 = rec[kh], r1 = rec[2 + kh];
+        // the RMW operands of this lane's items: issued before the MFMAs so that their latency overlaps
+        uint4 gq8[2], old8[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = lane + 64 * it;
+            const int c = item >> 2, grp = item & 3;
+            gq8[it] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);  // 1.0 (no Gaussian)
+            old8[it] = make_uint4(0, 0, 0, 0);
+            if (item < n_items) {
+                if (p.gauss) gq8[it] = *(const uint4*)(p.gauss + t0 + 8 * grp);
+                const unsigned short* src = (c < p.C ? p.acc + (size_t)c * vv : p.nacc) + v0 + 8 * grp;
+                old8[it] = *(const uint4*)src;
+            }
+        }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xform(r0, sc0, sh0), zero, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xform(r1, sc1, sh1), d, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) slab[(8 * (i >> 2) + 4 * kh + (i & 3)) * 36 + l31] = d[i] + bz[i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = lane + 64 * it;
+            const int c = item >> 2, grp = item & 3;
+            if (item < n_items) {
+                union {
+                    uint4 u;
+                    unsigned short h[8];
+                } g, o;
+                g.u = gq8[it];
+                o.u = old8[it];
+                float4 lo = make_float4(1.f, 1.f, 1.f, 1.f), hi = lo;  // the n_predictions row adds the Gaussian itself
+                if (c < p.C) {
+                    lo = *(const float4*)(slab + c * 36 + 8 * grp);
+                    hi = *(const float4*)(slab + c * 36 + 8 * grp + 4);
+                }
+                const float sum[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gg = us2f(g.h[e]);
+                    const float pr = (p.gauss || c >= p.C) ? sum[e] * gg : sum[e];  // prediction *= gaussian (fp32); n += g
+                    o.h[e] = f2us(us2f(o.h[e]) + pr);                               // fp16 += fp32 (fp32 add, RTNE)
+                }
+                unsigned short* dst = (c < p.C ? p.acc + (size_t)c * vv : p.nacc) + v0 + 8 * grp;
+                *(uint4*)dst = o.u;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const int P[3], int C, const float* w,
                 const float* bias, float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc,
                 uint16_t* nacc, const int PV[3], const int start[3]) {
@@ -1149,7 +1260,13 @@ int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const 
     size_t lds = ((size_t)C * F0 + C + 2 * F0) * 4;
     double bytes = (double)pv * (2.0 * F0 + (logits_out ? 4.0 * C : (4.0 * (C + 1) + 2.0)));
     KernelTimer tm(ctx, BOA_K_HEAD_ACCUM, 2.0 * pv * F0 * C, bytes);
-    if (pair)
+    static const bool mfma_off = getenv("BOA_HEAD_MFMA") && atoi(getenv("BOA_HEAD_MFMA")) == 0;
+    // 16-byte accumulator accesses: the tile's z origin, the volume's z extent and the buffers must be 8-voxel aligned
+    if (!logits_out && !mfma_off && F0 == 32 && C <= 31 && P[2] % 32 == 0 && start[2] % 8 == 0 && PV[2] % 8 == 0 &&
+        ((uintptr_t)acc) % 16 == 0 && ((uintptr_t)nacc) % 16 == 0 && (!gauss || ((uintptr_t)gauss) % 16 == 0))
+        hipLaunchKernelGGL(k_head_mfma, dim3((unsigned)std::min<size_t>(pv / 32 / 4, (size_t)ctx->cu_count * 8)), dim3(256), 0,
+                           ctx->stream, a);
+    else if (pair)
         hipLaunchKernelGGL((k_head<32, 2>), dim3((unsigned)((pv / 2 + 255) / 256)), dim3(256), lds, ctx->stream, a);
     else if (F0 == 32)
         hipLaunchKernelGGL((k_head<32, 1>), dim3((unsigned)((pv + 255) / 256)), dim3(256), lds, ctx->stream, a);
