@@ -115,18 +115,28 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
                                                             : conv_lds_bytes((int)HV, taps);
                             if (lds > 160 * 1024) continue;
                             const long long nblocks = tiles * (g.Cout / 32) * g.N;
+                            // experiment hook: BOA_CONV_TILE="w0,w1,w2,b0,b1,b2" forces that shape wherever it is legal
+                            static int ft[6] = {0, 0, 0, 0, 0, 0};
+                            static const bool have_ft = getenv("BOA_CONV_TILE") &&
+                                sscanf(getenv("BOA_CONV_TILE"), "%d,%d,%d,%d,%d,%d", ft, ft + 1, ft + 2, ft + 3, ft + 4, ft + 5) == 6;
+                            const bool forced = have_ft && variant == 1 && g.s[0] == 1 && w0 == ft[0] && w1 == ft[1] && w2 == ft[2] &&
+                                                b0 == ft[3] && b1 == ft[4] && b2 == ft[5];
                             const double valid = (double)dims[0] * dims[1] * dims[2];
                             const double waste = (double)covered / valid;
                             // LDS fragment reads are conflict-free when a wave row is contiguous (w2 lanes at the
                             // stride of the conv); short rows / strided rows cost extra LDS cycles
-                            const double lds_pen = (g.s[2] > 1 ? 1.25 : 1.0) * (w2 < 16 ? 1.15 : 1.0);
+                            // (measured: an 8x8x8 block tile of 4x1x8 wave tiles stages 26 % fewer halo voxels than 4x4x32 of 1x1x32 wave
+                            // tiles and is still 2-4 % slower: rows shorter than 32 lanes cost fragment-read conflicts)
+                            const double lds_pen = (g.s[2] > 1 ? 1.25 : 1.0) * (w2 < 16 ? 1.3 : (w2 < 32 ? 1.15 : 1.0));
                             const double t_mfma = (double)taps * R * 32.0 * lds_pen;
                             double t_chunk;
                             const double slots = cu_count;
                             if (variant == 1) {
                                 const bool res = conv_ws_resident((int)HV, taps, ncc, g.Cout);
-                                const double t_prod = (double)HV / 256.0 * 350.0 + (res ? 0.0 : taps * 64.0 / 256.0 * 60.0) + 700.0;
-                                t_chunk = std::max(t_mfma * 1.15, t_prod) + 500.0;
+                                // measured (s_memtime stamps, 32->32 @128^3): a 1360-voxel chunk costs the producers ~6500
+                                // cycles next to the consumers' MFMA stream -> ~4.3 cycles per halo voxel + fixed part
+                                const double t_prod = (double)HV * 4.3 + (res ? 0.0 : taps * 64.0 / 256.0 * 60.0) + 800.0;
+                                t_chunk = std::max(t_mfma * 1.15, t_prod * (g.s[2] > 1 ? 1.0 : lds_pen)) + 500.0;
                             } else {
                                 const double items = (2.0 * HV + taps * 64.0) / 256.0;
                                 const int bpc = lds <= 78 * 1024 ? 2 : 1;
@@ -135,7 +145,7 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
                             // epilogue + tile turnaround amortised over the chunks of a tile
                             const double t_tile = t_chunk * ncc + (variant == 1 ? 3000.0 : 6000.0);
                             const double rounds = std::ceil((double)nblocks / slots);
-                            const double cost = t_tile * rounds * waste / (double)M * (slots / (double)nblocks);
+                            const double cost = forced ? -1.0 : t_tile * rounds * waste / (double)M * (slots / (double)nblocks);
                             if (cost < best_cost) {
                                 best_cost = cost;
                                 found = true;

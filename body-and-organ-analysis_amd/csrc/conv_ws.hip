@@ -652,13 +652,12 @@ static size_t ws_plane_host(int HV) { return ((size_t)(HV * 16 + 127) / 128) * 1
 
 // resident weights need every tile of the launch to use the same weights: Cout == 32 (one cout chunk)
 bool conv_ws_resident(int HV, int taps, int ncc, int Cout) {
-    return Cout == 32 && (size_t)ncc * taps * 1024 + 4 * ws_plane_host(HV) + 4 * 32 * 80 <= 160 * 1024;
+    return Cout == 32 && (size_t)ncc * taps * 1024 + 4 * ws_plane_host(HV) <= 160 * 1024;
 }
 
 size_t conv_ws_lds_bytes(int HV, int taps, int ncc, int Cout) {
-    const size_t slabs = 4 * 32 * 80;  // per-consumer-wave epilogue transpose slabs
-    if (conv_ws_resident(HV, taps, ncc, Cout)) return (size_t)ncc * taps * 1024 + 4 * ws_plane_host(HV) + slabs;
-    return 2 * (2 * ws_plane_host(HV) + (size_t)taps * 1024) + slabs;
+    if (conv_ws_resident(HV, taps, ncc, Cout)) return (size_t)ncc * taps * 1024 + 4 * ws_plane_host(HV);
+    return 2 * (2 * ws_plane_host(HV) + (size_t)taps * 1024);
 }
 
 int conv_ws_nslots(int cu_count) { return cu_count * 4; }
