@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="tiles per conv-stack launch")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=4)
+    ap.add_argument("--no-prof", action="store_true", help="no per-launch events (measures their overhead; roofline fields become 0)")
     ap.add_argument("--dump", type=str, default=None, help="write per-kernel-class timings to this JSON file")
     args = ap.parse_args()
 
@@ -136,7 +137,7 @@ def main():
         step()
     ctx.sync()
     ctx.prof_reset()
-    ctx.prof_enable(True)
+    ctx.prof_enable(not args.no_prof)
     barrier()
     t_start = time.perf_counter()
     for _ in range(args.steps):

@@ -49,10 +49,7 @@ extern "C" void boa_destroy(boa_ctx* c) {
         hipEventDestroy(c->t0[i]);
         hipEventDestroy(c->t1[i]);
     }
-    for (auto& r : c->prof_pending) {
-        hipEventDestroy(r.e0);
-        hipEventDestroy(r.e1);
-    }
+    for (auto& r : c->prof_pending) hipEventDestroy(r.ev);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -99,12 +96,15 @@ extern "C" int boa_free(boa_ctx* c, void* dev) {
 
 extern "C" int boa_memset(boa_ctx* c, void* dev, int value, size_t bytes) {
     BOA_REQUIRE(c && dev, "boa_memset: NULL argument");
+    KernelTimer t(c, BOA_K_OTHER, 0, (double)bytes);  // accumulator zeroing is part of a volume's kernel time
     BOA_HIP_TRY(hipMemsetAsync(dev, value, bytes, c->stream));
+    t.stop();
     return BOA_OK;
 }
 
 extern "C" int boa_h2d(boa_ctx* c, void* dev_dst, const void* host_src, size_t bytes) {
     BOA_REQUIRE(c && dev_dst && host_src, "boa_h2d: NULL argument");
+    c->prof_break = true;
     BOA_HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
     BOA_HIP_TRY(hipStreamSynchronize(c->stream));
     return BOA_OK;
@@ -112,6 +112,7 @@ extern "C" int boa_h2d(boa_ctx* c, void* dev_dst, const void* host_src, size_t b
 
 extern "C" int boa_d2h(boa_ctx* c, void* host_dst, const void* dev_src, size_t bytes) {
     BOA_REQUIRE(c && host_dst && dev_src, "boa_d2h: NULL argument");
+    c->prof_break = true;
     BOA_HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
     BOA_HIP_TRY(hipStreamSynchronize(c->stream));
     return BOA_OK;
@@ -119,6 +120,7 @@ extern "C" int boa_d2h(boa_ctx* c, void* host_dst, const void* dev_src, size_t b
 
 extern "C" int boa_sync(boa_ctx* c) {
     BOA_REQUIRE(c, "ctx is NULL");
+    c->prof_break = true;
     BOA_HIP_TRY(hipStreamSynchronize(c->stream));
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
@@ -153,29 +155,36 @@ static hipEvent_t take_event(boa_ctx* c) {
 KernelTimer::KernelTimer(boa_ctx* c, int kclass, double flops, double bytes) : ctx(c), k(kclass) {
     if (!c->prof) return;
     if (c->prof_pending.size() >= 32768) boa_prof_flush(c);
-    e0 = take_event(c);
-    e1 = take_event(c);
+    on = true;
     c->prof_flops[k] += flops;
     c->prof_bytes[k] += bytes;
     c->prof_launches[k] += 1;
-    hipEventRecord(e0, c->stream);
+    if (c->prof_break || c->prof_pending.empty()) {
+        hipEvent_t e = take_event(c);
+        hipEventRecord(e, c->stream);
+        c->prof_pending.push_back({-1, e});
+        c->prof_break = false;
+    }
 }
 
 void KernelTimer::stop() {
-    if (!e0) return;
-    hipEventRecord(e1, ctx->stream);
-    ctx->prof_pending.push_back({k, e0, e1});
+    if (!on) return;
+    hipEvent_t e = take_event(ctx);
+    hipEventRecord(e, ctx->stream);
+    ctx->prof_pending.push_back({k, e});
 }
 
 int boa_prof_flush(boa_ctx* c) {
-    for (auto& r : c->prof_pending) {
+    if (!c->prof_pending.empty()) hipEventSynchronize(c->prof_pending.back().ev);
+    for (size_t i = 0; i < c->prof_pending.size(); ++i) {
+        const ProfRec& r = c->prof_pending[i];
         float ms = 0.f;
-        hipEventSynchronize(r.e1);
-        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) c->prof_ms[r.kclass] += ms;
-        c->ev_pool.push_back(r.e0);
-        c->ev_pool.push_back(r.e1);
+        if (r.kclass >= 0 && i > 0 && hipEventElapsedTime(&ms, c->prof_pending[i - 1].ev, r.ev) == hipSuccess)
+            c->prof_ms[r.kclass] += ms;
+        c->ev_pool.push_back(r.ev);
     }
     c->prof_pending.clear();
+    c->prof_break = true;
     return BOA_OK;
 }
 
