@@ -199,6 +199,9 @@ def test_conv_mfma_raw(ctx, N, Cin, dims, Cout, k, s):
 @pytest.mark.parametrize("N,Cin,dims,Cout,k,s", [
     (2, 32, (8, 16, 32), 32, (3, 3, 3), (1, 1, 1)),
     (1, 64, (12, 12, 24), 64, (3, 3, 3), (2, 2, 2)),
+    (2, 32, (16, 16, 32), 64, (3, 3, 3), (2, 2, 2)),      # cout-chunk-fastest tile order: halo reuse + two statistics sets
+    (3, 32, (64, 64, 32), 32, (3, 3, 3), (1, 1, 1)),      # persistent workgroups whose tile runs cross sample boundaries
+    (2, 32, (10, 12, 40), 32, (3, 3, 3), (1, 1, 1)),      # tiles sticking out of the tensor: masked statistics / stores
 ])
 def test_conv_block_norm_act(ctx, N, Cin, dims, Cout, k, s):
     """Conv -> InstanceNorm(affine) -> LeakyReLU with deferred normalisation vs torch-CPU fp32.  atol 6e-3 on
