@@ -209,13 +209,19 @@ __device__ __forceinline__ uint4 norm_act8_pk(uint4 raw, const unsigned* w /* 4 
     } s, t, sl;
     x.u = raw;
     sl.u = slope2;
+    // staged over the four channel pairs (all fmas, then all muls, then all maxes): a packed-fp16 result feeding the next
+    // packed op back to back costs an s_nop each time -- emitted pair by pair that was 2 nops per 3 useful instructions
+    h2_t y[4], z[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         s.u = w[2 * i];
         t.u = w[2 * i + 1];
-        const h2_t y = __builtin_elementwise_fma(x.v[i], s.v, t.v);
-        x.v[i] = __builtin_elementwise_max(y, y * sl.v);
+        y[i] = __builtin_elementwise_fma(x.v[i], s.v, t.v);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = y[i] * sl.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x.v[i] = __builtin_elementwise_max(y[i], z[i]);
     return x.u;
 }
 
