@@ -74,6 +74,8 @@ _PROTOS = {
     "boa_fill_holes_2d": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "boa_mask_assign": (i32, [vp, vp, u64, i32, i32, vp]),
     "boa_median3_inplane": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "boa_copy3": (i32, [vp, vp, i32, C.c_longlong, C.POINTER(C.c_longlong), ip, vp, i32, C.c_longlong, C.POINTER(C.c_longlong)]),
+    "boa_nonzero_bbox": (i32, [vp, vp, i32, ip, ip]),
     "boa_resample_cubic": (i32, [vp, vp, i32, ip, vp, i32, ip]),
     "boa_resample_nearest_u8": (i32, [vp, vp, ip, vp, ip]),
 }

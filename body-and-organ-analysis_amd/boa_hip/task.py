@@ -24,6 +24,7 @@ import numpy as np
 from . import label_maps, orientation
 from . import resample as rs
 from ._lib import check
+from .devarray import DevArray
 from .device import Context
 from .plans import ModelConfig
 from .predictor import HipPredictor
@@ -127,90 +128,152 @@ class SegmentationTask:
                     f"{self.task_name}: image spacing (z,y,x) {sp_zyx} differs from the plans' spacing {list(cfg.spacing)}; "
                     "nnU-Net's internal resampling (default_preprocessor.py:82-96) is not implemented on the device")
 
-    def predict_part_xyz(self, data_xyz: np.ndarray) -> np.ndarray:
-        """One (sub-)volume as TS writes it to s0k_0000.nii.gz: (x,y,z) int16/int32/float -> uint8 labels (x,y,z)."""
-        data = np.ascontiguousarray(data_xyz.transpose(2, 1, 0))   # nibabel reader: (z,y,x), float32 view of the values
-        if data.dtype == np.int16:
-            code = 0
-        elif data.dtype == np.int32:
-            code = 2
-        else:
-            data, code = data.astype(np.float32), 1
-        bbox = nonzero_bbox(data)
-        sl = tuple(slice(a, b) for a, b in bbox)
-        crop = np.ascontiguousarray(data[sl])
-        d_ct = self.ctx.from_numpy(crop)
-        d_lab = self.ctx.alloc(max(crop.size, 1))
+    # ---- one (sub-)volume, device resident ----------------------------------------------------------------------
+    def _predict_part_device(self, part_xyz: DevArray, dst_xyz: DevArray, src_lo: int, src_hi: int):
+        """`part_xyz`: (x,y,z) view of the (resampled) CT that TS would write to s0k_0000.nii.gz.  Its labels for the
+        part-local z range [src_lo, src_hi) are written into `dst_xyz` (a zero-initialised (x,y,z) view of the same
+        x/y extent and src_hi - src_lo slices).  nibabel reader view change, crop_to_nonzero and insert_crop_into_image
+        (export_prediction.py:44-47) are views + one device copy each way."""
+        dt = part_xyz.dtype
+        want = dt if dt in (np.dtype(np.int16), np.dtype(np.int32)) else np.dtype(np.float32)
+        code = {np.dtype(np.int16): 0, np.dtype(np.float32): 1, np.dtype(np.int32): 2}[want]
+        zyx = part_xyz.transpose((2, 1, 0)).contiguous(want, force_copy=False)
+        bbox = zyx.nonzero_bbox()
+        full = all(b == [0, n] for b, n in zip(bbox, zyx.shape))
+        crop = zyx if full else zyx.box(bbox).contiguous()
+        d_lab = DevArray.empty(self.ctx, crop.shape, np.uint8)
         try:
-            self.predict_zyx_device(d_ct, crop.shape, d_lab, in_dtype=code)
-            seg_crop = d_lab.download(crop.shape, np.uint8)
+            self.predict_zyx_device(crop.buf, crop.shape, d_lab.buf, in_dtype=code)
+            k0, k1 = max(bbox[0][0], src_lo), min(bbox[0][1], src_hi)
+            if k0 < k1:
+                src = d_lab.slice(0, k0 - bbox[0][0], k1 - bbox[0][0]).transpose((2, 1, 0))
+                dst = dst_xyz.slice(2, k0 - src_lo, k1 - src_lo).slice(1, bbox[1][0], bbox[1][1]).slice(0, bbox[2][0], bbox[2][1])
+                src.copy_to(dst)
         finally:
-            d_ct.free()
             d_lab.free()
-        seg = np.zeros(data.shape, dtype=np.uint8)                  # insert_crop_into_image, export_prediction.py:44-47
-        seg[sl] = seg_crop
-        return seg.transpose(2, 1, 0)
+            if crop is not zyx:
+                crop.free()
+            if zyx.buf is not part_xyz.buf:
+                zyx.free()
+
+    def predict_part_xyz(self, data_xyz: np.ndarray) -> np.ndarray:
+        """One (sub-)volume as TS writes it to s0k_0000.nii.gz: (x,y,z) array -> uint8 labels (x,y,z)."""
+        src = DevArray.from_numpy(self.ctx, self._supported(data_xyz))
+        seg = DevArray.zeros(self.ctx, src.shape, np.uint8)
+        try:
+            self._predict_part_device(src, seg, 0, src.shape[2])
+            return seg.download()
+        finally:
+            src.free()
+            seg.free()
+
+    @staticmethod
+    def _supported(data: np.ndarray) -> np.ndarray:
+        data = np.ascontiguousarray(data)
+        if data.dtype in (np.uint8, np.int16, np.int32, np.float32, np.float64):
+            return data
+        return data.astype(np.float64)   # what get_fdata() hands to the reference
 
     # ---- nnUNet_predict_image ------------------------------------------------------------------------------
     def predict_image(self, data: np.ndarray, affine: np.ndarray, force_split: bool = False,
                       crop_mask: Optional[np.ndarray] = None, crop_addon=(3, 3, 3), axcodes: str = "RAS") -> np.ndarray:
-        """CT array in file axis order + its affine -> uint8 label array on the same grid."""
+        """CT array in file axis order + its affine -> uint8 label array on the same grid.  The volume is uploaded
+        once; reorientation, crops, splits and restores are device views / copies, resampling and inference run on the
+        device, only the final label volume comes back."""
         if data.ndim == 2:
             raise ValueError("TotalSegmentator does not work for 2D images. Use a 3D image.")
         if data.ndim > 3:
             data = data[:, :, :, 0]
         if data.dtype.fields is not None:
             raise TypeError(f"Invalid dtype {data.dtype}. Expected a simple dtype, not a structured one.")
-        orig_shape = data.shape
+        ctx = self.ctx
+        orig_shape = tuple(int(v) for v in data.shape)
         affine = np.asarray(affine, dtype=np.float64)
-        img, aff = data, affine
+        aff = affine
         bbox = None
-        if crop_mask is not None:
-            if crop_mask.sum() == 0:                                 # TS/nnunet.py:428-446
-                return np.zeros(orig_shape, dtype=np.uint8)
-            addon = (np.array(crop_addon) / orientation.zooms_from_affine(aff)).astype(int)   # mm -> voxels
-            bbox = get_bbox_from_mask(crop_mask, outside_value=0, addon=addon)
-            img = img[tuple(slice(a, b) for a, b in bbox)]
-            aff = aff.copy()
-            aff[:3, 3] = np.dot(affine, np.array([bbox[0][0], bbox[1][0], bbox[2][0], 1]))[:3]
-            img = img.astype(np.int32)                                # crop_to_mask(dtype=np.int32)
-        cropped_affine = aff
-        img, aff, _ = orientation.as_closest_canonical(img, aff)
-        resample = None if self.resample is None else [self.resample] * 3
-        if self.resample_only_thickness:
-            img, aff = orientation.with_axcodes(img, aff, axcodes)
+        if crop_mask is not None and crop_mask.sum() == 0:              # TS/nnunet.py:428-446
+            return np.zeros(orig_shape, dtype=np.uint8)
+        owned = []                                                     # device arrays to release
+
+        def own(a):
+            owned.append(a)
+            return a
+        try:
+            view = own(DevArray.from_numpy(ctx, self._supported(data)))
+            cast = None
+            if crop_mask is not None:
+                addon = (np.array(crop_addon) / orientation.zooms_from_affine(aff)).astype(int)   # mm -> voxels
+                bbox = get_bbox_from_mask(crop_mask, outside_value=0, addon=addon)
+                view = view.box(bbox)
+                aff = aff.copy()
+                aff[:3, 3] = np.dot(affine, np.array([bbox[0][0], bbox[1][0], bbox[2][0], 1]))[:3]
+                cast = np.int32                                          # crop_to_mask(dtype=np.int32)
+            cropped_affine = aff
+            ornt = orientation.io_orientation(aff)                       # as_closest_canonical
+            if not np.array_equal(ornt, orientation.RAS_ORNT):
+                aff = aff.dot(orientation.inv_ornt_aff(ornt, view.shape))
+                view = view.apply_orientation(ornt)
+            resample = None if self.resample is None else [self.resample] * 3
+            thick_ornt = None
+            if self.resample_only_thickness:
+                cur = "".join(orientation.aff2axcodes(aff))
+                if cur != "".join(axcodes):
+                    thick_ornt = orientation.ornt_transform(orientation.axcodes2ornt(cur), orientation.axcodes2ornt(axcodes))
+                    aff = aff.dot(orientation.inv_ornt_aff(thick_ornt, view.shape))
+                    view = view.apply_orientation(thick_ornt)
+                zooms = orientation.zooms_from_affine(aff)
+                resample = [zooms[0], zooms[1], resample[0]]
+            in_shape = view.shape
             zooms = orientation.zooms_from_affine(aff)
-            resample = [zooms[0], zooms[1], resample[0]]
-        in_shape = img.shape
-        zooms = orientation.zooms_from_affine(aff)
-        if resample is not None:
-            img_rsp, zoom = rs.change_spacing_array(self.ctx, np.ascontiguousarray(img), zooms, resample, order=3,
-                                                    dtype=np.int32)
-            sp_rsp = zooms if zoom is None else np.array(resample, dtype=np.float64)
-        else:
-            img_rsp, zoom, sp_rsp = img, None, zooms
-        self._check_plan_spacing(sp_rsp)
-        ss = img_rsp.shape
-        do_split = (np.prod(ss) > NR_VOXELS_THR and ss[2] > 200 and self.multimodel) or force_split
-        if do_split:
-            parts, comb = split_bounds(ss[2])
-            seg = np.zeros(ss, dtype=np.uint8)
-            for (lo, hi), (dst, src) in zip(parts, comb):
-                seg[:, :, dst] = self.predict_part_xyz(img_rsp[:, :, lo:hi])[:, :, src]
-        else:
-            seg = self.predict_part_xyz(img_rsp)
-        if resample is not None and zoom is not None:
-            seg, _ = rs.change_spacing_array(self.ctx, np.ascontiguousarray(seg), sp_rsp.astype(np.float32), resample,
-                                             target_shape=in_shape, order=0, dtype=np.uint8)
-        if self.resample_only_thickness:
-            # the labels are in `axcodes` order; TS hands them to undo_canonical as they are (RAS is the default, a no-op)
-            seg = orientation.apply_orientation(
-                seg, orientation.ornt_transform(orientation.axcodes2ornt(axcodes), orientation.RAS_ORNT))
-        seg = orientation.undo_canonical(seg, cropped_affine)
-        if bbox is not None:                                         # undo_crop, TS/cropping.py:126-132
-            full = np.zeros(orig_shape, dtype=np.uint8)
-            full[tuple(slice(a, b) for a, b in bbox)] = seg
-            seg = full
-        if seg.shape != tuple(orig_shape[:3]):
-            raise ValueError(f"shape mismatch after restore: {seg.shape} vs {orig_shape}")   # check_if_shape_and_affine_identical
-        return np.ascontiguousarray(seg, dtype=np.uint8)
+            zoom = None
+            if resample is not None:                                     # change_spacing (TS/resampling.py:165-181)
+                new_spacing = np.array(resample)
+                zoom = zooms / new_spacing
+                if np.array_equal(zooms, new_spacing):
+                    zoom = None
+            if zoom is not None:
+                src = view.contiguous(cast)
+                if src.buf is not view.buf:
+                    own(src)
+                if src.dtype == np.uint8:
+                    src = own(src.contiguous(np.int16, force_copy=True))
+                out_shape = rs.zoomed_shape(in_shape, zoom)
+                buf = rs.resample_cubic_device(ctx, src.buf, src.dtype, src.shape, out_shape, np.int32)
+                img_rsp = own(DevArray(ctx, buf, out_shape, np.int32))
+                sp_rsp = np.array(resample, dtype=np.float64)
+            else:
+                img_rsp = view if cast is None else own(view.contiguous(cast))
+                sp_rsp = zooms
+            self._check_plan_spacing(sp_rsp)
+            ss = img_rsp.shape
+            seg = own(DevArray.zeros(ctx, ss, np.uint8))
+            do_split = (np.prod(ss) > NR_VOXELS_THR and ss[2] > 200 and self.multimodel) or force_split
+            if do_split:
+                parts, comb = split_bounds(ss[2])
+                for (lo, hi), (dst, srcsl) in zip(parts, comb):
+                    a, b, _ = srcsl.indices(hi - lo)
+                    self._predict_part_device(img_rsp.slice(2, lo, hi), seg.slice(2, dst.start, dst.stop), a, b)
+            else:
+                self._predict_part_device(img_rsp, seg, 0, ss[2])
+            if zoom is not None:                                         # back to the input grid (TS/nnunet.py:685-687)
+                if tuple(in_shape) != tuple(ss):
+                    buf = rs.resample_nearest_device(ctx, seg.buf, ss, in_shape)
+                    seg = own(DevArray(ctx, buf, in_shape, np.uint8))
+            out = seg
+            if thick_ornt is not None:
+                # the labels are in `axcodes` order; back to RAS before undo_canonical
+                out = out.apply_orientation(orientation.ornt_transform(orientation.axcodes2ornt(axcodes), orientation.RAS_ORNT))
+            out = out.apply_orientation(orientation.ornt_transform(orientation.RAS_ORNT, orientation.io_orientation(cropped_affine)))
+            if bbox is not None:                                         # undo_crop, TS/cropping.py:126-132
+                full = own(DevArray.zeros(ctx, orig_shape, np.uint8))
+                out.copy_to(full.box(bbox))
+                out = full
+            if tuple(out.shape) != orig_shape[:3]:
+                raise ValueError(f"shape mismatch after restore: {out.shape} vs {orig_shape}")   # check_if_shape_and_affine_identical
+            return out.download()
+        finally:
+            seen = set()
+            for a in owned:
+                if id(a.buf) not in seen:
+                    seen.add(id(a.buf))
+                    a.free()

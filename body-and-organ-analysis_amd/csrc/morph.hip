@@ -161,3 +161,122 @@ extern "C" int boa_mask_assign(boa_ctx* c, const uint8_t* dev_mask, size_t n, in
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// boa_copy3: strided 3-D gather copy with dtype conversion -- the device form of the index remaps around a task
+// (TS/alignment.py reorientation = axis permutation + flips, TS/cropping.py crop / un-crop, the (x,y,z) <-> (z,y,x)
+// view change between nibabel and nnU-Net arrays, the z-splits of TS/nnunet.py:495-505 and their recombination).
+//   out[(o + out_off) in out_full] = convert(in[in_off + sum_k o_k * in_step[k]])     for o in [0, dims)
+// in_step[k] (elements, may be negative) is the input stride walked by output axis k; in_off the element offset of o = 0.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_copy3(const TI* __restrict__ in, long long in_off, long long s0, long long s1, long long s2,
+                                               int d0, int d1, int d2, TO* __restrict__ out, long long out_off, long long t0,
+                                               long long t1, long long t2) {
+    const size_t n = (size_t)d0 * d1 * d2;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int o2 = (int)(i % d2), o1 = (int)((i / d2) % d1), o0 = (int)(i / ((size_t)d2 * d1));
+    const TI v = in[in_off + o0 * s0 + o1 * s1 + o2 * s2];
+    out[out_off + o0 * t0 + o1 * t1 + o2 * t2] = (TO)v;  // float -> int conversions truncate like numpy astype
+}
+
+template <typename TI>
+static int copy3_out(boa_ctx* c, const void* in, long long in_off, const long long s[3], const int d[3], void* out, int out_dtype,
+                     long long out_off, const long long t[3]) {
+    const size_t n = (size_t)d[0] * d[1] * d[2];
+    const unsigned grid = (unsigned)((n + 255) / 256);
+#define LAUNCH(TO) hipLaunchKernelGGL((k_copy3<TI, TO>), dim3(grid), dim3(256), 0, c->stream, (const TI*)in, in_off, s[0], s[1], s[2], \
+                                      d[0], d[1], d[2], (TO*)out, out_off, t[0], t[1], t[2])
+    switch (out_dtype) {
+        case 0: LAUNCH(uint8_t); break;
+        case 1: LAUNCH(int16_t); break;
+        case 2: LAUNCH(int32_t); break;
+        case 3: LAUNCH(float); break;
+        case 4: LAUNCH(double); break;
+        default: boa_set_error("boa_copy3: out dtype %d", out_dtype); return BOA_EINVAL;
+    }
+#undef LAUNCH
+    return BOA_OK;
+}
+
+// dtype codes: 0 uint8, 1 int16, 2 int32, 3 float32, 4 float64
+extern "C" int boa_copy3(boa_ctx* c, const void* dev_in, int in_dtype, long long in_off, const long long in_step[3],
+                         const int dims[3], void* dev_out, int out_dtype, long long out_off, const long long out_step[3]) {
+    BOA_REQUIRE(c && dev_in && dev_out && in_step && dims && out_step, "boa_copy3: NULL argument");
+    BOA_REQUIRE(dims[0] >= 0 && dims[1] >= 0 && dims[2] >= 0, "boa_copy3: negative dims");
+    if ((size_t)dims[0] * dims[1] * dims[2] == 0) return BOA_OK;
+    KernelTimer t(c, BOA_K_OTHER, 0, 0);
+    int rc;
+    switch (in_dtype) {
+        case 0: rc = copy3_out<uint8_t>(c, dev_in, in_off, in_step, dims, dev_out, out_dtype, out_off, out_step); break;
+        case 1: rc = copy3_out<int16_t>(c, dev_in, in_off, in_step, dims, dev_out, out_dtype, out_off, out_step); break;
+        case 2: rc = copy3_out<int32_t>(c, dev_in, in_off, in_step, dims, dev_out, out_dtype, out_off, out_step); break;
+        case 3: rc = copy3_out<float>(c, dev_in, in_off, in_step, dims, dev_out, out_dtype, out_off, out_step); break;
+        case 4: rc = copy3_out<double>(c, dev_in, in_off, in_step, dims, dev_out, out_dtype, out_off, out_step); break;
+        default: boa_set_error("boa_copy3: in dtype %d", in_dtype); rc = BOA_EINVAL;
+    }
+    t.stop();
+    if (rc) return rc;
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+// bounding box of `data != 0` (crop_to_nonzero, NN/preprocessing/cropping/cropping.py:6-29): per axis [min, max + 1),
+// or [0, dim) when everything is zero.  host_bbox: int[6] = {lo0, hi0, lo1, hi1, lo2, hi2}.  Synchronous.
+template <typename T>
+__global__ __launch_bounds__(256) void k_nonzero_bbox(const T* __restrict__ in, int d0, int d1, int d2, int* __restrict__ bb) {
+    const size_t n = (size_t)d0 * d1 * d2;
+    int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (in[i] != (T)0) {
+            const int o2 = (int)(i % d2), o1 = (int)((i / d2) % d1), o0 = (int)(i / ((size_t)d2 * d1));
+            lo[0] = min(lo[0], o0); hi[0] = max(hi[0], o0);
+            lo[1] = min(lo[1], o1); hi[1] = max(hi[1], o1);
+            lo[2] = min(lo[2], o2); hi[2] = max(hi[2], o2);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            lo[a] = min(lo[a], __shfl_xor(lo[a], m));
+            hi[a] = max(hi[a], __shfl_xor(hi[a], m));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (hi[a] >= 0) {
+                atomicMin(&bb[2 * a], lo[a]);
+                atomicMax(&bb[2 * a + 1], hi[a]);
+            }
+        }
+    }
+}
+
+extern "C" int boa_nonzero_bbox(boa_ctx* c, const void* dev_in, int dtype, const int dims[3], int host_bbox[6]) {
+    BOA_REQUIRE(c && dev_in && dims && host_bbox, "boa_nonzero_bbox: NULL argument");
+    int* d_bb = nullptr;
+    BOA_HIP_TRY(hipMalloc(&d_bb, 6 * sizeof(int)));
+    const int init[6] = {1 << 30, -1, 1 << 30, -1, 1 << 30, -1};
+    BOA_HIP_TRY(hipMemcpyAsync(d_bb, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    const size_t n = (size_t)dims[0] * dims[1] * dims[2];
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 16);
+    c->prof_break = true;
+    if (n) {
+        switch (dtype) {
+            case 1: hipLaunchKernelGGL(k_nonzero_bbox<int16_t>, dim3(grid), dim3(256), 0, c->stream, (const int16_t*)dev_in, dims[0], dims[1], dims[2], d_bb); break;
+            case 2: hipLaunchKernelGGL(k_nonzero_bbox<int32_t>, dim3(grid), dim3(256), 0, c->stream, (const int32_t*)dev_in, dims[0], dims[1], dims[2], d_bb); break;
+            case 3: hipLaunchKernelGGL(k_nonzero_bbox<float>, dim3(grid), dim3(256), 0, c->stream, (const float*)dev_in, dims[0], dims[1], dims[2], d_bb); break;
+            default: hipFree(d_bb); boa_set_error("boa_nonzero_bbox: dtype %d (1 int16, 2 int32, 3 float32)", dtype); return BOA_EINVAL;
+        }
+    }
+    int bb[6];
+    hipError_t e = hipMemcpyAsync(bb, d_bb, sizeof(bb), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_bb);
+    BOA_HIP_TRY(e);
+    for (int a = 0; a < 3; ++a) {
+        const bool any = bb[2 * a + 1] >= 0;
+        host_bbox[2 * a] = any ? bb[2 * a] : 0;
+        host_bbox[2 * a + 1] = any ? bb[2 * a + 1] + 1 : dims[a];
+    }
+    return BOA_OK;
+}

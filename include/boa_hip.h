@@ -239,6 +239,21 @@ int boa_mask_assign(boa_ctx* ctx, const uint8_t* dev_mask, size_t n, int invert,
  * with size 3 on two axes and 1 on `flat_axis` (0 = z, 1 = y, 2 = x of the [Z][Y][X] array), mode="reflect". */
 int boa_median3_inplane(boa_ctx* ctx, const int16_t* dev_in, int Z, int Y, int X, int flat_axis, int16_t* dev_out);
 
+/* ------------------------------------------------------------------ index remaps around a task ------- */
+/* Strided 3-D gather copy with dtype conversion: the device form of as_closest_canonical / undo_canonical
+ * (TS/alignment.py:8-46: axis permutation + flips), crop_to_bbox / undo_crop (TS/cropping.py:41-49,126-132), the
+ * (x,y,z) <-> (z,y,x) view change between nibabel and nnU-Net arrays (NN/imageio/nibabel_reader_writer.py:51-56),
+ * crop_to_nonzero / insert_crop_into_image, and the z-splits of TS/nnunet.py:495-505,583-586.
+ *   out[out_off + sum_k o_k * out_step[k]] = (out type) in[in_off + sum_k o_k * in_step[k]]   for o in [0, dims)
+ * Offsets / steps are in elements (steps may be negative).  dtype codes: 0 uint8, 1 int16, 2 int32, 3 float32,
+ * 4 float64; float -> integer conversion truncates (numpy astype). */
+int boa_copy3(boa_ctx* ctx, const void* dev_in, int in_dtype, long long in_off, const long long in_step[3],
+              const int dims[3], void* dev_out, int out_dtype, long long out_off, const long long out_step[3]);
+/* Bounding box of data != 0 (crop_to_nonzero, NN/preprocessing/cropping/cropping.py:6-29; binary_fill_holes cannot
+ * change it): host_bbox = {lo0, hi0, lo1, hi1, lo2, hi2} with hi exclusive; [0, dim) when all zero.
+ * dtype: 1 int16, 2 int32, 3 float32.  Synchronous. */
+int boa_nonzero_bbox(boa_ctx* ctx, const void* dev_in, int dtype, const int dims[3], int host_bbox[6]);
+
 /* ------------------------------------------------------------------ resampling (TS/resampling.py) --- */
 /* change_spacing / resample_img order 3 (TS/resampling.py:24-56,129-222): scipy.ndimage.zoom(data, zoom, order=3,
  * mode="nearest") restated in fp64 (edge pad 12, cubic B-spline prefilter with 'reflect' initialisation, 64-tap

@@ -160,3 +160,40 @@ def test_bca_pipeline_vs_oracle_composition(ctx):
     assert out["vertebrae"] == vert
     ref = obca.bca_measurements_json(ct_l, rg, pt, tis, sp, vert or None)
     _cmp(json.loads(json.dumps(out["bca_measurements"], default=float)), json.loads(json.dumps(ref, default=float)), 1e-9)
+
+
+def test_crop_mask_and_permuted_axes(ctx):
+    """crop-to-mask (TS/cropping.py:75-110) + a file whose axes are a permutation of RAS with flips: the device views must
+    land every label on the voxel the host-side numpy remaps put it."""
+    from boa_hip import orientation as o
+    from boa_hip.task import SegmentationTask, get_bbox_from_mask
+    from oracle import pipeline as opipe
+    ct_ras = _ct((44, 40, 48), 7)
+    sp = (1.5, 1.5, 1.5)
+    m, om = _model(901, 4, 901, (1.5, 1.5, 1.5))
+    # file axes = (P, I, R): array[j, k, i] = ras[i, -j, -k]
+    aff = np.array([[0, 0, 1.5, -10.0], [-1.5, 0, 0, 50.0], [0, -1.5, 0, 70.0], [0, 0, 0, 1.0]])
+    ornt = o.io_orientation(aff)
+    ct_file = np.ascontiguousarray(o.apply_orientation(ct_ras, o.ornt_transform(o.RAS_ORNT, ornt)))
+    assert o.aff2axcodes(aff) == ("P", "I", "R")
+    np.testing.assert_array_equal(o.apply_orientation(ct_file, ornt), ct_ras)
+    mask = np.zeros(ct_file.shape, np.uint8)
+    mask[6:30, 5:38, 10:36] = 1
+    t = SegmentationTask(ctx, "other", [m], resample=1.5, max_batch=4)
+    got = t.predict_image(ct_file, aff, crop_mask=mask, crop_addon=(3, 3, 3))
+    t.close()
+    # oracle composition with host numpy remaps
+    bbox = get_bbox_from_mask(mask, 0, (np.array([3, 3, 3]) / o.zooms_from_affine(aff)).astype(int))
+    sl = tuple(slice(a, b) for a, b in bbox)
+    crop = ct_file[sl].astype(np.int32)
+    crop_ras = np.ascontiguousarray(o.apply_orientation(crop, ornt))
+    want_ras = opipe.predict_image(crop_ras, sp, [om + (None,)], None, "other", 1.5, multimodel=False)
+    want = np.zeros(ct_file.shape, np.uint8)
+    want[sl] = o.apply_orientation(want_ras, o.ornt_transform(o.RAS_ORNT, ornt))
+    assert got.shape == ct_file.shape
+    outside = np.ones(ct_file.shape, bool)
+    outside[sl] = False
+    assert (got[outside] == 0).all() and bbox[0] == [4, 32]
+    agree = float((got == want).mean())
+    print("crop + permuted axes agreement", agree)
+    assert agree >= 0.97
