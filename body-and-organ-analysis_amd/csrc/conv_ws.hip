@@ -1,21 +1,27 @@
 // k_conv_ws: wave-specialised, persistent implicit-GEMM conv for gfx950.
 //
-// One 512-thread workgroup per CU: waves 0-3 ("consumers") issue nothing but LDS fragment reads and
-// v_mfma_f32_32x32x16_f16; waves 4-7 ("producers") gather the next 16-channel chunk of the input halo tile from
-// HBM/L2, apply the producer layer's deferred InstanceNorm + LeakyReLU and write it (plus, when they do not fit
-// resident, the chunk's weights) into the other LDS buffer.  MFMA and VALU/VMEM are separate pipes of a SIMD, so
-// the two roles overlap; one __syncthreads() per chunk hands buffers over.  Workgroups are persistent and walk
-// consecutive output tiles, so the staging of a tile's first chunk hides under the previous tile's last chunk and
-// the chip-wide working set at any time is a contiguous run of tiles (halo reuse in L2).
+// One 512-thread workgroup per CU with two roles that run SEPARATE loops and meet at one __syncthreads() per
+// 16-channel chunk:
+//   waves 0-3 ("consumers") read A (weights) / B (input voxels) fragments from LDS and issue v_mfma_f32_32x32x16_f16
+//     (compile-time taps, fully unrolled, fragments of tap t+1 in flight while tap t's MFMAs issue); after a tile's
+//     last chunk they add the bias, accumulate the InstanceNorm partial sums in registers, transpose the D fragment
+//     into voxel records with v_permlane32_swap and store 2 x 16 bytes per lane;
+//   waves 4-7 ("producers") gather the next chunk of the input halo tile from HBM/L2 (loads issued one barrier interval
+//     ahead: prod_issue / prod_commit), apply the producer layer's deferred InstanceNorm + LeakyReLU in packed fp16 and
+//     write it (plus, when they do not fit resident, the chunk's weights) into the other LDS buffer.
+// Workgroups are persistent and walk a contiguous run of output tiles (x fastest; cout chunk fastest for the
+// 2-chunk / 2-cout-chunk case, where the staged halo is reused), so the staging of a tile's first chunk hides under
+// the previous tile's last chunk and the chip-wide working set is a contiguous run of tiles (halo reuse in L2).
+// Per-tile bookkeeping is division free (relative offsets precomputed per kernel, incremental tile walk, wave-uniform
+// fast path for tiles whose halo / output lies inside the tensor).
 //
-// Consumer inner loop: the taps are compile-time (template K0,K1,K2), fully unrolled, with the A/B fragments of
-// tap t+1 read into a second register set while the MFMAs of tap t issue (hipcc otherwise emits
-// ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per fragment: ~200 cycles per MFMA instead of 32).
-// Producer: per-tile voxel offsets live in registers; per chunk every global load is issued before the first
-// is consumed.
-//
-// Same arithmetic as k_conv_mfma (conv.hip); statistics partials are written per consumer wave
-// (partials[n][cout][2][tiles * 4]) so that no cross-wave reduction (and no extra barrier) is needed.
+// Same arithmetic as k_conv_mfma (conv.hip).  Statistics: partials[n][cout][2][nslots], one slot per (workgroup,
+// consumer wave), written once per (sample, cout chunk) a wave works on; the table is zero elsewhere (zeroed at
+// allocation, re-zeroed by k_norm_finalize).
+// Debug: `dbg` bits (BOA_WS_DBG) skip stages for ablation -- 1 MFMA loop, 2 producers, 4 output stores, 8 epilogue,
+// 16 weight staging, 32 halo commit, 64 transform, 256/512 producer priority; results are then wrong by design.
+// BOA_WS_TRACE=1 records s_memtime stamps of block 0 (consumer wave 0: 4 chunk start, 5 MFMA loop done, 6 epilogue done;
+// producer wave 4: 1 barrier passed, 7 loads landed, 2 committed, 8 tile set up, 3 next loads issued).
 #include <stdlib.h>
 
 #include "conv.h"
