@@ -1,9 +1,10 @@
 """File-level mirror of BOA/compute/inference.py: `compute_all_models` (:50-144) with the reference's signature,
 outputs and folder contract, on the device engine.
 
-Supported models: `total`, `bca`, `body_parts`, `body_regions` (the hot path of BASELINE.json's configs 1-4).  The
-crop-cascade models of `--models all` (lung_vessels, cerebral_bleed, ...) raise NotImplementedError
--- they are not silently skipped.  Weights come from `$nnUNet_results` (boa_hip/model_store.py); nothing is downloaded.
+Supported models: `total`, `bca`, `body_parts`, `body_regions` and the crop-cascade models of `--models all`
+(lung_vessels, cerebral_bleed, hip_implant, pleural_pericard_effusion, liver_vessels: rough 6 mm `total` -> crop ->
+native-resolution model, TS/python_api.py:670-757).  The licensed `heartchambers_highres` raises NotImplementedError --
+nothing is silently skipped.  Weights come from `$nnUNet_results` (boa_hip/model_store.py); nothing is downloaded.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ import numpy as np
 from .. import label_maps, model_store, nifti, orientation
 from ..device import Context
 from ..pipeline import BcaPipelineHip
-from ..task import SegmentationTask
+from ..task import SegmentationTask, run_cascade_task
 from .config import resolve_device
 from .constants import BASE_MODELS
 from .measurements import compute_measurements
@@ -92,9 +93,9 @@ def compute_all_models(
         "num_slices": int(shape[2]),
         "num_slices_resampled": convert_resampling_slices(slices=shape[-1], current_sampling=spacing[-1], target_resampling=1.5),
     }
-    unsupported = [m for m in measurement_models if m != "total"]
+    unsupported = [m for m in measurement_models if m != "total" and m not in model_store.CASCADE_MODELS]
     if unsupported:
-        raise NotImplementedError(f"models {unsupported} (crop-cascade tasks of `--models all`) are not implemented on the device yet")
+        raise NotImplementedError(f"models {unsupported} are not implemented on the device")
     segmentation_folder.mkdir(parents=True, exist_ok=True)
     ctx = get_context(totalsegmentator_params.get("device"))
     data, affine, hdr = nifti.load(ct_path)
@@ -107,15 +108,24 @@ def compute_all_models(
             logger.info("The model was already computed, skipping...")
             continue
         fast = bool(totalsegmentator_params.get("fast", False))
-        key = "total_fast" if fast else "total"
-        info = model_store.TASKS[key]
-        task = SegmentationTask(ctx, "total", model_store.load_task_models(key), resample=info["resample"],
-                                multimodel=not fast)
-        try:
-            seg = task.predict_image(ct, affine)
-        finally:
-            task.close()
-        nifti.save(seg_file, seg, affine, like=hdr, extensions=[(0, nifti.label_xml(label_maps.CLASS_MAP_TOTAL))])
+        if chosen_task == "total":
+            key = "total_fast" if fast else "total"
+            info = model_store.TASKS[key]
+            task = SegmentationTask(ctx, "total", model_store.load_task_models(key), resample=info["resample"],
+                                    multimodel=not fast)
+            try:
+                seg = task.predict_image(ct, affine)
+            finally:
+                task.close()
+            names = label_maps.CLASS_MAP_TOTAL
+        else:
+            if fast:
+                raise ValueError(f"task {chosen_task} does not work with option --fast")   # TS/python_api.py:242 ff.
+            info = model_store.TASKS[chosen_task]
+            seg = run_cascade_task(ctx, chosen_task, ct, affine, model_store.load_task_models("total_6mm"),
+                                   model_store.load_task_models(chosen_task), info["crop"], info["crop_addon"])
+            names = label_maps.class_map(chosen_task)
+        nifti.save(seg_file, seg, affine, like=hdr, extensions=[(0, nifti.label_xml(names))])
 
     measurement_file = segmentation_folder / "total-measurements.json"
     if measurement_models and (recompute or not measurement_file.is_file()):

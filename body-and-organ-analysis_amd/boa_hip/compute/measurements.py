@@ -31,22 +31,29 @@ def compute_measurements(ct_path: pathlib.Path, segmentation_folder: pathlib.Pat
     spacing = tuple(float(v) for v in hdr.get_zooms())
     am = asd = None
     for model_name in sorted(models, key=lambda m: m != "total"):
-        model_path = segmentation_folder / f"{model_name}.nii.gz"
+        # (the reference looks for ADDITIONAL_MODELS_OUTPUT_NAME[model] while inference writes <model>.nii.gz, so e.g.
+        #  lung_vessels -> lung_vessels_airways.nii.gz is never found and silently skipped: kept as is, :263-270)
+        model_path = segmentation_folder / f"{'total' if model_name == 'total' else label_maps.output_name(model_name)}.nii.gz"
         if not model_path.exists():
             continue
-        if model_name != "total":
-            raise NotImplementedError(f"measurements for model {model_name!r} are not implemented on the device yet")
         seg, saff, shdr = nifti.load(model_path)
         if not np.isclose(spacing, tuple(float(v) for v in shdr.get_zooms())).all():
             raise ValueError("The spacing of the image and of the segmentation should be the same")
-        label_map = {name: k for k, name in label_maps.CLASS_MAP_TOTAL.items()}
-        meas, fat_mask = M.total_measurements(ctx, ct.astype(np.int16), np.ascontiguousarray(seg.transpose(2, 1, 0)),
-                                              label_map, spacing, cnr_adjustment=cnr_adjustment)
-        measurements["segmentations"].update(meas["segmentations"])
-        if "cnr_adjusted" in meas:
-            measurements["cnr_adjusted"] = meas["cnr_adjusted"]
-        am, asd = meas["info"].get("autochthon_mean"), meas["info"].get("autochthon_std")
-        nifti.save(segmentation_folder / "ct_pfav.nii.gz", np.ascontiguousarray(fat_mask.transpose(2, 1, 0)), saff, like=shdr)
+        label_map = label_maps.measurement_label_map(model_name)
+        seg_zyx = np.ascontiguousarray(seg.transpose(2, 1, 0))
+        if model_name == "total":
+            meas, fat_mask = M.total_measurements(ctx, ct.astype(np.int16), seg_zyx, label_map, spacing,
+                                                  cnr_adjustment=cnr_adjustment)
+            measurements["segmentations"].update(meas["segmentations"])
+            if "cnr_adjusted" in meas:
+                measurements["cnr_adjusted"] = meas["cnr_adjusted"]
+            am, asd = meas["info"].get("autochthon_mean"), meas["info"].get("autochthon_std")
+            nifti.save(segmentation_folder / "ct_pfav.nii.gz", np.ascontiguousarray(fat_mask.transpose(2, 1, 0)), saff, like=shdr)
+        else:
+            if cnr_adjustment and model_name in label_maps.cnr_adjusted_regions():
+                raise NotImplementedError(f"CNR-adjusted measurements for {model_name!r} are not implemented on the device")
+            measurements["segmentations"][model_name] = M.metrics_for_each_region(
+                ctx, ct.astype(np.int16), seg_zyx, label_map, am, asd, spacing)
     measurements["info"]["autochthon_mean"] = am
     measurements["info"]["autochthon_std"] = asd
     return measurements

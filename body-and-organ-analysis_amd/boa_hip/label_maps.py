@@ -73,3 +73,38 @@ def part_lut(task_id: int):
     for j, name in pm.items():
         lut[j] = CLASS_MAP_TOTAL_INV[name]
     return lut
+
+
+# ---- label tables of the other models BOA measures (data file generated from the reference tables, pinned by G11) ----
+_DATA = None
+
+
+def _data() -> dict:
+    global _DATA
+    if _DATA is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "measurement_label_maps.json")) as f:
+            _DATA = json.load(f)
+    return _DATA
+
+
+def measurement_label_map(model_name: str) -> dict:
+    """{region name: label id} exactly as compute_measurements derives it (BOA/compute/measurements.py:289-293): every
+    TotalSegmentator class_map task whose name starts with `model_name` contributes (for "total" also the `total_mr` /
+    `total_v1` tables as `mr_*` / `v1_*` regions -- a quirk of the reference that its JSON carries)."""
+    return {k: int(v) for k, v in _data()["label_maps"][model_name]}
+
+
+def class_map(task: str) -> dict:
+    """{label id: structure name} of a task (TS/map_to_binary.py class_map)."""
+    return {int(k): v for k, v in _data()["class_maps"][task].items()}
+
+
+def output_name(model_name: str) -> str:
+    """File stem compute_measurements looks for (BOA/compute/util.py:6-14, measurements.py:263-268)."""
+    return _data()["output_names"].get(model_name, model_name)
+
+
+def cnr_adjusted_regions() -> dict:
+    return {k: set(v) for k, v in _data()["cnr_adjusted_regions"].items()}

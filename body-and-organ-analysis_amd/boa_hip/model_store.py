@@ -20,7 +20,24 @@ TASKS: Dict[str, dict] = {
                    "folds": [0, 1, 2, 3, 4], "resample_only_thickness": True},
     "body_regions": {"task_id": [542], "resample": 5.0, "trainer": "nnUNetTrainerNoMirroring", "folds": [0, 1, 2, 3, 4],
                      "resample_only_thickness": True},
+    # rough organ segmentation for the crop cascade (TS/python_api.py:685-707): single model, `total` label map
+    "total_6mm": {"task_id": [298], "resample": 6.0, "trainer": "nnUNetTrainer_4000epochs_NoMirroring", "folds": [0]},
+    # crop-cascade tasks of `--models all` (TS/python_api.py:236-259,311-329): native resolution (resample None), cropped
+    # to the listed `total` structures (+ crop_addon mm); folds None = every fold_k present (nnU-Net's default)
+    "lung_vessels": {"task_id": [258], "resample": None, "trainer": "nnUNetTrainer", "folds": [0],
+                     "crop": ["lung_upper_lobe_left", "lung_lower_lobe_left", "lung_upper_lobe_right",
+                              "lung_middle_lobe_right", "lung_lower_lobe_right"], "crop_addon": [3, 3, 3]},
+    "cerebral_bleed": {"task_id": [150], "resample": None, "trainer": "nnUNetTrainer", "folds": [0], "crop": ["brain"],
+                       "crop_addon": [3, 3, 3]},
+    "hip_implant": {"task_id": [260], "resample": None, "trainer": "nnUNetTrainer", "folds": [0],
+                    "crop": ["femur_left", "femur_right", "hip_left", "hip_right"], "crop_addon": [3, 3, 3]},
+    "pleural_pericard_effusion": {"task_id": [315], "resample": None, "trainer": "nnUNetTrainer", "folds": None,
+                                  "crop": ["lung_upper_lobe_left", "lung_lower_lobe_left", "lung_upper_lobe_right",
+                                           "lung_middle_lobe_right", "lung_lower_lobe_right"], "crop_addon": [50, 50, 50]},
+    "liver_vessels": {"task_id": [8], "resample": None, "trainer": "nnUNetTrainer", "folds": [0], "crop": ["liver"],
+                      "crop_addon": [20, 20, 20]},
 }
+CASCADE_MODELS = ("lung_vessels", "cerebral_bleed", "hip_implant", "pleural_pericard_effusion", "liver_vessels")
 
 
 def results_dir() -> str:
@@ -45,11 +62,16 @@ def load_task_models(task: str, fast_bca: bool = False, root: str = None, config
                      ) -> List[Tuple[int, P.ModelConfig, List[np.ndarray]]]:
     """-> [(task_id, ModelConfig, [weight blob per fold])] for SegmentationTask."""
     info = TASKS[task]
-    folds: Sequence[int] = [0] if (fast_bca and task in ("body_parts", "body_regions")) else info["folds"]
+    folds = [0] if (fast_bca and task in ("body_parts", "body_regions")) else info["folds"]
     out = []
     for tid in info["task_id"]:
         folder = os.path.join(find_dataset_dir(tid, root), f"{info['trainer']}__nnUNetPlans__{configuration}")
         cfg = P.load_model_folder(folder, configuration)
+        if folds is None:  # nnU-Net: use every fold present (predict_from_raw_data.py:68-73 auto-detection)
+            folds = sorted(int(d[5:]) for d in os.listdir(folder) if d.startswith("fold_") and d[5:].isdigit() and
+                           os.path.isfile(os.path.join(folder, d, "checkpoint_final.pth")))
+            if not folds:
+                raise FileNotFoundError(f"no fold_k/checkpoint_final.pth below {folder}")
         blobs = []
         for f in folds:
             ck = os.path.join(folder, f"fold_{f}", "checkpoint_final.pth")

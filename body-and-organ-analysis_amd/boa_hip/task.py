@@ -277,3 +277,23 @@ class SegmentationTask:
                 if id(a.buf) not in seen:
                     seen.add(id(a.buf))
                     a.free()
+
+
+def run_cascade_task(ctx: Context, task: str, data: np.ndarray, affine: np.ndarray, rough_models, task_models,
+                     crop_names: Sequence[str], crop_addon=(3, 3, 3), max_batch: int = 8) -> np.ndarray:
+    """Crop-cascade task of `--models all` (TS/python_api.py:670-757): a rough `total` segmentation at 6 mm (single model
+    Dataset298, labels = the `total` map) -> crop mask = union of the `crop_names` structures -> the task's own model at
+    native resolution on the cropped image -> labels on the input grid.
+    rough_models / task_models: [(task_id, ModelConfig, [weight blob per fold])] as `model_store.load_task_models` gives."""
+    rough = SegmentationTask(ctx, "total", rough_models, resample=6.0, multimodel=False, max_batch=max_batch)
+    try:
+        organ_seg = rough.predict_image(data, affine)
+    finally:
+        rough.close()
+    inv = label_maps.CLASS_MAP_TOTAL_INV
+    crop_mask = np.isin(organ_seg, [inv[n] for n in crop_names]).astype(np.uint8)
+    t = SegmentationTask(ctx, task, task_models, resample=None, multimodel=False, max_batch=max_batch)
+    try:
+        return t.predict_image(data, affine, crop_mask=crop_mask, crop_addon=crop_addon)
+    finally:
+        t.close()

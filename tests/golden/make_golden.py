@@ -371,12 +371,34 @@ def g10_config():
                                   "LICENSE_MODELS": sorted(LICENSE_MODELS), "AVAILABLE_MODELS": sorted(AVAILABLE_MODELS)})
 
 
+# ---------------------------------------------------------------------------------------------- G11
+def g11_measurement_label_maps():
+    """The per-model label maps exactly as compute_measurements builds them (BOA/compute/measurements.py:16-18,
+    289-293: every `class_map` task whose name starts with the model name contributes, e.g. `total_mr_*` / `total_v1_*`
+    entries appear under "total" as `mr_*` / `v1_*`), the class maps of the tasks BOA can run and the output names."""
+    from body_organ_analysis.compute.measurements import CNR_ADJUSTED_REGIONS, reverse_class_map_complete
+    from body_organ_analysis.compute.util import ADDITIONAL_MODELS_OUTPUT_NAME
+    from totalsegmentator.map_to_binary import class_map
+    models = ["total", "lung_vessels", "cerebral_bleed", "hip_implant", "coronary_arteries", "pleural_pericard_effusion",
+              "liver_vessels", "heartchambers_highres", "body_parts", "body_regions"]
+    lm = {}
+    for m in models:
+        # [name, id] pairs in the reference's dict order (the order of the regions in total-measurements.json)
+        lm[m] = list({k[len(m) + 1:]: v for k, v in reverse_class_map_complete.items()
+                      if k.startswith(m) and not k.startswith(m + "_v2")}.items())
+    cm = {m: {str(k): v for k, v in class_map[m].items()} for m in models if m in class_map}
+    save_json("g11_measurement_label_maps.json",
+              {"label_maps": lm, "class_maps": cm, "output_names": ADDITIONAL_MODELS_OUTPUT_NAME,
+               "cnr_adjusted_regions": {k: sorted(v) for k, v in CNR_ADJUSTED_REGIONS.items()}})
+
+
 if __name__ == "__main__":
     ct = load_example_ct()
     print("example ct", ct.shape, ct.dtype, ct.min(), ct.max())
     only = sys.argv[1:]
     fns = dict(g1=g1_steps, g2=g2_gaussian, g3=g3_sliding_window, g3b=g3b_fold_ensemble, g4=lambda: g4_ctnorm(ct),
-               g5=lambda: g5_resample(ct), g67=g67_argmax_merge, g10=g10_config, g9=g9_measurements, g8=g8_bca)
+               g5=lambda: g5_resample(ct), g67=g67_argmax_merge, g10=g10_config, g9=g9_measurements, g8=g8_bca,
+               g11=g11_measurement_label_maps)
     for k, f in fns.items():
         if not only or k in only:
             f()

@@ -17,6 +17,12 @@ def _write_models(root, sp_zyx_total, sp_zyx_bca):
         geom = plans.model_config_from_plans(pj, dj).geometry
         model_store.write_model_folder(root, tid, f"TotalSegmentator_part{tid - 290}", "nnUNetTrainerNoMirroring", pj, dj,
                                        [plans.synthetic_state_dict(geom, seed=tid)])
+    # crop cascade: rough `total` at 6 mm (118 classes) and a native-resolution task model
+    for tid, nc, name, trainer, sp in ((298, 118, "TotalSegmentator_6mm", "nnUNetTrainer_4000epochs_NoMirroring", (6.0, 6.0, 6.0)),
+                                       (258, 3, "lung_vessels", "nnUNetTrainer", sp_zyx_total)):
+        pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc, spacing=sp)
+        geom = plans.model_config_from_plans(pj, dj).geometry
+        model_store.write_model_folder(root, tid, name, trainer, pj, dj, [plans.synthetic_state_dict(geom, seed=tid)])
     for tid, nc, name, trainer in ((543, 7, "BCA_body_parts", "nnUNetTrainer_1500epochs_NoMirroring"),
                                    (542, 12, "BCA_inference", "nnUNetTrainerNoMirroring")):
         pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc, spacing=sp_zyx_bca)
@@ -78,4 +84,18 @@ def test_compute_all_models_total_bca(tmp_path, monkeypatch):
     compute_all_models(ct_path, out, ["total"], params, recompute=False)
     assert os.path.getmtime(out / "total.nii.gz") == before
     with pytest.raises(NotImplementedError):
-        compute_all_models(ct_path, out, ["lung_vessels"], params)
+        compute_all_models(ct_path, out, ["heartchambers_highres"], params)
+    # crop-cascade model: rough 6 mm `total` -> lung mask -> native-resolution model; same result as the array-level driver
+    from boa_hip.task import run_cascade_task
+    compute_all_models(ct_path, out, ["lung_vessels"], params)
+    lv, _, lh = nifti.load(out / "lung_vessels.nii.gz")
+    info = model_store.TASKS["lung_vessels"]
+    want = run_cascade_task(ctx, "lung_vessels", ct, aff, model_store.load_task_models("total_6mm"),
+                            model_store.load_task_models("lung_vessels"), info["crop"], info["crop_addon"])
+    np.testing.assert_array_equal(lv, want)
+    assert lv.any() and set(np.unique(lv)) <= {0, 1, 2}
+    assert nifti.parse_label_xml(lh.extensions[0][1]) == {1: "lung_vessels", 2: "lung_trachea_bronchia"}
+    # the reference measures <ADDITIONAL_MODELS_OUTPUT_NAME>.nii.gz = lung_vessels_airways.nii.gz, which inference never
+    # writes: the model is (silently, as in the reference) absent from total-measurements.json
+    with open(out / "total-measurements.json") as f:
+        assert "lung_vessels" not in json.load(f)["segmentations"]

@@ -208,3 +208,19 @@ def test_model_store_folder_contract(tmp_path):
     assert tid == 542 and len(blobs) == 5 and cfg.geometry.num_classes == 3
     np.testing.assert_array_equal(blobs[3], plans.weight_blob_from_state_dict(geom, sds[3]))
     assert len(model_store.load_task_models("body_regions", fast_bca=True, root=str(tmp_path))[0][2]) == 1
+
+
+def test_measurement_label_maps_match_reference_tables():
+    """boa_hip/data/measurement_label_maps.json (product data) == G11 (derived by the reference's own code)."""
+    from boa_hip import label_maps
+    with open(os.path.join(GOLDEN, "g11_measurement_label_maps.json")) as f:
+        g = json.load(f)
+    for model, pairs in g["label_maps"].items():
+        lm = label_maps.measurement_label_map(model)
+        assert list(lm.items()) == [(k, v) for k, v in pairs], model          # content and order
+    assert len(label_maps.measurement_label_map("total")) == 295              # total + total_v1 + total_mr quirk
+    for model, cm in g["class_maps"].items():
+        assert label_maps.class_map(model) == {int(k): v for k, v in cm.items()}
+    assert label_maps.class_map("total") == label_maps.CLASS_MAP_TOTAL
+    assert label_maps.output_name("lung_vessels") == "lung_vessels_airways" and label_maps.output_name("total") == "total"
+    assert label_maps.cnr_adjusted_regions() == {k: set(v) for k, v in g["cnr_adjusted_regions"].items()}
