@@ -204,6 +204,23 @@ def bca_measurements(ctx: Context, ct: np.ndarray, regions: np.ndarray, parts: n
     d_ct = ctx.from_numpy(np.ascontiguousarray(ct, dtype=np.int16))
     d_rg = ctx.from_numpy(np.ascontiguousarray(regions, dtype=np.uint8))
     d_pt = ctx.from_numpy(np.ascontiguousarray(parts, dtype=np.uint8))
+    try:
+        out, tis = bca_measurements_device(ctx, d_ct, d_rg, d_pt, shape, spacing_xyz, vertebrae, return_tissues,
+                                           median_filtering, orientation, body_parts_override)
+        if return_tissues:
+            t = tis.download(shape, np.uint8)
+            tis.free()
+            return out, t
+        return out
+    finally:
+        for b in (d_ct, d_rg, d_pt):
+            b.free()
+
+
+def bca_measurements_device(ctx: Context, d_ct: DeviceBuffer, d_rg: DeviceBuffer, d_pt: DeviceBuffer, shape, spacing_xyz,
+                            vertebrae=None, return_tissues: bool = False, median_filtering: bool = False,
+                            orientation="LPS", body_parts_override=None):
+    """`bca_measurements` on resident (z,y,x) buffers (int16 CT, uint8 regions / parts) -> (dict, tissues buffer | None)."""
     d_med = None
     try:
         if median_filtering:
@@ -211,26 +228,21 @@ def bca_measurements(ctx: Context, ct: np.ndarray, regions: np.ndarray, parts: n
         tis, counts, hu_sums = tissue_aggregate(ctx, d_ct, d_rg, d_pt, shape, want_tissues=return_tissues, ct_rules=d_med)
         present = slice_label_presence(ctx, d_rg, shape)
         out = bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae, body_parts_override)
-        if return_tissues:
-            t = tis.download(shape, np.uint8)
-            tis.free()
-            return out, t
-        return out
+        return out, tis
     finally:
-        for b in (d_ct, d_rg, d_pt, d_med):
-            if b is not None:
-                b.free()
+        if d_med is not None:
+            d_med.free()
 
 
-def create_vertebrae_info(ctx: Context, total_zyx: np.ndarray, class_map_total: Dict[int, str], parts: Dict[str, bool],
-                          d_total: Optional[DeviceBuffer] = None) -> Dict[str, Tuple[int, int]]:
+def create_vertebrae_info(ctx: Context, total_zyx: Optional[np.ndarray], class_map_total: Dict[int, str], parts: Dict[str, bool],
+                          d_total: Optional[DeviceBuffer] = None, shape=None) -> Dict[str, Tuple[int, int]]:
     """BCA/commands.py:24-45: slice range (min, max+1) of every vertebra label that is present and whose body part
     (C -> neck, T -> thorax, L -> abdomen) was detected.  One presence pass on the device."""
     own = d_total is None
     if own:
         d_total = ctx.from_numpy(np.ascontiguousarray(total_zyx, dtype=np.uint8))
     try:
-        present = slice_label_presence(ctx, d_total, total_zyx.shape)
+        present = slice_label_presence(ctx, d_total, total_zyx.shape if shape is None else shape)
     finally:
         if own:
             d_total.free()
@@ -253,9 +265,18 @@ def create_vertebrae_info(ctx: Context, total_zyx: np.ndarray, class_map_total: 
 def postprocess_region_segmentation(ctx: Context, seg: np.ndarray) -> np.ndarray:
     """BCA/body_regions/postprocess.py:18-40 on the device: for the masks {seg > 0}, {thoracic, mediastinum,
     pericardium}, {pericardium}, {abdominal cavity}: all 26-connected components except the largest -> 255."""
-    shape = seg.shape
-    n = int(np.prod(shape))
     d_seg = ctx.from_numpy(np.ascontiguousarray(seg, dtype=np.uint8))
+    try:
+        postprocess_region_segmentation_device(ctx, d_seg, seg.shape)
+        return d_seg.download(seg.shape, np.uint8)
+    finally:
+        d_seg.free()
+
+
+def postprocess_region_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shape) -> None:
+    """In place on a resident uint8 (z,y,x) label buffer."""
+    shape = tuple(int(v) for v in shape)
+    n = int(np.prod(shape))
     d_mask = ctx.alloc(n)
     d_roots = ctx.alloc(n * 4)
     d_sizes = ctx.alloc(n * 4)
@@ -273,9 +294,8 @@ def postprocess_region_segmentation(ctx: Context, seg: np.ndarray) -> np.ndarray
         run(2, (REGION["THORACIC_CAVITY"], REGION["MEDIASTINUM"], REGION["PERICARDIUM"]))
         run(0, (REGION["PERICARDIUM"], 0, 0))
         run(0, (REGION["ABDOMINAL_CAVITY"], 0, 0))
-        return d_seg.download(shape, np.uint8)
     finally:
-        for b in (d_seg, d_mask, d_roots, d_sizes):
+        for b in (d_mask, d_roots, d_sizes):
             b.free()
 
 
@@ -284,10 +304,22 @@ def postprocess_part_segmentation(ctx: Context, seg: np.ndarray, threshold: int 
     slice-wise external-contour fill (boa_fill_holes_2d), remove 26-connected objects with <= threshold-1 voxels,
     remove 26-connected holes with <= threshold-1 voxels, `out[filled] = label`."""
     seg = np.ascontiguousarray(seg, dtype=np.uint8)
-    shape = tuple(int(v) for v in seg.shape)
+    d_seg = ctx.from_numpy(seg)
+    try:
+        d_out = postprocess_part_segmentation_device(ctx, d_seg, seg.shape, threshold)
+        try:
+            return d_out.download(seg.shape, np.uint8)
+        finally:
+            d_out.free()
+    finally:
+        d_seg.free()
+
+
+def postprocess_part_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shape, threshold: int = 3000) -> DeviceBuffer:
+    """Resident uint8 (z,y,x) labels -> new resident buffer with the cleaned labels."""
+    shape = tuple(int(v) for v in shape)
     Z, Y, X = shape
     n = Z * Y * X
-    d_seg = ctx.from_numpy(seg)
     d_out = ctx.zeros(n)
     d_mask, d_fill, d_tmp = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
     d_roots, d_sizes = ctx.alloc(n * 4), ctx.alloc(n * 4)
@@ -307,7 +339,10 @@ def postprocess_part_segmentation(ctx: Context, seg: np.ndarray, threshold: int 
             check(ctx.lib.boa_ccl26(ctx.h, d_mask.vp, Z, Y, X, d_roots.vp, d_sizes.vp, C.byref(ncomp)))
             check(ctx.lib.boa_ccl_remove_small(ctx.h, d_roots.vp, d_sizes.vp, n, threshold - 1, d_mask.vp))
             check(ctx.lib.boa_mask_assign(ctx.h, d_mask.vp, n, 1, int(label), d_out.vp))   # out[~d_mask] = label
-        return d_out.download(shape, np.uint8)
+        return d_out
+    except Exception:
+        d_out.free()
+        raise
     finally:
-        for b in (d_seg, d_out, d_mask, d_fill, d_tmp, d_roots, d_sizes):
+        for b in (d_mask, d_fill, d_tmp, d_roots, d_sizes):
             b.free()

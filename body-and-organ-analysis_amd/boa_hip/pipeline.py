@@ -13,11 +13,14 @@ NIfTI files of the reference's folder contract are written by the caller (I/O is
 """
 from __future__ import annotations
 
+import os
+import time
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
 from . import bca, label_maps, orientation
+from .devarray import DevArray
 from .device import Context
 from .plans import ModelConfig
 from .task import SegmentationTask
@@ -53,6 +56,26 @@ def from_lps_zyx(arr_zyx: np.ndarray, affine: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(orientation.apply_orientation(arr_zyx.transpose(2, 1, 0), orientation.ornt_transform(cur, tgt)))
 
 
+_PROF = bool(os.environ.get("BOA_PIPE_PROF"))
+
+
+class _Stage:
+    """`with _Stage(ctx, "name"):` prints the wall time of a pipeline stage when BOA_PIPE_PROF is set."""
+
+    def __init__(self, ctx, name):
+        self.ctx, self.name = ctx, name
+
+    def __enter__(self):
+        if _PROF:
+            self.ctx.sync()
+            self.t = time.perf_counter()
+
+    def __exit__(self, *a):
+        if _PROF:
+            self.ctx.sync()
+            print(f"[pipe] {self.name}: {time.perf_counter() - self.t:.3f} s", flush=True)
+
+
 class BcaPipelineHip:
     """parts_model / regions_model: (ModelConfig, [weight blob per fold])."""
 
@@ -72,56 +95,104 @@ class BcaPipelineHip:
         for t in self.tasks.values():
             t.close()
 
+    def _inference_device(self, task_name: str, d_ct: DevArray, affine: np.ndarray, force_split: bool, crop, raw) -> DevArray:
+        """BCA/infer/infer.py:39-89 on resident data: network labels on the input grid (file axis order), then the task's
+        post-processing applied to the SimpleITK view (z,y,x) of the file; returns the cleaned labels in file order."""
+        if raw is None:
+            with _Stage(self.ctx, f"{task_name}: networks"):
+                d_raw = self.tasks[task_name].predict_image(d_ct, affine, force_split=force_split, crop_mask=crop, return_device=True)
+        else:
+            d_raw = DevArray.from_numpy(self.ctx, np.ascontiguousarray(raw, dtype=np.uint8))
+        with _Stage(self.ctx, f"{task_name}: post-processing"):
+            zyx = d_raw.transpose((2, 1, 0)).contiguous(force_copy=True)
+            d_raw.free()
+            if task_name == "body_parts":
+                buf = bca.postprocess_part_segmentation_device(self.ctx, zyx.buf, zyx.shape)
+                zyx.free()
+                zyx = DevArray(self.ctx, buf, zyx.shape, np.uint8)
+            elif task_name == "body_regions":
+                bca.postprocess_region_segmentation_device(self.ctx, zyx.buf, zyx.shape)
+            else:
+                zyx.free()
+                raise ValueError(task_name)
+            out = zyx.transpose((2, 1, 0)).contiguous(force_copy=True)
+            zyx.free()
+            return out
+
     def inference(self, task_name: str, ct: np.ndarray, affine: np.ndarray, force_split: bool = False,
                   crop: Optional[np.ndarray] = None, raw: Optional[np.ndarray] = None) -> np.ndarray:
-        """BCA/infer/infer.py:39-89: network labels on the input grid, then the task's post-processing applied to the
-        SimpleITK view (z,y,x) of the file.  `raw` short-cuts the network (testing seam)."""
-        if raw is None:
-            raw = self.tasks[task_name].predict_image(ct, affine, force_split=force_split, crop_mask=crop)
-        arr = np.ascontiguousarray(raw.transpose(2, 1, 0)).astype(np.uint8, copy=False)
-        if task_name == "body_parts":
-            out = bca.postprocess_part_segmentation(self.ctx, arr)
-        elif task_name == "body_regions":
-            out = bca.postprocess_region_segmentation(self.ctx, arr)
-        else:
-            raise ValueError(task_name)
-        return np.ascontiguousarray(out.transpose(2, 1, 0))
+        """`inference()` for one BCA task on host arrays (file axis order) -> cleaned labels (file axis order)."""
+        d_ct = DevArray.from_numpy(self.ctx, SegmentationTask._supported(ct))
+        try:
+            out = self._inference_device(task_name, d_ct, np.asarray(affine, dtype=np.float64), force_split, crop, raw)
+            try:
+                return out.download()
+            finally:
+                out.free()
+        finally:
+            d_ct.free()
+
+    def _lps_zyx(self, d: DevArray, affine: np.ndarray, dtype=None) -> DevArray:
+        """BCA/io.py:78-94 `process_image` as a device view: reorient to LPS, SimpleITK array order (z,y,x), contiguous."""
+        cur = "".join(orientation.aff2axcodes(affine))
+        v = d if cur == "LPS" else d.apply_orientation(orientation.ornt_transform(orientation.axcodes2ornt(cur), orientation.axcodes2ornt("LPS")))
+        return v.transpose((2, 1, 0)).contiguous(dtype, force_copy=True)
 
     def run(self, ct: np.ndarray, affine: np.ndarray, total_seg: Optional[np.ndarray] = None,
             median_filtering: bool = False, examined_body_region: Optional[str] = None, crop_body: bool = False,
             force_split: bool = False, raw_parts: Optional[np.ndarray] = None, raw_regions: Optional[np.ndarray] = None) -> dict:
         """-> {"body_parts", "body_regions", "tissues" (file axis order, uint8), "bca_measurements" (dict),
-        "vertebrae" (dict)}.  `total_seg`: the `total` label volume on the same grid (vertebra groups), optional."""
+        "vertebrae" (dict)}.  `total_seg`: the `total` label volume on the same grid (vertebra groups), optional.
+        The CT is uploaded once; every stage (nets, post-processing, LPS reload, tissues, tables) works on resident
+        buffers, the three label volumes are downloaded at the end."""
+        ctx = self.ctx
         affine = np.asarray(affine, dtype=np.float64)
-        parts = self.inference("body_parts", ct, affine, force_split, raw=raw_parts)
-        regions = self.inference("body_regions", ct, affine, force_split, crop=parts if crop_body else None,
-                                 raw=raw_regions)
-        # everything the report needs, in LPS (z,y,x)
-        ct_l, spacing = to_lps_zyx(ct, affine)
-        rg_l, _ = to_lps_zyx(regions, affine)
-        pt_l, _ = to_lps_zyx(parts, affine)
-        ct_l = ct_l.astype(np.int16, copy=False)
-        present = None
-        d_rg = self.ctx.from_numpy(rg_l)
+        d_ct = DevArray.from_numpy(ctx, SegmentationTask._supported(ct))
+        live = [d_ct]
         try:
-            present = bca.slice_label_presence(self.ctx, d_rg, rg_l.shape)
+            d_parts = self._inference_device("body_parts", d_ct, affine, force_split, None, raw_parts)
+            live.append(d_parts)
+            crop = d_parts.download() if crop_body else None
+            d_regions = self._inference_device("body_regions", d_ct, affine, force_split, crop, raw_regions)
+            live.append(d_regions)
+            with _Stage(ctx, "LPS reload, body-part flags, vertebrae, tissues + tables, JSON"):
+                _, laff = orientation.with_axcodes(np.empty(d_ct.shape, dtype=np.uint8), affine, "LPS")
+                sp = np.sqrt(np.sum(np.asarray(laff, dtype=np.float64)[:3, :3] ** 2, axis=0))
+                spacing = (float(sp[0]), float(sp[1]), float(sp[2]))
+                ct_l = self._lps_zyx(d_ct, affine, np.int16)
+                rg_l = self._lps_zyx(d_regions, affine)
+                pt_l = self._lps_zyx(d_parts, affine)
+                live += [ct_l, rg_l, pt_l]
+                present = bca.slice_label_presence(ctx, rg_l.buf, rg_l.shape)
+                if examined_body_region:
+                    flags = dict(abdomen=False, neck=False, thorax=False)
+                    key = examined_body_region.lower()
+                    if key not in flags and key != "none":
+                        raise KeyError(examined_body_region.upper())
+                    if key in flags:
+                        flags[key] = True
+                else:
+                    flags = bca.examined_body_part(present, spacing)
+                vertebrae = {}
+                if total_seg is not None:
+                    d_tot = DevArray.from_numpy(ctx, np.ascontiguousarray(total_seg, dtype=np.uint8))
+                    live.append(d_tot)
+                    tot_l = self._lps_zyx(d_tot, affine)
+                    live.append(tot_l)
+                    vertebrae = bca.create_vertebrae_info(ctx, None, label_maps.CLASS_MAP_TOTAL, flags, d_total=tot_l.buf,
+                                                          shape=tot_l.shape)
+                js, d_tis = bca.bca_measurements_device(ctx, ct_l.buf, rg_l.buf, pt_l.buf, ct_l.shape, spacing, vertebrae or None,
+                                                        True, median_filtering, "LPS", flags if examined_body_region else None)
+                tis_l = DevArray(ctx, d_tis, ct_l.shape, np.uint8)
+                live.append(tis_l)
+                # back to the file's axis order: (z,y,x) LPS -> (x,y,z) LPS -> file orientation
+                back = orientation.ornt_transform(orientation.axcodes2ornt("LPS"), orientation.io_orientation(affine))
+                tissues = tis_l.transpose((2, 1, 0)).apply_orientation(back).download()
+            return {"body_parts": d_parts.download(), "body_regions": d_regions.download(), "tissues": tissues,
+                    "bca_measurements": js, "vertebrae": vertebrae, "examined_body_part": flags}
         finally:
-            d_rg.free()
-        if examined_body_region:
-            flags = dict(abdomen=False, neck=False, thorax=False)
-            key = examined_body_region.lower()
-            if key not in flags and key != "none":
-                raise KeyError(examined_body_region.upper())
-            if key in flags:
-                flags[key] = True
-        else:
-            flags = bca.examined_body_part(present, spacing)
-        vertebrae = {}
-        if total_seg is not None:
-            tot_l, _ = to_lps_zyx(total_seg, affine)
-            vertebrae = bca.create_vertebrae_info(self.ctx, tot_l, label_maps.CLASS_MAP_TOTAL, flags)
-        js, tis_l = bca.bca_measurements(self.ctx, ct_l, rg_l, pt_l, spacing, vertebrae or None, return_tissues=True,
-                                         median_filtering=median_filtering, orientation="LPS",
-                                         body_parts_override=flags if examined_body_region else None)
-        return {"body_parts": parts, "body_regions": regions, "tissues": from_lps_zyx(tis_l, affine),
-                "bca_measurements": js, "vertebrae": vertebrae, "examined_body_part": flags}
+            seen = set()
+            for a in live:
+                if id(a.buf) not in seen:
+                    seen.add(id(a.buf))
+                    a.free()

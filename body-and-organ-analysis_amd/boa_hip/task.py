@@ -175,31 +175,35 @@ class SegmentationTask:
         return data.astype(np.float64)   # what get_fdata() hands to the reference
 
     # ---- nnUNet_predict_image ------------------------------------------------------------------------------
-    def predict_image(self, data: np.ndarray, affine: np.ndarray, force_split: bool = False,
-                      crop_mask: Optional[np.ndarray] = None, crop_addon=(3, 3, 3), axcodes: str = "RAS") -> np.ndarray:
+    def predict_image(self, data, affine: np.ndarray, force_split: bool = False,
+                      crop_mask: Optional[np.ndarray] = None, crop_addon=(3, 3, 3), axcodes: str = "RAS",
+                      return_device: bool = False):
         """CT array in file axis order + its affine -> uint8 label array on the same grid.  The volume is uploaded
         once; reorientation, crops, splits and restores are device views / copies, resampling and inference run on the
-        device, only the final label volume comes back."""
-        if data.ndim == 2:
-            raise ValueError("TotalSegmentator does not work for 2D images. Use a 3D image.")
-        if data.ndim > 3:
-            data = data[:, :, :, 0]
-        if data.dtype.fields is not None:
-            raise TypeError(f"Invalid dtype {data.dtype}. Expected a simple dtype, not a structured one.")
+        device, only the final label volume comes back.  `data` may be a resident DevArray (not freed here);
+        `return_device=True` returns the labels as a contiguous DevArray (caller frees) instead of downloading."""
+        resident = isinstance(data, DevArray)
+        if not resident:
+            if data.ndim == 2:
+                raise ValueError("TotalSegmentator does not work for 2D images. Use a 3D image.")
+            if data.ndim > 3:
+                data = data[:, :, :, 0]
+            if data.dtype.fields is not None:
+                raise TypeError(f"Invalid dtype {data.dtype}. Expected a simple dtype, not a structured one.")
         ctx = self.ctx
         orig_shape = tuple(int(v) for v in data.shape)
         affine = np.asarray(affine, dtype=np.float64)
         aff = affine
         bbox = None
         if crop_mask is not None and crop_mask.sum() == 0:              # TS/nnunet.py:428-446
-            return np.zeros(orig_shape, dtype=np.uint8)
+            return DevArray.zeros(ctx, orig_shape, np.uint8) if return_device else np.zeros(orig_shape, dtype=np.uint8)
         owned = []                                                     # device arrays to release
 
         def own(a):
             owned.append(a)
             return a
         try:
-            view = own(DevArray.from_numpy(ctx, self._supported(data)))
+            view = data if resident else own(DevArray.from_numpy(ctx, self._supported(data)))
             cast = None
             if crop_mask is not None:
                 addon = (np.array(crop_addon) / orientation.zooms_from_affine(aff)).astype(int)   # mm -> voxels
@@ -270,6 +274,11 @@ class SegmentationTask:
                 out = full
             if tuple(out.shape) != orig_shape[:3]:
                 raise ValueError(f"shape mismatch after restore: {out.shape} vs {orig_shape}")   # check_if_shape_and_affine_identical
+            if return_device:
+                res = out.contiguous(force_copy=(resident and out.buf is data.buf))
+                keep = id(res.buf)
+                owned[:] = [a for a in owned if id(a.buf) != keep]
+                return res
             return out.download()
         finally:
             seen = set()

@@ -53,6 +53,14 @@ struct boa_net {
     float* first_padded = nullptr;  // zero-padded fp32 gather buffer of the first conv
     std::vector<void*> allocs;
     int dims[BOA_MAX_STAGES][3];
+    // packed weight sets (one device arena each), cached per host blob: switching folds is a pointer swap, not a re-pack
+    struct WeightSet {
+        const float* key;
+        size_t n;
+        unsigned long long sample_hash;  // FNV-1a over ~4096 evenly spaced floats: guards against a recycled host address
+        unsigned char* arena;
+    };
+    std::vector<WeightSet> wsets;
 };
 
 static int net_alloc(boa_net* net, size_t bytes, void** out) {
@@ -122,18 +130,13 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
     if (first) {
         BOA_REQUIRE(s[0] == 1 && s[1] == 1 && s[2] == 1, "first conv must have stride 1");
         L.nblk = conv_first_nblk(dout, net->ctx->cu_count);
-        BOA_TRY(net_alloc(net, L.w_elems * sizeof(float), (void**)&L.wfirst));
     } else {
         BOA_REQUIRE((cin0 % 16) == 0 && (cin1 % 16) == 0 && (cout % 32) == 0,
                     "conv %d+%d -> %d: channel counts must be multiples of 16 (in) / 32 (out)", cin0, cin1, cout);
         BOA_REQUIRE(choose_conv_tile(L.g, net->ctx->cu_count, &L.t), "no tile configuration fits conv %dx%dx%d", din[0],
                     din[1], din[2]);
         L.nblk = conv_nblk(L.t, net->ctx->cu_count);
-        BOA_TRY(net_alloc(net, conv_wpk_halves(cin0 + cin1, cout, k) * sizeof(__half), (void**)&L.wpk));
     }
-    BOA_TRY(net_alloc(net, cout * sizeof(float), (void**)&L.bias));
-    BOA_TRY(net_alloc(net, cout * sizeof(float), (void**)&L.gamma));
-    BOA_TRY(net_alloc(net, cout * sizeof(float), (void**)&L.beta));
     size_t vox = (size_t)dout[0] * dout[1] * dout[2];
     BOA_TRY(net_alloc(net, (size_t)N * vox * cout * sizeof(__half), (void**)&L.out));
     BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * L.nblk * sizeof(float), (void**)&L.partials));
@@ -143,55 +146,118 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
     return BOA_OK;
 }
 
+// Device layout of one weight set: every tensor of the blob, in blob order, at a 256-byte aligned offset of one arena.
+// `visit(piece kind, layer pointers..., byte size)` is called in blob order; used both to size / fill the arena and
+// to point the layers at it.
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+template <typename F>
+static void for_each_weight_piece(boa_net* net, F&& f) {
+    auto conv = [&](ConvLayer& L) {
+        const int cin = L.Cin0 + L.Cin1, cout = L.g.Cout;
+        f(L.first ? 0 : 1, &L, nullptr, L.first ? L.w_elems * sizeof(float) : conv_wpk_halves(cin, cout, L.g.k) * sizeof(__half));
+        f(2, &L, nullptr, cout * sizeof(float));  // bias
+        f(3, &L, nullptr, cout * sizeof(float));  // gamma
+        f(4, &L, nullptr, cout * sizeof(float));  // beta
+    };
+    for (auto& st : net->enc)
+        for (auto& L : st) conv(L);
+    for (size_t k = 0; k < net->up.size(); ++k) {
+        UpLayer& U = net->up[k];
+        f(5, nullptr, &U, convt_wpk_halves(U.Cin, U.Cout, U.s) * sizeof(__half));
+        f(6, nullptr, &U, U.Cout * sizeof(float));
+        for (auto& L : net->dec[k]) conv(L);
+    }
+    f(7, nullptr, nullptr, (size_t)net->d.num_classes * net->d.features[0] * sizeof(float));
+    f(8, nullptr, nullptr, net->d.num_classes * sizeof(float));
+}
+
+static void point_layers_at(boa_net* net, unsigned char* arena) {
+    size_t off = 0;
+    for_each_weight_piece(net, [&](int kind, ConvLayer* L, UpLayer* U, size_t bytes) {
+        void* p = arena + off;
+        switch (kind) {
+            case 0: L->wfirst = (float*)p; break;
+            case 1: L->wpk = (__half*)p; break;
+            case 2: L->bias = (float*)p; break;
+            case 3: L->gamma = (float*)p; break;
+            case 4: L->beta = (float*)p; break;
+            case 5: U->wpk = (__half*)p; break;
+            case 6: U->bias = (float*)p; break;
+            case 7: net->head_w = (float*)p; break;
+            default: net->head_b = (float*)p; break;
+        }
+        off += align256(bytes);
+    });
+}
+
 extern "C" int boa_net_load_weights(boa_net* net, const float* w, size_t n_floats) {
     BOA_REQUIRE(net && w, "boa_net_load_weights: NULL argument");
     size_t expect = boa_net_weight_count(&net->d);
     BOA_REQUIRE(n_floats == expect, "weight blob has %zu floats, geometry needs %zu", n_floats, expect);
     boa_ctx* c = net->ctx;
     BOA_HIP_TRY(hipStreamSynchronize(c->stream));
-    const float* p = w;
-    std::vector<__half> tmp;
-    auto load_conv = [&](ConvLayer& L) -> int {
-        const int cin = L.Cin0 + L.Cin1, cout = L.g.Cout;
-        const int taps = L.g.k[0] * L.g.k[1] * L.g.k[2];
-        if (L.first) {
-            std::vector<float> wf((size_t)cin * taps * cout);
-            for (int co = 0; co < cout; ++co)
-                for (int ci = 0; ci < cin; ++ci)
-                    for (int t = 0; t < taps; ++t) wf[((size_t)ci * taps + t) * cout + co] = p[((size_t)co * cin + ci) * taps + t];
-            BOA_HIP_TRY(hipMemcpy(L.wfirst, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
-        } else {
-            tmp.assign(conv_wpk_halves(cin, cout, L.g.k), __float2half_rn(0.f));
-            pack_conv_weights(p, cin, cout, L.g.k, tmp.data());
-            BOA_HIP_TRY(hipMemcpy(L.wpk, tmp.data(), tmp.size() * sizeof(__half), hipMemcpyHostToDevice));
+    // cached set of the same host blob (fold switching in predict_logits_from_preprocessed_data, :483-489)?
+    unsigned long long hsh = 1469598103934665603ull;
+    {
+        const size_t step = n_floats > 4096 ? n_floats / 4096 : 1;
+        for (size_t i = 0; i < n_floats; i += step) {
+            unsigned u;
+            memcpy(&u, w + i, 4);
+            hsh = (hsh ^ u) * 1099511628211ull;
         }
-        p += L.w_elems;
-        BOA_HIP_TRY(hipMemcpy(L.bias, p, cout * sizeof(float), hipMemcpyHostToDevice));
-        p += cout;
-        BOA_HIP_TRY(hipMemcpy(L.gamma, p, cout * sizeof(float), hipMemcpyHostToDevice));
-        p += cout;
-        BOA_HIP_TRY(hipMemcpy(L.beta, p, cout * sizeof(float), hipMemcpyHostToDevice));
-        p += cout;
-        return BOA_OK;
-    };
-    for (auto& st : net->enc)
-        for (auto& L : st) BOA_TRY(load_conv(L));
-    for (size_t k = 0; k < net->up.size(); ++k) {
-        UpLayer& U = net->up[k];
-        tmp.assign(convt_wpk_halves(U.Cin, U.Cout, U.s), __float2half_rn(0.f));
-        pack_convt_weights(p, U.Cin, U.Cout, U.s, tmp.data());
-        BOA_HIP_TRY(hipMemcpy(U.wpk, tmp.data(), tmp.size() * sizeof(__half), hipMemcpyHostToDevice));
-        p += (size_t)U.Cin * U.Cout * U.s[0] * U.s[1] * U.s[2];
-        BOA_HIP_TRY(hipMemcpy(U.bias, p, U.Cout * sizeof(float), hipMemcpyHostToDevice));
-        p += U.Cout;
-        for (auto& L : net->dec[k]) BOA_TRY(load_conv(L));
     }
-    size_t hw = (size_t)net->d.num_classes * net->d.features[0];
-    BOA_HIP_TRY(hipMemcpy(net->head_w, p, hw * sizeof(float), hipMemcpyHostToDevice));
-    p += hw;
-    BOA_HIP_TRY(hipMemcpy(net->head_b, p, net->d.num_classes * sizeof(float), hipMemcpyHostToDevice));
-    p += net->d.num_classes;
+    for (auto& ws : net->wsets)
+        if (ws.key == w && ws.n == n_floats && ws.sample_hash == hsh) {
+            point_layers_at(net, ws.arena);
+            return BOA_OK;
+        }
+    size_t total = 0;
+    for_each_weight_piece(net, [&](int, ConvLayer*, UpLayer*, size_t bytes) { total += align256(bytes); });
+    std::vector<unsigned char> stage(total, 0);
+    const float* p = w;
+    size_t off = 0;
+    for_each_weight_piece(net, [&](int kind, ConvLayer* L, UpLayer* U, size_t bytes) {
+        unsigned char* dst = stage.data() + off;
+        switch (kind) {
+            case 0: {  // first conv: [cout][cin][taps] -> [cin][taps][cout] fp32
+                const int cin = L->Cin0 + L->Cin1, cout = L->g.Cout, taps = L->g.k[0] * L->g.k[1] * L->g.k[2];
+                float* wf = (float*)dst;
+                for (int co = 0; co < cout; ++co)
+                    for (int ci = 0; ci < cin; ++ci)
+                        for (int t = 0; t < taps; ++t) wf[((size_t)ci * taps + t) * cout + co] = p[((size_t)co * cin + ci) * taps + t];
+                p += L->w_elems;
+                break;
+            }
+            case 1:
+                pack_conv_weights(p, L->Cin0 + L->Cin1, L->g.Cout, L->g.k, (__half*)dst);
+                p += L->w_elems;
+                break;
+            case 5:
+                pack_convt_weights(p, U->Cin, U->Cout, U->s, (__half*)dst);
+                p += (size_t)U->Cin * U->Cout * U->s[0] * U->s[1] * U->s[2];
+                break;
+            default:  // fp32 vectors / head matrix, copied as they are
+                memcpy(dst, p, bytes);
+                p += bytes / sizeof(float);
+                break;
+        }
+        off += align256(bytes);
+    });
     BOA_REQUIRE((size_t)(p - w) == expect, "internal: weight cursor mismatch");
+    if (net->wsets.size() >= 8) {  // bounded cache: drop the oldest set
+        hipFree(net->wsets.front().arena);
+        net->wsets.erase(net->wsets.begin());
+    }
+    unsigned char* arena = nullptr;
+    BOA_TRY(boa_malloc(c, total, (void**)&arena));
+    hipError_t e = hipMemcpy(arena, stage.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(arena);
+        BOA_HIP_TRY(e);
+    }
+    net->wsets.push_back({w, n_floats, hsh, arena});
+    point_layers_at(net, arena);
     return BOA_OK;
 }
 
@@ -199,6 +265,7 @@ extern "C" void boa_net_destroy(boa_net* net) {
     if (!net) return;
     hipStreamSynchronize(net->ctx->stream);
     for (void* a : net->allocs) hipFree(a);
+    for (auto& ws : net->wsets) hipFree(ws.arena);
     delete net;
 }
 
@@ -262,8 +329,6 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
             boa_set_error("transposed conv %d -> %d: unsupported channel counts", U.Cin, U.Cout);
             return fail(BOA_EINVAL);
         }
-        if ((rc = net_alloc(net, convt_wpk_halves(U.Cin, U.Cout, U.s) * sizeof(__half), (void**)&U.wpk))) return fail(rc);
-        if ((rc = net_alloc(net, U.Cout * sizeof(float), (void**)&U.bias))) return fail(rc);
         size_t vox = (size_t)dup[0] * dup[1] * dup[2];
         if ((rc = net_alloc(net, (size_t)max_batch * vox * U.Cout * sizeof(__half), (void**)&U.out))) return fail(rc);
         net->dec[k].resize(d.n_conv_dec[k]);
@@ -274,8 +339,6 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
             if (rc) return fail(rc);
         }
     }
-    if ((rc = net_alloc(net, (size_t)d.num_classes * d.features[0] * sizeof(float), (void**)&net->head_w))) return fail(rc);
-    if ((rc = net_alloc(net, d.num_classes * sizeof(float), (void**)&net->head_b))) return fail(rc);
     if ((rc = net_alloc(net, (size_t)max_batch * 3 * sizeof(int), (void**)&net->dev_origins))) return fail(rc);
     {
         int PD[3];
