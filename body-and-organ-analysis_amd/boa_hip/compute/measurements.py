@@ -11,6 +11,7 @@ import numpy as np
 
 from .. import label_maps, nifti
 from .. import measurements as M
+from ..devarray import DevArray
 from ..device import Context
 
 logger = logging.getLogger(__name__)
@@ -27,7 +28,10 @@ def compute_measurements(ct_path: pathlib.Path, segmentation_folder: pathlib.Pat
         ctx = get_context(None)
     segmentation_folder = pathlib.Path(segmentation_folder)
     data, _, hdr = nifti.load(ct_path)
-    ct = np.ascontiguousarray(nifti.fdata(data, hdr).transpose(2, 1, 0))       # SimpleITK view (z,y,x)
+    # SimpleITK view (z,y,x) of the file, int16 HU, made on the device (a 512^3 host transpose costs ~0.5 s)
+    d_file = DevArray.from_numpy(ctx, data if (data.dtype == np.int16 and not nifti.is_scaled(hdr)) else nifti.fdata(data, hdr))
+    d_ct = d_file.transpose((2, 1, 0)).contiguous(np.int16, force_copy=True)
+    d_file.free()
     spacing = tuple(float(v) for v in hdr.get_zooms())
     am = asd = None
     for model_name in sorted(models, key=lambda m: m != "total"):
@@ -40,20 +44,32 @@ def compute_measurements(ct_path: pathlib.Path, segmentation_folder: pathlib.Pat
         if not np.isclose(spacing, tuple(float(v) for v in shdr.get_zooms())).all():
             raise ValueError("The spacing of the image and of the segmentation should be the same")
         label_map = label_maps.measurement_label_map(model_name)
-        seg_zyx = np.ascontiguousarray(seg.transpose(2, 1, 0))
-        if model_name == "total":
-            meas, fat_mask = M.total_measurements(ctx, ct.astype(np.int16), seg_zyx, label_map, spacing,
-                                                  cnr_adjustment=cnr_adjustment)
-            measurements["segmentations"].update(meas["segmentations"])
-            if "cnr_adjusted" in meas:
-                measurements["cnr_adjusted"] = meas["cnr_adjusted"]
-            am, asd = meas["info"].get("autochthon_mean"), meas["info"].get("autochthon_std")
-            nifti.save(segmentation_folder / "ct_pfav.nii.gz", np.ascontiguousarray(fat_mask.transpose(2, 1, 0)), saff, like=shdr)
-        else:
-            if cnr_adjustment and model_name in label_maps.cnr_adjusted_regions():
-                raise NotImplementedError(f"CNR-adjusted measurements for {model_name!r} are not implemented on the device")
-            measurements["segmentations"][model_name] = M.metrics_for_each_region(
-                ctx, ct.astype(np.int16), seg_zyx, label_map, am, asd, spacing)
+        d_sfile = DevArray.from_numpy(ctx, np.ascontiguousarray(seg, dtype=np.uint8))
+        d_seg = d_sfile.transpose((2, 1, 0)).contiguous(force_copy=True)
+        d_sfile.free()
+        try:
+            if d_seg.shape != d_ct.shape:
+                raise ValueError("The spacing of the image and of the segmentation should be the same")
+            if model_name == "total":
+                meas, d_mask = M.total_measurements(ctx, None, None, label_map, spacing, cnr_adjustment=cnr_adjustment,
+                                                    d_ct=d_ct.buf, d_lab=d_seg.buf, shape=d_ct.shape, mask_on_device=True)
+                measurements["segmentations"].update(meas["segmentations"])
+                if "cnr_adjusted" in meas:
+                    measurements["cnr_adjusted"] = meas["cnr_adjusted"]
+                am, asd = meas["info"].get("autochthon_mean"), meas["info"].get("autochthon_std")
+                fat = DevArray(ctx, d_mask, d_ct.shape, np.uint8)
+                try:
+                    nifti.save(segmentation_folder / "ct_pfav.nii.gz", fat.transpose((2, 1, 0)).download(), saff, like=shdr)
+                finally:
+                    fat.free()
+            else:
+                if cnr_adjustment and model_name in label_maps.cnr_adjusted_regions():
+                    raise NotImplementedError(f"CNR-adjusted measurements for {model_name!r} are not implemented on the device")
+                hist = M.label_hu_histogram(ctx, d_ct.buf, d_seg.buf, d_ct.size)
+                measurements["segmentations"][model_name] = M._metrics_from_hist(hist, label_map, am, asd, spacing)
+        finally:
+            d_seg.free()
+    d_ct.free()
     measurements["info"]["autochthon_mean"] = am
     measurements["info"]["autochthon_std"] = asd
     return measurements

@@ -161,17 +161,25 @@ def _metrics_from_hist(hist, label_map, am, asd, spacing):
     return res
 
 
-def total_measurements(ctx: Context, ct: np.ndarray, total_seg: np.ndarray, label_map: Dict[str, int], spacing,
-                       cnr_adjustment: bool = True, model_name: str = "total") -> Tuple[dict, np.ndarray]:
-    """compute_measurements (:244-343) for models == ["total"] on arrays.  Returns (measurements dict, ct_pfav mask)."""
-    if ct.shape != total_seg.shape:
-        raise ValueError("The spacing of the image and of the segmentation should be the same")  # shape contract
-    shape, n = ct.shape, ct.size
+def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Optional[np.ndarray], label_map: Dict[str, int],
+                       spacing, cnr_adjustment: bool = True, model_name: str = "total", d_ct: Optional[DeviceBuffer] = None,
+                       d_lab: Optional[DeviceBuffer] = None, shape=None, mask_on_device: bool = False):
+    """compute_measurements (:244-343) for models == ["total"] on (z,y,x) arrays.  Returns (measurements dict, ct_pfav
+    mask).  Resident inputs: pass `d_ct` (int16) / `d_lab` (uint8) + `shape` instead of the host arrays (not freed here);
+    `mask_on_device=True` returns the mask as a DeviceBuffer (caller frees)."""
+    own = d_ct is None
+    if own:
+        if ct.shape != total_seg.shape:
+            raise ValueError("The spacing of the image and of the segmentation should be the same")  # shape contract
+        shape = ct.shape
+        d_ct = ctx.from_numpy(np.ascontiguousarray(ct, dtype=np.int16))
+        d_lab = ctx.from_numpy(np.ascontiguousarray(total_seg, dtype=np.uint8))
+    shape = tuple(int(v) for v in shape)
+    n = int(np.prod(shape))
     ml = np.prod(spacing) / 1000.0
     meas: Dict[str, Any] = {"segmentations": {}, "info": {}}
-    d_ct = ctx.from_numpy(np.ascontiguousarray(ct, dtype=np.int16))
-    d_lab = ctx.from_numpy(np.ascontiguousarray(total_seg, dtype=np.uint8))
     d_m, d_e, d_t = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    keep_mask = None
     try:
         hist = label_hu_histogram(ctx, d_ct, d_lab, n)
         # autochthon reference: (left | right) minus fat, eroded (:42-58)
@@ -197,7 +205,13 @@ def total_measurements(ctx: Context, ct: np.ndarray, total_seg: np.ndarray, labe
             pf[f"ct_pfav_lobe_{side}"] = fat_metrics([nm for nm in LUNG_MASKS if nm.endswith(side)])
         pf["ct_pfav_lungs"] = fat_metrics(LUNG_MASKS)
         label_hu_mask(ctx, d_ct, d_lab, [label_map[nm] for nm in LUNG_MASKS], 1, n, d_m)
-        fat_mask = d_m.download(shape, np.uint8)
+        if mask_on_device:
+            keep_mask = ctx.alloc(n)
+            check(ctx.lib.boa_copy3(ctx.h, d_m.vp, 0, 0, (C.c_longlong * 3)(0, 0, 1), (C.c_int * 3)(1, 1, n), keep_mask.vp, 0, 0,
+                                    (C.c_longlong * 3)(0, 0, 1)), "boa_copy3")
+            fat_mask = keep_mask
+        else:
+            fat_mask = d_m.download(shape, np.uint8)
         meas["segmentations"][model_name] = {**seg, **pf}
         if cnr_adjustment and model_name in CNR_ADJUSTED_REGIONS:
             if am is not None and asd is not None:
@@ -217,7 +231,8 @@ def total_measurements(ctx: Context, ct: np.ndarray, total_seg: np.ndarray, labe
                 meas.setdefault("cnr_adjusted", {}).update(adj)
         meas["info"]["autochthon_mean"] = am
         meas["info"]["autochthon_std"] = asd
+        keep_mask = None
         return meas, fat_mask
     finally:
-        for b in (d_ct, d_lab, d_m, d_e, d_t):
+        for b in ((d_ct, d_lab) if own else ()) + (d_m, d_e, d_t) + ((keep_mask,) if keep_mask is not None else ()):
             b.free()

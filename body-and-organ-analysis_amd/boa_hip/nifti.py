@@ -125,6 +125,12 @@ def load(path) -> Tuple[np.ndarray, np.ndarray, NiftiHeader]:
     return data.astype(dt.newbyteorder("=")), best_affine(h), h
 
 
+def is_scaled(h: NiftiHeader) -> bool:
+    """True when get_fdata() would apply scl_slope / scl_inter."""
+    s, i = h.scl_slope, h.scl_inter
+    return bool(np.isfinite(s) and s != 0 and not (s == 1.0 and (i == 0 or not np.isfinite(i))))
+
+
 def fdata(data: np.ndarray, h: NiftiHeader) -> np.ndarray:
     """nibabel's get_fdata(): float64 with scl_slope / scl_inter applied when they are set."""
     out = data.astype(np.float64)
