@@ -7,6 +7,9 @@ forwards), Gaussian-weighted fp16 accumulation, normalise + argmax + part->globa
 resident in HBM when the timed region starts and the uint8 label volume stays in HBM (PCIe-inclusive rate: see
 DESIGN.md).  One "step" = one whole volume.  Multi-GPU: one process per GPU, every rank segments its own volume
 (volume-level sharding, no data-path collective) -> weak scaling; value = all volumes / max-over-ranks time.
+`--shard tiles` instead lets the N GPUs share every volume (tile rows split across ranks, overlap slabs of the fp16
+accumulators over RCCL, boa_hip/tile_shard.py): strong scaling, the latency mode; not the default because whole volumes
+are the cheaper way to fill a node.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--batch 4] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -72,6 +75,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=4)
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events (measures their overhead; roofline fields become 0)")
+    ap.add_argument("--shard", choices=["volumes", "tiles"], default="volumes",
+                    help="N>1: 'volumes' = one volume per GPU, no data-path collective (weak scaling, default); 'tiles' = all "
+                         "GPUs share each volume: tile rows split, overlap slabs over RCCL (strong scaling, latency mode)")
+    ap.add_argument("--shard-mode", choices=["exact", "allreduce"], default="exact",
+                    help="--shard tiles: ordered send/recv hand-over (bit-exact) or pairwise fp16 all-reduce of the slabs")
     ap.add_argument("--dump", type=str, default=None, help="write per-kernel-class timings to this JSON file")
     args = ap.parse_args()
 
@@ -102,7 +110,11 @@ def main():
         p.set_parameters([blob])
         p._ensure_net(0)
         predictors.append((tid, cfg, p))
-    ct = synthetic.ct_phantom(shape, seed=20260928 + rank)
+    tile_shard = None
+    if dist is not None and args.shard == "tiles":
+        from boa_hip import tile_shard as ts
+        tile_shard = ts.TileShard(ts.ShardComm(dist, rank, world, f"cuda:{local_rank}"), args.shard_mode)
+    ct = synthetic.ct_phantom(shape, seed=20260928 + (0 if tile_shard else rank))
     log(f"setup (synthetic weights + phantom {shape}) {time.perf_counter() - t0:.1f}s")
     nvox = int(np.prod(shape))
     d_ct = ctx.from_numpy(ct)
@@ -125,7 +137,8 @@ def main():
                                        ip["percentile_99_5"]))
         d_lab.zero()
         for tid, cfg, p in predictors:
-            p.predict_segmentation_device(d_vol, shape, d_lab, lut=label_maps.part_lut(tid), merge=True, work=work)
+            p.predict_segmentation_device(d_vol, shape, d_lab, lut=label_maps.part_lut(tid), merge=True, work=work,
+                                          shard=tile_shard)
 
     def barrier():
         ctx.sync()
@@ -164,11 +177,13 @@ def main():
         log(f"  sum of kernel times {total_ms:.1f} ms of {elapsed * 1e3:.1f} ms wall; label checksum {labels_sum}")
         res = {
             "metric": "CT volumes/sec (512^3 @1.5 mm, total) on MI355X",
-            "value": n_gpus * args.steps / elapsed, "unit": "volumes/s", "n_gpus": n_gpus, "steps": args.steps,
+            "value": (1 if tile_shard else n_gpus) * args.steps / elapsed, "unit": "volumes/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "strong" if tile_shard else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"configs[1]: single {shape[0]}x{shape[1]}x{shape[2]} @1.5 mm volume, `total` "
-                                   f"(5 part models, {tiles_per_volume} tile forwards of 128^3, step 0.8), 1 volume per GPU",
+                                   f"(5 part models, {tiles_per_volume} tile forwards of 128^3, step 0.8), " +
+                                   (f"each volume tile-sharded over {n_gpus} GPUs ({args.shard_mode} slab exchange)"
+                                    if tile_shard else "1 volume per GPU"),
                        "tiles_per_volume": tiles_per_volume, "tile_batch": args.batch,
                        "tflop_per_volume": flops_per_volume / 1e12,
                        "precision": "fp16 activations/weights, fp32 MFMA accumulate, fp16 logit accumulators (reference semantics)"},

@@ -54,6 +54,10 @@ _PROTOS = {
     "boa_ct_normalize": (i32, [vp, vp, i32, vp, u64, f32, f32, f32, f32]),
     "boa_accumulate_tile": (i32, [vp, vp, vp, vp, vp, i32, ip, ip, ip]),
     "boa_finalize_labels": (i32, [vp, vp, vp, i32, ip, vp, i32, i32, i32, vp, i32, vp, ip, ip, vp]),
+    "boa_finalize_labels_planes": (i32, [vp, vp, vp, i32, ip, vp, i32, i32, i32, vp, i32, vp, ip, ip, vp, i32, i32]),
+    "boa_net_predict_sliding_window_deferred": (i32, [vp, vp, ip, ip, ip, ip, i32, vp, vp, vp, ip, C.POINTER(vp)]),
+    "boa_net_apply_deferred": (i32, [vp, vp, vp, vp, vp, ip]),
+    "boa_stash_destroy": (None, [vp]),
     "boa_net_create": (i32, [vp, C.POINTER(NetDesc), vp, u64, i32, i32, C.POINTER(vp)]),
     "boa_net_destroy": (None, [vp]),
     "boa_net_weight_count": (u64, [C.POINTER(NetDesc)]),
@@ -73,6 +77,7 @@ _PROTOS = {
     "boa_label_select": (i32, [vp, vp, u64, i32, ip, vp]),
     "boa_fill_holes_2d": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "boa_mask_assign": (i32, [vp, vp, u64, i32, i32, vp]),
+    "boa_label_overlay": (i32, [vp, vp, u64, vp]),
     "boa_median3_inplane": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "boa_copy3": (i32, [vp, vp, i32, C.c_longlong, C.POINTER(C.c_longlong), ip, vp, i32, C.c_longlong, C.POINTER(C.c_longlong)]),
     "boa_nonzero_bbox": (i32, [vp, vp, i32, ip, ip]),

@@ -167,9 +167,13 @@ class HipPredictor:
         return pred
 
     def predict_segmentation_device(self, dvol: DeviceBuffer, V, labels_out: DeviceBuffer, lut: Optional[np.ndarray] = None,
-                                    merge: bool = False, work: Optional[dict] = None):
+                                    merge: bool = False, work: Optional[dict] = None, shard=None):
         """All folds -> labels on device.  dvol: fp32 [Cin,*V] resident; labels_out: uint8 [*V] resident (updated in
-        place when merge=True).  `work` may carry preallocated acc / n / fold buffers to reuse across models."""
+        place when merge=True).  `work` may carry preallocated acc / n / fold buffers to reuse across models.
+        `shard` (tile_shard.TileShard): this volume is shared by the ranks of shard.comm -- every rank holds the volume,
+        runs its block of tile rows, exchanges the overlap slabs and ends with the same labels_out."""
+        if shard is not None and shard.comm.world > 1:
+            return self._predict_segmentation_sharded(dvol, V, labels_out, lut, merge, work, shard)
         PV, below = sw.pad_amounts(V, self.geom.patch_size)
         origins = sw.get_sliding_window_origins(PV, self.geom.patch_size, self.tile_step_size)
         C_ = self.geom.num_classes
@@ -207,6 +211,65 @@ class HipPredictor:
                 int3(V) if crop else None, flag.vp), "boa_finalize_labels")
         if int(flag.download((1,), np.int32)[0]):
             raise RuntimeError("Encountered inf in predicted array. Aborting...")
+        if own:
+            for b in work.values():
+                b.free()
+
+    def _predict_segmentation_sharded(self, dvol, V, labels_out, lut, merge, work, shard):
+        from . import tile_shard as ts
+        PV, below = sw.pad_amounts(V, self.geom.patch_size)
+        origins = sw.get_sliding_window_origins(PV, self.geom.patch_size, self.tile_step_size)
+        plan = ts.plan_rows(origins, self.geom.patch_size[0], PV[0], shard.comm.world)
+        C_, nvox, nv = self.geom.num_classes, int(np.prod(PV)), int(np.prod(V))
+        nf = len(self.list_of_parameters)
+        own = work is None
+        work = work if work is not None else {}
+
+        def buf(name, nbytes):
+            b = work.get(name)
+            if b is None or b.nbytes < nbytes:
+                if b is not None:
+                    b.free()
+                b = self.ctx.alloc(nbytes)
+                work[name] = b
+            return b
+
+        acc, nacc = buf("acc", C_ * nvox * 2), buf("n", nvox * 2)
+        fold = buf("fold", C_ * nvox * 2) if nf > 1 else None
+        part = buf("part", nv)
+        flag = buf("flag", 4)
+        flag.zero()
+        check(self.lib.boa_memset(self.ctx.h, part.vp, 0, nv), "boa_memset")
+        lut_arr = None
+        if lut is not None:
+            lut_arr = np.zeros(256, dtype=np.uint8)
+            lut_arr[:len(lut)] = lut
+        crop = any(b != 0 for b in below) or list(PV) != list(V)
+        for f in range(nf):
+            self._ensure_net(f)
+            eng = ts.HipShardEngine(self, shard.comm, dvol, V, PV, below, origins, acc, nacc)
+            try:
+                lo, hi = ts.run_fold_sharded(eng, plan, shard.comm, shard.mode)
+            finally:
+                eng.close()
+            last = f == nf - 1
+            check(self.lib.boa_finalize_labels_planes(
+                self.ctx.h, acc.vp, nacc.vp, C_, int3(PV), fold.vp if fold else None, 0 if f == 0 else 1,
+                nf if (last and fold) else 0, 0, lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None,
+                0, part.vp if last else None, int3(below) if crop else None, int3(V) if crop else None, flag.vp, lo, hi),
+                "boa_finalize_labels_planes")
+        bad = int(flag.download((1,), np.int32)[0])
+        ts.all_reduce_labels(self.ctx, shard.comm, part, nv)
+        import torch
+        t = torch.tensor([bad], dtype=torch.int32, device=shard.comm.device)
+        shard.comm.all_reduce_sum(t)
+        if int(t.item()):
+            raise RuntimeError("Encountered inf in predicted array. Aborting...")
+        if merge:
+            check(self.lib.boa_label_overlay(self.ctx.h, part.vp, nv, labels_out.vp), "boa_label_overlay")
+        else:
+            one, st = (C.c_int * 3)(1, 1, nv), (C.c_longlong * 3)(0, 0, 1)
+            check(self.lib.boa_copy3(self.ctx.h, part.vp, 0, 0, st, one, labels_out.vp, 0, 0, st), "boa_copy3")
         if own:
             for b in work.values():
                 b.free()

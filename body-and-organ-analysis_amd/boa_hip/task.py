@@ -94,6 +94,9 @@ class SegmentationTask:
                 lut = None
             self.parts.append((task_id, cfg, p, lut))
         self._work: Dict[str, object] = {}
+        # tile_shard.TileShard: several ranks share every volume (tile rows split, overlap slabs exchanged); each rank
+        # must be given the same input and ends with the same labels.  None = this process handles whole volumes.
+        self.shard = None
 
     def close(self):
         for _, _, p, _ in self.parts:
@@ -118,7 +121,8 @@ class SegmentationTask:
             # every model normalises with its own plans' intensity properties (default_preprocessor.py:336-348)
             check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, in_dtype, vol.vp, n, ip["mean"], ip["std"],
                                            ip["percentile_00_5"], ip["percentile_99_5"]), "boa_ct_normalize")
-            p.predict_segmentation_device(vol, list(shape), d_labels, lut=lut, merge=self.multimodel, work=self._work)
+            p.predict_segmentation_device(vol, list(shape), d_labels, lut=lut, merge=self.multimodel, work=self._work,
+                                          shard=self.shard)
 
     def _check_plan_spacing(self, spacing_xyz):
         sp_zyx = [float(s) for s in spacing_xyz[::-1]]

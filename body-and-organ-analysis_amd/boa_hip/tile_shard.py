@@ -1,0 +1,333 @@
+"""One volume on several GPUs: the tiles of the sliding-window predictor and the Gaussian-weighted aggregation buffer are
+partitioned across the ranks of one node, the overlap regions travel over RCCL / xGMI (granularity 3).
+
+Partition.  The tile grid of `_internal_get_sliding_window_slicers` (NN/inference/predict_from_raw_data.py:523-558) is
+ordered axis 0 outermost, and the reference adds tile after tile into fp16 buffers (:611-614), so per voxel the rounding
+sequence is "ascending tile index".  Ranks therefore own BLOCKS OF TILE ROWS along axis 0: every tile of rank r precedes
+every tile of rank r+1, and only the slab where the last row of r and the first row of r+1 overlap (patch - step planes,
+32 of 128 at step 0.8) is touched by both.
+
+Two exchange modes:
+
+* ``exact`` (default) -- rank r+1 does not add the slab planes of its first-row tiles at once; it keeps their head input
+  (boa_net_predict_sliding_window_deferred), receives rank r's finished partial sums for the slab (one send/recv per
+  boundary, all boundaries concurrently on distinct xGMI links), and then adds the kept planes in tile order
+  (boa_net_apply_deferred).  Per voxel the fp16 `+=` sequence is the reference's: labels AND logits are bit-identical
+  to the single-GPU loop.  No rank waits for more than its direct neighbour: the slab a rank sends never contains
+  planes it deferred (plan_rows checks that blocks two apart do not overlap).
+* ``allreduce`` -- every rank accumulates all of its tiles from zero and the two partial sums of each slab are added by a
+  2-rank RCCL all-reduce in fp16.  One rounding differs from the reference's sequence (P + Q instead of adding Q's tiles
+  one by one), so labels can flip where two logits are within an fp16 ulp; the GPU test reports the flip fraction.
+
+After the exchange each rank owns a disjoint range of axis-0 planes: it runs normalise + argmax + remap on those planes
+only (boa_finalize_labels_planes), and one uint8 all-reduce (sum over disjoint supports) hands every rank the part's label
+volume, which is then merged into the combined volume in part order (TS/nnunet.py:553-556) identically on all ranks.
+
+The protocol (`run_fold_sharded`) is written against a small engine interface so that the CPU tests drive it over gloo
+with a numpy engine; `HipShardEngine` is the product engine on top of the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import check, int3
+
+
+# ---------------------------------------------------------------------------------------------------- plan
+@dataclass
+class RowPlan:
+    rows: List[int]                    # sorted axis-0 tile starts
+    blocks: List[Tuple[int, int]]      # per active rank: row indices [b0, b1)
+    patch0: int
+    pv0: int
+    row_of_tile: np.ndarray            # [n_tiles] row index of every tile (canonical order)
+
+    @property
+    def active(self) -> int:
+        return len(self.blocks)
+
+    def tiles(self, rank: int) -> np.ndarray:
+        """Indices (canonical order kept) of the tiles of `rank`."""
+        if rank >= self.active:
+            return np.zeros(0, dtype=np.int64)
+        b0, b1 = self.blocks[rank]
+        return np.nonzero((self.row_of_tile >= b0) & (self.row_of_tile < b1))[0]
+
+    def boundary(self, k: int) -> Optional[Tuple[int, int]]:
+        """Planes [lo, hi) shared by rank k (its last row) and rank k+1 (its first row); None if they do not overlap."""
+        if k < 0 or k + 1 >= self.active:
+            return None
+        first_upper = self.blocks[k + 1][0]
+        lo, hi = self.rows[first_upper], self.rows[first_upper - 1] + self.patch0
+        return (lo, hi) if hi > lo else None
+
+    def owned_planes(self, rank: int) -> Tuple[int, int]:
+        """Planes whose sums are complete on `rank` after the exchange (a partition of [0, pv0))."""
+        if rank >= self.active:
+            return (0, 0)
+        lo = 0 if rank == 0 else self.rows[self.blocks[rank][0]]
+        hi = self.pv0 if rank == self.active - 1 else self.rows[self.blocks[rank + 1][0]]
+        return (lo, hi)
+
+    def defer_planes(self, rank: int) -> np.ndarray:
+        """Per tile of `rank`: number of leading planes that must wait for the lower rank (exact mode) = the part of
+        the tile below the end of the lower rank's last row (normally only the first row of the block reaches it)."""
+        t = self.tiles(rank)
+        out = np.zeros(len(t), dtype=np.int32)
+        b = self.boundary(rank - 1)
+        if b is not None:
+            starts = np.asarray(self.rows)[self.row_of_tile[t]]
+            out[:] = np.clip(b[1] - starts, 0, self.patch0)
+        return out
+
+
+def plan_rows(origins: np.ndarray, patch0: int, pv0: int, world: int) -> RowPlan:
+    """Contiguous, balanced blocks of tile rows for at most `world` ranks.  The number of active ranks is reduced until
+    blocks two apart do not overlap (small volumes, where the actual step can fall to 0.4 * patch)."""
+    origins = np.asarray(origins).reshape(-1, 3)
+    rows = sorted(set(int(v) for v in origins[:, 0]))
+    row_of_tile = np.searchsorted(np.asarray(rows), origins[:, 0]).astype(np.int64)
+    if np.any(np.diff(row_of_tile) < 0):
+        raise ValueError("tile origins must be in canonical (axis 0 outermost) order")
+    for a in range(max(1, min(world, len(rows))), 0, -1):
+        q, r = divmod(len(rows), a)
+        blocks, lo = [], 0
+        for i in range(a):
+            hi = lo + q + (1 if i < r else 0)
+            blocks.append((lo, hi))
+            lo = hi
+        # blocks two apart must not overlap: then the slab a rank sends up never contains planes it deferred itself
+        if all(rows[blocks[i][1] - 1] + patch0 <= rows[blocks[i + 2][0]] for i in range(a - 2)):
+            return RowPlan(rows, blocks, int(patch0), int(pv0), row_of_tile)
+    raise AssertionError("unreachable: one block is always valid")
+
+
+# ---------------------------------------------------------------------------------------------------- transport
+class ShardComm:
+    """torch.distributed transport for the slabs ("nccl" = RCCL with device tensors, "gloo" with host tensors)."""
+
+    def __init__(self, dist, rank: int, world: int, device: str = "cpu"):
+        self.dist, self.rank, self.world, self.device = dist, int(rank), int(world), device
+        self._pairs = None
+
+    @property
+    def on_device(self) -> bool:
+        return str(self.device).startswith("cuda")
+
+    def empty(self, shape, dtype):
+        import torch
+        return torch.empty(tuple(int(s) for s in shape), dtype=dtype, device=self.device)
+
+    def _done(self):
+        if self.on_device:
+            import torch
+            torch.cuda.synchronize()
+
+    def shift_up(self, send, recv):
+        """send -> rank+1, recv <- rank-1 (either may be None); every boundary moves at the same time."""
+        ops = []
+        if send is not None:
+            ops.append(self.dist.P2POp(self.dist.isend, send, self.rank + 1))
+        if recv is not None:
+            ops.append(self.dist.P2POp(self.dist.irecv, recv, self.rank - 1))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+            self._done()
+
+    def pair_group(self, k: int):
+        """Group of ranks {k, k+1}; created collectively (every rank creates every pair, in the same order)."""
+        if self._pairs is None:
+            self._pairs = [self.dist.new_group([i, i + 1]) for i in range(self.world - 1)]
+        return self._pairs[k]
+
+    def pair_all_reduce(self, k: int, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.pair_group(k))
+        self._done()
+
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self._done()
+
+
+# ---------------------------------------------------------------------------------------------------- protocol
+def run_fold_sharded(engine, plan: RowPlan, comm: ShardComm, mode: str = "exact") -> Tuple[int, int]:
+    """One fold of one model on this rank.  Engine interface:
+         begin()                         zero the accumulators
+         run(tile_idx, defer) -> stash   forward + accumulate this rank's tiles; `defer[i]` leading planes kept back
+         pack(lo, hi) -> tensor          planes [lo, hi) of (acc channels..., n) as one fp16 tensor on comm.device
+         empty(lo, hi) -> tensor         receive buffer of the same shape
+         unpack(lo, hi, tensor)          overwrite those planes
+         apply(stash)                    add the kept planes in tile order
+       Returns the planes this rank owns afterwards."""
+    if mode not in ("exact", "allreduce"):
+        raise ValueError(f"unknown tile-shard mode {mode!r}")
+    r = comm.rank
+    if mode == "allreduce" and comm.world > 1:
+        comm.pair_group(0)  # collective creation, also on idle ranks
+    engine.begin()
+    if r >= plan.active:
+        return (0, 0)
+    tiles = plan.tiles(r)
+    lower, upper = plan.boundary(r - 1), plan.boundary(r)
+    if mode == "exact":
+        stash = engine.run(tiles, plan.defer_planes(r))
+        send = engine.pack(*upper) if upper else None
+        recv = engine.empty(*lower) if lower else None
+        comm.shift_up(send, recv)
+        if lower:
+            engine.unpack(lower[0], lower[1], recv)
+        engine.apply(stash)
+    else:
+        engine.run(tiles, np.zeros(len(tiles), dtype=np.int32))
+        for parity in (0, 1):                     # a rank sits in at most one boundary of each parity
+            for k, slab in ((r - 1, lower), (r, upper)):
+                if slab is None or k % 2 != parity:
+                    continue
+                t = engine.pack(*slab)
+                comm.pair_all_reduce(k, t)
+                if k == r - 1:                     # the upper rank owns the slab
+                    engine.unpack(slab[0], slab[1], t)
+    return plan.owned_planes(r)
+
+
+# ---------------------------------------------------------------------------------------------------- product engine
+class _Foreign:
+    """Non-owning view of device memory that belongs to a torch tensor (same attributes as DeviceBuffer)."""
+
+    def __init__(self, tensor):
+        self._keep = tensor
+        self.ptr = tensor.data_ptr()
+        self.nbytes = tensor.numel() * tensor.element_size()
+
+    @property
+    def vp(self):
+        return C.c_void_p(self.ptr)
+
+    def free(self):
+        pass
+
+
+class HipShardEngine:
+    """Engine over one HipPredictor fold: acc fp16 [C][PV] and n fp16 [PV] resident on this rank's GPU."""
+
+    def __init__(self, predictor, comm: ShardComm, dvol, V, PV, below, origins, acc, nacc):
+        self.p, self.comm = predictor, comm
+        self.ctx, self.lib = predictor.ctx, predictor.lib
+        self.dvol, self.V, self.PV, self.below = dvol, list(V), list(PV), list(below)
+        self.origins = np.ascontiguousarray(origins, dtype=np.int32).reshape(-1, 3)
+        self.acc, self.nacc = acc, nacc
+        self.C = predictor.geom.num_classes
+        self._stage = None
+
+    def begin(self):
+        self.acc.zero()
+        self.nacc.zero()
+
+    def run(self, tile_idx, defer):
+        org = np.ascontiguousarray(self.origins[np.asarray(tile_idx, dtype=np.int64)], dtype=np.int32)
+        defer = np.ascontiguousarray(defer, dtype=np.int32)
+        g = self.p._gaussian()
+        st = C.c_void_p()
+        if len(org) == 0:
+            return None
+        check(self.lib.boa_net_predict_sliding_window_deferred(
+            self.p._net, self.dvol.vp, int3(self.V), int3(self.PV), int3(self.below), org.ctypes.data_as(C.POINTER(C.c_int)),
+            len(org), g.vp if g else None, self.acc.vp, self.nacc.vp, defer.ctypes.data_as(C.POINTER(C.c_int)), C.byref(st)),
+            "boa_net_predict_sliding_window_deferred")
+        return st
+
+    def apply(self, stash):
+        if stash is None:
+            return
+        try:
+            g = self.p._gaussian()
+            check(self.lib.boa_net_apply_deferred(self.p._net, stash, g.vp if g else None, self.acc.vp, self.nacc.vp,
+                                                  int3(self.PV)), "boa_net_apply_deferred")
+        finally:
+            self.lib.boa_stash_destroy(stash)
+
+    # ---- slabs: (C + 1) x planes x PV1*PV2 halves, packed by the strided device copy ---------------------------------
+    def _move(self, lo, hi, flat, to_flat: bool):
+        pl, plane = hi - lo, self.PV[1] * self.PV[2]
+        vv = self.PV[0] * plane
+        ll3 = lambda *v: (C.c_longlong * 3)(*v)  # noqa: E731
+        for buf, ch, off in ((self.acc, self.C, 0), (self.nacc, 1, self.C * pl * plane)):
+            dims = (C.c_int * 3)(ch, pl, plane)
+            if to_flat:
+                check(self.lib.boa_copy3(self.ctx.h, buf.vp, 1, lo * plane, ll3(vv, plane, 1), dims, flat.vp, 1, off,
+                                         ll3(pl * plane, plane, 1)), "boa_copy3")
+            else:
+                check(self.lib.boa_copy3(self.ctx.h, flat.vp, 1, off, ll3(pl * plane, plane, 1), dims, buf.vp, 1, lo * plane,
+                                         ll3(vv, plane, 1)), "boa_copy3")
+
+    def _staging(self, nbytes):
+        if self._stage is None or self._stage.nbytes < nbytes:
+            if self._stage is not None:
+                self._stage.free()
+            self._stage = self.ctx.alloc(nbytes)
+        return self._stage
+
+    def empty(self, lo, hi):
+        import torch
+        return self.comm.empty((self.C + 1, hi - lo, self.PV[1], self.PV[2]), torch.float16)
+
+    def pack(self, lo, hi):
+        import torch
+        t = self.empty(lo, hi)
+        shape = tuple(t.shape)
+        if self.comm.on_device:
+            self._move(lo, hi, _Foreign(t), True)
+            self.ctx.sync()
+        else:
+            st = self._staging(t.numel() * 2)
+            self._move(lo, hi, st, True)
+            t.view(torch.int16).numpy()[...] = st.download(shape, np.int16)
+        return t
+
+    def unpack(self, lo, hi, t):
+        import torch
+        if self.comm.on_device:
+            self._move(lo, hi, _Foreign(t), False)
+            self.ctx.sync()
+        else:
+            st = self._staging(t.numel() * 2)
+            st.upload(t.view(torch.int16).numpy())
+            self._move(lo, hi, st, False)
+
+    def close(self):
+        if self._stage is not None:
+            self._stage.free()
+            self._stage = None
+
+
+def all_reduce_labels(ctx, comm: ShardComm, buf, n: int):
+    """Sum of uint8 label volumes with disjoint supports, in place in the device buffer `buf` (n voxels)."""
+    import torch
+    if comm.world == 1:
+        return
+    if comm.on_device:
+        t = comm.empty((n,), torch.uint8)
+        one = (C.c_int * 3)(1, 1, n)
+        st = (C.c_longlong * 3)(0, 0, 1)
+        f = _Foreign(t)
+        check(ctx.lib.boa_copy3(ctx.h, buf.vp, 0, 0, st, one, f.vp, 0, 0, st), "boa_copy3")
+        ctx.sync()
+        comm.all_reduce_sum(t)
+        check(ctx.lib.boa_copy3(ctx.h, f.vp, 0, 0, st, one, buf.vp, 0, 0, st), "boa_copy3")
+        ctx.sync()
+    else:
+        t = torch.from_numpy(buf.download((n,), np.uint8))
+        comm.all_reduce_sum(t)
+        buf.upload(t.numpy())
+
+
+@dataclass
+class TileShard:
+    """What `HipPredictor.predict_segmentation_device(..., shard=...)` needs: the transport and the exchange mode."""
+    comm: ShardComm
+    mode: str = "exact"

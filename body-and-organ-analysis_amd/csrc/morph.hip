@@ -162,6 +162,22 @@ extern "C" int boa_mask_assign(boa_ctx* c, const uint8_t* dev_mask, size_t n, in
     return BOA_OK;
 }
 
+__global__ __launch_bounds__(256) void k_label_overlay(const unsigned char* __restrict__ part, size_t n,
+                                                       unsigned char* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char v = part[i];
+    if (v) out[i] = v;
+}
+
+extern "C" int boa_label_overlay(boa_ctx* c, const uint8_t* dev_part, size_t n, uint8_t* dev_out) {
+    BOA_REQUIRE(c && dev_part && dev_out, "boa_label_overlay: NULL argument");
+    if (n == 0) return BOA_OK;
+    hipLaunchKernelGGL(k_label_overlay, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_part, n, dev_out);
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // boa_copy3: strided 3-D gather copy with dtype conversion -- the device form of the index remaps around a task
 // (TS/alignment.py reorientation = axis permutation + flips, TS/cropping.py crop / un-crop, the (x,y,z) <-> (z,y,x)

@@ -485,6 +485,121 @@ extern "C" int boa_net_predict_sliding_window(boa_net* net, const float* dev_vol
 }
 
 // ------------------------------------------------------------------------------------------------------
+// tile-sharded sliding window (several GPUs on one volume): the rank that owns tile rows [b0, b1) along
+// axis 0 cannot add the first `defer` planes of its row-b0 tiles before the lower rank's partial sums for those
+// planes have arrived (the reference's fp16 `+=` runs in ascending tile order per voxel).  The head input of those
+// planes is kept in a stash and applied afterwards; everything else is accumulated at once.
+struct boa_stash {
+    boa_ctx* ctx = nullptr;
+    unsigned char* arena = nullptr;
+    struct Item {
+        size_t act_off, ss_off;
+        int planes;
+        int start[3];
+    };
+    std::vector<Item> items;
+};
+
+extern "C" void boa_stash_destroy(boa_stash* st) {
+    if (!st) return;
+    if (st->arena) boa_free(st->ctx, st->arena);
+    delete st;
+}
+
+extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float* dev_volume, const int V[3],
+                                                       const int PV[3], const int* vol_off, const int* host_origins,
+                                                       int n_tiles, const uint16_t* dev_gauss, uint16_t* dev_acc,
+                                                       uint16_t* dev_n, const int* host_defer_planes,
+                                                       boa_stash** stash_out) {
+    BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_acc && dev_n && host_defer_planes && stash_out,
+                "boa_net_predict_sliding_window_deferred: NULL argument");
+    const boa_net_desc& d = net->d;
+    const int zero[3] = {0, 0, 0};
+    const int* off = vol_off ? vol_off : zero;
+    for (int a = 0; a < 3; ++a)
+        BOA_REQUIRE(PV[a] >= d.patch[a] && off[a] >= 0 && off[a] + V[a] <= PV[a],
+                    "sliding window: padded dim %d (%d) must cover patch (%d) and volume (%d at %d)", a, PV[a],
+                    d.patch[a], V[a], off[a]);
+    const int F = d.features[0];
+    const size_t plane = (size_t)d.patch[1] * d.patch[2];
+    const size_t pv = (size_t)d.patch[0] * plane;
+    boa_stash* st = new boa_stash;
+    st->ctx = net->ctx;
+    size_t bytes = 0;
+    for (int i = 0; i < n_tiles; ++i) {
+        int dp = host_defer_planes[i];
+        if (dp < 0 || dp > d.patch[0]) {
+            delete st;
+            BOA_REQUIRE(false, "deferred sliding window: tile %d defers %d planes of %d", i, dp, d.patch[0]);
+        }
+        if (dp == 0) continue;
+        boa_stash::Item it;
+        it.act_off = bytes;
+        bytes += ((size_t)dp * plane * F * 2 + 255) / 256 * 256;
+        it.ss_off = bytes;
+        bytes += 256 * ((F * 2 * 4 + 255) / 256);
+        it.planes = dp;
+        for (int a = 0; a < 3; ++a) it.start[a] = host_origins[(size_t)i * 3 + a];
+        st->items.push_back(it);
+    }
+    int rc = bytes ? boa_malloc(net->ctx, bytes, (void**)&st->arena) : BOA_OK;
+    if (rc != BOA_OK) {
+        delete st;
+        return rc;
+    }
+    size_t item = 0;
+    for (int t0 = 0; t0 < n_tiles && rc == BOA_OK; t0 += net->maxN) {
+        int nb = std::min(net->maxN, n_tiles - t0);
+        rc = net_forward_stack(net, dev_volume, V, off, host_origins + (size_t)t0 * 3, nb);
+        ConvLayer& last = net->dec.back().back();
+        for (int i = 0; i < nb && rc == BOA_OK; ++i) {
+            const int* stt = host_origins + (size_t)(t0 + i) * 3;
+            const __half* act = last.out + (size_t)i * pv * F;
+            const float* ss = last.ss + (size_t)i * F * 2;
+            int dp = host_defer_planes[t0 + i];
+            if (dp > 0) {
+                const boa_stash::Item& it = st->items[item++];
+                if (hipMemcpyAsync(st->arena + it.act_off, act, (size_t)dp * plane * F * 2, hipMemcpyDeviceToDevice,
+                                   net->ctx->stream) != hipSuccess ||
+                    hipMemcpyAsync(st->arena + it.ss_off, ss, (size_t)F * 2 * 4, hipMemcpyDeviceToDevice,
+                                   net->ctx->stream) != hipSuccess) {
+                    boa_set_error("deferred sliding window: stash copy failed");
+                    rc = BOA_EHIP;
+                    break;
+                }
+                net->ctx->prof_break = true;
+            }
+            if (dp < d.patch[0]) {
+                int P[3] = {d.patch[0] - dp, d.patch[1], d.patch[2]};
+                int s2[3] = {stt[0] + dp, stt[1], stt[2]};
+                rc = launch_head(net->ctx, act + (size_t)dp * plane * F, ss, F, P, d.num_classes, net->head_w, net->head_b,
+                                 d.lrelu_slope, nullptr, dev_gauss ? dev_gauss + (size_t)dp * plane : nullptr, dev_acc, dev_n,
+                                 PV, s2);
+            }
+        }
+    }
+    if (rc != BOA_OK) {
+        boa_stash_destroy(st);
+        return rc;
+    }
+    *stash_out = st;
+    return BOA_OK;
+}
+
+extern "C" int boa_net_apply_deferred(boa_net* net, const boa_stash* st, const uint16_t* dev_gauss, uint16_t* dev_acc,
+                                      uint16_t* dev_n, const int PV[3]) {
+    BOA_REQUIRE(net && st && dev_acc && dev_n && PV, "boa_net_apply_deferred: NULL argument");
+    const boa_net_desc& d = net->d;
+    for (const boa_stash::Item& it : st->items) {  // the stash keeps the canonical tile order
+        int P[3] = {it.planes, d.patch[1], d.patch[2]};
+        BOA_TRY(launch_head(net->ctx, (const __half*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
+                            d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
+                            dev_acc, dev_n, PV, it.start));
+    }
+    return BOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // unit-test seams
 extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, const int dims[3],
                                    const float* host_w, const float* host_b, const float* host_gamma,

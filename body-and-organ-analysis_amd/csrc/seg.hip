@@ -96,16 +96,17 @@ struct FinalizeArgs {
     int C, V0, V1, V2;
     int fold_mode, n_folds_final, write_logits, do_argmax, merge;
     int crop, o0, o1, o2, c0, c1, c2;
+    size_t v_begin, v_count;  // flat voxel range processed (whole planes of axis 0); the channel stride stays V0*V1*V2
     unsigned char lut[256];
 };
 
 template <int VEC>
 __global__ void k_finalize_labels(FinalizeArgs a) {
     const size_t vv = (size_t)a.V0 * a.V1 * a.V2;
-    const size_t nvec = vv / VEC;
+    const size_t nvec = a.v_count / VEC;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nvec) return;
-    const size_t base = t * VEC;
+    const size_t base = a.v_begin + t * VEC;
     float nf[VEC];
     float best[VEC];
     int bidx[VEC];
@@ -229,8 +230,21 @@ extern "C" int boa_finalize_labels(boa_ctx* c, uint16_t* dev_acc, const uint16_t
                                    uint16_t* dev_fold_sum, int fold_mode, int n_folds_final, int write_logits,
                                    const uint8_t* host_lut, int merge, uint8_t* dev_labels_out, const int* crop_off,
                                    const int* crop_dims, int* dev_inf_flag) {
+    BOA_REQUIRE(V, "boa_finalize_labels: NULL argument");
+    return boa_finalize_labels_planes(c, dev_acc, dev_n, C, V, dev_fold_sum, fold_mode, n_folds_final, write_logits, host_lut,
+                                      merge, dev_labels_out, crop_off, crop_dims, dev_inf_flag, 0, V[0]);
+}
+
+extern "C" int boa_finalize_labels_planes(boa_ctx* c, uint16_t* dev_acc, const uint16_t* dev_n, int C, const int V[3],
+                                          uint16_t* dev_fold_sum, int fold_mode, int n_folds_final, int write_logits,
+                                          const uint8_t* host_lut, int merge, uint8_t* dev_labels_out,
+                                          const int* crop_off, const int* crop_dims, int* dev_inf_flag, int plane_lo,
+                                          int plane_hi) {
     BOA_REQUIRE(c && dev_acc && dev_n && V && dev_inf_flag, "boa_finalize_labels: NULL argument");
     BOA_REQUIRE(C >= 1 && C <= 255, "boa_finalize_labels: C=%d out of range", C);
+    BOA_REQUIRE(plane_lo >= 0 && plane_lo <= plane_hi && plane_hi <= V[0], "boa_finalize_labels: planes [%d,%d) of %d",
+                plane_lo, plane_hi, V[0]);
+    if (plane_lo == plane_hi) return BOA_OK;
     FinalizeArgs a;
     a.acc = dev_acc;
     a.n = dev_n;
@@ -255,8 +269,12 @@ extern "C" int boa_finalize_labels(boa_ctx* c, uint16_t* dev_acc, const uint16_t
         a.c0 = V[0]; a.c1 = V[1]; a.c2 = V[2];
     }
     for (int i = 0; i < 256; ++i) a.lut[i] = host_lut ? host_lut[i] : (unsigned char)i;
-    size_t vv = (size_t)V[0] * V[1] * V[2];
-    bool vec8 = (vv % 8 == 0) && (((uintptr_t)dev_acc | (uintptr_t)dev_n | (uintptr_t)dev_fold_sum) % 16 == 0);
+    size_t vtot = (size_t)V[0] * V[1] * V[2];
+    a.v_begin = (size_t)plane_lo * V[1] * V[2];
+    a.v_count = (size_t)(plane_hi - plane_lo) * V[1] * V[2];
+    size_t vv = a.v_count;
+    bool vec8 = (vtot % 8 == 0) && (a.v_begin % 8 == 0) && (vv % 8 == 0) &&
+                (((uintptr_t)dev_acc | (uintptr_t)dev_n | (uintptr_t)dev_fold_sum) % 16 == 0);
     int block = 256;
     double bytes = (double)vv * (2.0 * C + 2 + 1 + (write_logits ? 2.0 * C : 0) + (dev_fold_sum ? 4.0 * C : 0));
     KernelTimer t(c, BOA_K_ARGMAX, 0, bytes);

@@ -104,6 +104,12 @@ int boa_finalize_labels(boa_ctx* ctx, uint16_t* dev_acc, const uint16_t* dev_n, 
                         uint16_t* dev_fold_sum, int fold_mode, int n_folds_final, int write_logits,
                         const uint8_t* host_lut, int merge, uint8_t* dev_labels_out,
                         const int* crop_off, const int* crop_dims, int* dev_inf_flag);
+/* boa_finalize_labels restricted to planes [plane_lo, plane_hi) of axis 0 of the padded grid (the planes a rank owns in
+ * the tile-sharded mode); acc / n / fold_sum keep the full-grid layout. */
+int boa_finalize_labels_planes(boa_ctx* ctx, uint16_t* dev_acc, const uint16_t* dev_n, int C, const int V[3],
+                               uint16_t* dev_fold_sum, int fold_mode, int n_folds_final, int write_logits,
+                               const uint8_t* host_lut, int merge, uint8_t* dev_labels_out, const int* crop_off,
+                               const int* crop_dims, int* dev_inf_flag, int plane_lo, int plane_hi);
 
 /* ------------------------------------------------------------------ network (PlainConvUNet) ---------- */
 /* Geometry of dynamic_network_architectures PlainConvUNet as the reference instantiates it from plans.json
@@ -157,6 +163,22 @@ int boa_net_forward(boa_net* net, const float* dev_volume, const int V[3], const
 int boa_net_predict_sliding_window(boa_net* net, const float* dev_volume, const int V[3], const int PV[3],
                                    const int* vol_off, const int* host_origins, int n_tiles,
                                    const uint16_t* dev_gauss, uint16_t* dev_acc, uint16_t* dev_n);
+
+/* ---- one volume on several GPUs (SURVEY 8e "tile partitioning"): each rank owns a block of tile rows along axis 0 ----
+ * Same loop as boa_net_predict_sliding_window over THIS rank's tiles, except that for tile i the first
+ * host_defer_planes[i] planes (axis 0) are not accumulated: their head input is kept in *stash_out.  The caller places
+ * the lower rank's partial sums for those planes into acc / n (they were received over RCCL/xGMI) and then calls
+ * boa_net_apply_deferred, which adds the stashed planes in the original tile order -- per voxel the fp16 `+=` sequence
+ * is the reference's (predict_from_raw_data.py:611-614), so the result is bit-identical to the single-GPU loop.
+ * The head weights must still be those of the same fold when the stash is applied. */
+typedef struct boa_stash boa_stash;
+int boa_net_predict_sliding_window_deferred(boa_net* net, const float* dev_volume, const int V[3], const int PV[3],
+                                            const int* vol_off, const int* host_origins, int n_tiles,
+                                            const uint16_t* dev_gauss, uint16_t* dev_acc, uint16_t* dev_n,
+                                            const int* host_defer_planes, boa_stash** stash_out);
+int boa_net_apply_deferred(boa_net* net, const boa_stash* stash, const uint16_t* dev_gauss, uint16_t* dev_acc,
+                           uint16_t* dev_n, const int PV[3]);
+void boa_stash_destroy(boa_stash* stash);
 
 /* Debug / unit-test seam: run ONE conv block on device tensors in PyTorch layout.
  *   in  dev fp32 [N][Cin][D][H][W], w/b/gamma/beta host fp32; out dev fp32 [N][Cout][Do][Ho][Wo] =
@@ -235,6 +257,9 @@ int boa_fill_holes_2d(boa_ctx* ctx, const uint8_t* dev_mask, int Z, int Y, int X
                       uint8_t* dev_scratch_u8, uint8_t* dev_out);
 /* `out[filled] = label` (BCA/body_parts/postprocess.py:50): out[i] = value where (mask[i] != 0) != invert. */
 int boa_mask_assign(boa_ctx* ctx, const uint8_t* dev_mask, size_t n, int invert, int value, uint8_t* dev_out);
+/* the part -> combined merge `seg_combined[seg == jdx] = class_map_inv[name]` (TS/nnunet.py:553-556) on label volumes that
+ * already carry global labels: out[i] = part[i] where part[i] != 0 (tile-sharded mode merges after the label exchange). */
+int boa_label_overlay(boa_ctx* ctx, const uint8_t* dev_part, size_t n, uint8_t* dev_out);
 /* subclassify_tissues(median_filtering=True) (BCA/tissue/subclassification.py:21-36): scipy.ndimage.median_filter
  * with size 3 on two axes and 1 on `flat_axis` (0 = z, 1 = y, 2 = x of the [Z][Y][X] array), mode="reflect". */
 int boa_median3_inplane(boa_ctx* ctx, const int16_t* dev_in, int Z, int Y, int X, int flat_axis, int16_t* dev_out);

@@ -1,0 +1,152 @@
+"""Tile-sharded mode on the device (SURVEY 8e granularity 3): two processes share cuda:0 and one CT; each runs its block of
+tile rows, the overlap slab travels through torch.distributed (gloo here -- one GPU box; RCCL when every rank has its own
+GPU), each rank finalises its planes and the label volumes are all-reduced.
+
+`exact` mode must give labels bit-identical to the single-process loop (which the other GPU tests pin to the oracle);
+`allreduce` mode may flip labels at fp16 near-ties inside the slabs only -- the flip fraction is printed and bounded."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPE = (96, 40, 44)
+PARTS = ((801, 6, 1), (802, 4, 2))        # (task id, classes, folds)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _models():
+    from boa_hip import plans
+    models, luts = [], {}
+    for tid, nc, folds in PARTS:
+        pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc, spacing=(1.5, 1.5, 1.5))
+        cfg = plans.model_config_from_plans(pj, dj)
+        blobs = [plans.weight_blob_from_state_dict(cfg.geometry, plans.synthetic_state_dict(cfg.geometry, seed=tid + 17 * f))
+                 for f in range(folds)]
+        models.append((tid, cfg, blobs))
+        luts[tid] = np.concatenate([[0], np.arange(1, nc) + 10 * (tid - 800)]).astype(np.uint8)
+    return models, luts
+
+
+def _ct():
+    ct = np.random.default_rng(5).normal(0, 300, size=SHAPE).astype(np.int16)
+    ct[ct == 0] = 1
+    return ct
+
+
+def _predict(ctx, shard=None):
+    from boa_hip.task import SegmentationTask
+    models, luts = _models()
+    task = SegmentationTask(ctx, "total", models, resample=1.5, multimodel=True, max_batch=4, part_luts=luts)
+    task.step_size = 0.5
+    for _, _, p, _ in task.parts:
+        p.tile_step_size = 0.5
+    task.shard = shard
+    d_ct = ctx.from_numpy(_ct())
+    d_lab = ctx.alloc(int(np.prod(SHAPE)))
+    try:
+        task.predict_zyx_device(d_ct, SHAPE, d_lab, in_dtype=0)
+        return d_lab.download(SHAPE, np.uint8)
+    finally:
+        d_ct.free()
+        d_lab.free()
+        task.close()
+
+
+def _worker(rank, world, port, mode, q):
+    sys.path[:0] = [HERE, os.path.join(HERE, "body-and-organ-analysis_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from boa_hip import distributed as D
+    from boa_hip import tile_shard as ts
+    from boa_hip.device import Context
+    dist = D.init("gloo", rank, world)
+    ctx = Context(0)
+    lab = _predict(ctx, ts.TileShard(ts.ShardComm(dist, rank, world, "cpu"), mode))
+    q.put((rank, lab))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def _run(world, mode):
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.fixture(scope="module")
+def single():
+    from boa_hip.device import Context
+    c = Context(0)
+    lab = _predict(c)
+    c.close()
+    assert len(np.unique(lab)) > 3
+    return lab
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_mode_labels_bit_identical(single, world):
+    got = _run(world, "exact")
+    for r in range(world):
+        np.testing.assert_array_equal(got[r], single)       # every rank ends with the full, identical label volume
+
+
+def test_allreduce_mode_flips_only_near_ties(single):
+    got = _run(2, "allreduce")
+    np.testing.assert_array_equal(got[0], got[1])
+    flips = got[0] != single
+    print("allreduce mode: label flips", int(flips.sum()), "of", flips.size)
+    from boa_hip import sliding_window as sw
+    from boa_hip import tile_shard as ts
+    o = sw.get_sliding_window_origins(list(SHAPE), (32, 32, 32), 0.5)
+    lo, hi = ts.plan_rows(o, 32, SHAPE[0], 2).boundary(0)
+    outside = np.ones(SHAPE[0], dtype=bool)
+    outside[lo:hi] = False
+    assert not flips[outside].any()
+    assert flips.mean() < 2e-3
+
+
+def test_rccl_plumbing_single_rank(single):
+    """world_size 1 over the "nccl" (= RCCL) backend: device tensors that alias the engine's buffers, stream hand-over,
+    the uint8 label all-reduce.  (Two RCCL ranks cannot share one GPU; the 2-rank protocol is covered over gloo above.)"""
+    import torch
+    import torch.distributed as dist
+    from boa_hip import tile_shard as ts
+    from boa_hip.device import Context
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c = Context(0)
+        comm = ts.ShardComm(dist, 0, 1, "cuda:0")
+        ref = np.random.default_rng(1).integers(0, 255, size=4096 * 3, dtype=np.uint8)
+        buf = c.from_numpy(ref)
+        comm.world = 2                      # force the exchange path; a 1-rank sum returns the input
+        ts.all_reduce_labels(c, comm, buf, ref.size)
+        np.testing.assert_array_equal(buf.download(ref.shape, np.uint8), ref)
+        buf.free()
+        c.close()
+    finally:
+        dist.destroy_process_group()

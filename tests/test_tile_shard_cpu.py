@@ -1,0 +1,175 @@
+"""CPU, gloo, world_size 2 and 3: the tile-sharded protocol (boa_hip/tile_shard.py) driven with a numpy engine built from
+the oracle's accumulate step.  `exact` mode must reproduce the single-process fp16 accumulators bit for bit (the
+reference's per-voxel `+=` order, NN/inference/predict_from_raw_data.py:611-614); `allreduce` mode differs by one
+rounding in the overlap slabs only."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [HERE, os.path.join(HERE, "body-and-organ-analysis_amd")]
+
+PATCH = (32, 24, 16)
+HEADS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net(patch):
+    """toy network: 3 heads from one channel, with values large enough for fp16 rounding to matter"""
+    x = patch[0]
+    return np.stack([37.0 * x + 0.3, -11.0 * x * x + 5.0, 3.0 * np.abs(x) - 1.7]).astype(np.float32)
+
+
+def _volume(shape):
+    return np.random.default_rng(7).normal(0, 1.5, size=(1, *shape)).astype(np.float32)
+
+
+class NumpyEngine:
+    def __init__(self, data, origins, patch, heads):
+        from oracle import sliding_window as osw
+        self.osw, self.data, self.origins, self.patch, self.heads = osw, data, origins, patch, heads
+        self.g = osw.compute_gaussian(tuple(patch), 1.0 / 8, 10.0)
+
+    def begin(self):
+        self.acc = np.zeros((self.heads, *self.data.shape[1:]), dtype=np.float16)
+        self.n = np.zeros(self.data.shape[1:], dtype=np.float16)
+
+    def _pred(self, t):
+        s, p = self.origins[t], self.patch
+        return _net(self.data[:, s[0]:s[0] + p[0], s[1]:s[1] + p[1], s[2]:s[2] + p[2]])
+
+    def run(self, tiles, defer):
+        stash = []
+        for t, d in zip(tiles, defer):
+            pred, s = self._pred(t), self.origins[t]
+            if d:
+                stash.append((pred[:, :d].copy(), self.g[:d], (s[0], s[1], s[2])))
+            if d < self.patch[0]:
+                self.osw.accumulate_tile(self.acc, self.n, pred[:, d:], self.g[d:], (s[0] + d, s[1], s[2]))
+        return stash
+
+    def apply(self, stash):
+        for pred, g, s in stash:
+            self.osw.accumulate_tile(self.acc, self.n, pred, g, s)
+
+    def empty(self, lo, hi):
+        import torch
+        return torch.empty((self.heads + 1, hi - lo, *self.n.shape[1:]), dtype=torch.float16)
+
+    def pack(self, lo, hi):
+        import torch
+        return torch.from_numpy(np.concatenate([self.acc[:, lo:hi], self.n[None, lo:hi]]).copy())
+
+    def unpack(self, lo, hi, t):
+        a = t.numpy()
+        self.acc[:, lo:hi] = a[:-1]
+        self.n[lo:hi] = a[-1]
+
+
+def _single(shape, step):
+    from oracle import sliding_window as osw
+    data = _volume(shape)
+    sl = osw.get_sliding_window_slicers(shape, PATCH, step)
+    origins = np.array([[s[0], s[1], s[2]] for s in sl])
+    eng = NumpyEngine(data, origins, PATCH, HEADS)
+    eng.begin()
+    eng.run(range(len(origins)), [0] * len(origins))
+    return data, origins, eng.acc, eng.n
+
+
+def _worker(rank, world, port, shape, step, mode, q):
+    sys.path[:0] = [HERE, os.path.join(HERE, "body-and-organ-analysis_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from boa_hip import distributed as D
+    from boa_hip import tile_shard as ts
+    dist = D.init("gloo", rank, world)
+    data, origins, _, _ = (None, None, None, None)
+    from oracle import sliding_window as osw
+    data = _volume(shape)
+    origins = np.array([[s[0], s[1], s[2]] for s in osw.get_sliding_window_slicers(shape, PATCH, step)])
+    plan = ts.plan_rows(origins, PATCH[0], shape[0], world)
+    eng = NumpyEngine(data, origins, PATCH, HEADS)
+    lo, hi = ts.run_fold_sharded(eng, plan, ts.ShardComm(dist, rank, world, "cpu"), mode)
+    q.put((rank, lo, hi, eng.acc[:, lo:hi].copy(), eng.n[lo:hi].copy(), plan.active))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, shape, step, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, step, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("world,shape,step", [(2, (80, 40, 36), 0.5), (3, (80, 40, 36), 0.5), (2, (75, 24, 30), 0.8)])
+def test_exact_mode_is_bit_identical(world, shape, step):
+    _, _, acc, n = _single(shape, step)
+    got = _run(world, shape, step, "exact")
+    covered = 0
+    for rank, lo, hi, a, nn, active in got:
+        assert active >= 2
+        assert lo == covered or hi == 0
+        if hi:
+            covered = hi
+        np.testing.assert_array_equal(a.view(np.uint16), acc[:, lo:hi].view(np.uint16))
+        np.testing.assert_array_equal(nn.view(np.uint16), n[lo:hi].view(np.uint16))
+    assert covered == shape[0]
+
+
+def test_allreduce_mode_differs_only_in_the_slabs():
+    from boa_hip import tile_shard as ts
+    shape, step, world = (80, 40, 36), 0.5, 2
+    _, origins, acc, n = _single(shape, step)
+    plan = ts.plan_rows(origins, PATCH[0], shape[0], world)
+    slab = plan.boundary(0)
+    got = _run(world, shape, step, "allreduce")
+    full = np.concatenate([g[3] for g in got], axis=1)
+    assert full.shape == acc.shape
+    diff = full.view(np.uint16) != acc.view(np.uint16)
+    outside = np.ones(shape[0], dtype=bool)
+    outside[slab[0]:slab[1]] = False
+    assert not diff[:, outside].any()                       # untouched planes are exact
+    np.testing.assert_allclose(full.astype(np.float32), acc.astype(np.float32), rtol=2e-3, atol=1e-2)  # one fp16 rounding
+
+
+def test_plan_rows_properties():
+    from boa_hip import sliding_window as sw
+    from boa_hip import tile_shard as ts
+    for V, P, step in [((512, 512, 512), (128, 128, 128), 0.8), ((768, 512, 512), (128, 128, 128), 0.8),
+                       ((232, 100, 100), (128, 128, 128), 0.8), ((300, 128, 128), (128, 128, 128), 0.5),
+                       ((100, 50, 50), (128, 128, 128), 0.5), ((1024, 512, 512), (128, 128, 128), 0.8)]:
+        PV, _ = sw.pad_amounts(list(V), P)
+        o = sw.get_sliding_window_origins(PV, P, step)
+        for world in (1, 2, 3, 4, 8):
+            plan = ts.plan_rows(o, P[0], PV[0], world)
+            assert 1 <= plan.active <= world
+            tiles = np.concatenate([plan.tiles(r) for r in range(world)])
+            assert tiles.tolist() == list(range(len(o)))                    # every tile once, canonical order kept
+            planes = [plan.owned_planes(r) for r in range(plan.active)]
+            assert planes[0][0] == 0 and planes[-1][1] == PV[0]
+            assert all(planes[i][1] == planes[i + 1][0] for i in range(len(planes) - 1))
+            for r in range(1, plan.active - 1):                             # deferred and sent planes are disjoint
+                lo_b, up_b = plan.boundary(r - 1), plan.boundary(r)
+                if lo_b and up_b:
+                    assert lo_b[1] <= up_b[0]
+            assert all(plan.owned_planes(r) == (0, 0) and len(plan.tiles(r)) == 0 for r in range(plan.active, world))
