@@ -80,6 +80,8 @@ def main():
                          "GPUs share each volume: tile rows split, overlap slabs over RCCL (strong scaling, latency mode)")
     ap.add_argument("--shard-mode", choices=["exact", "allreduce"], default="exact",
                     help="--shard tiles: ordered send/recv hand-over (bit-exact) or pairwise fp16 all-reduce of the slabs")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo lets several ranks share one GPU for validation)")
     ap.add_argument("--dump", type=str, default=None, help="write per-kernel-class timings to this JSON file")
     args = ap.parse_args()
 
@@ -91,7 +93,9 @@ def main():
     import torch
     if world > 1:
         from boa_hip import distributed as D
-        dist = D.init("nccl", rank, world, local_rank)  # backend "nccl" is RCCL on ROCm
+        if args.backend == "gloo":
+            local_rank %= max(torch.cuda.device_count(), 1)
+        dist = D.init(args.backend, rank, world, local_rank)  # backend "nccl" is RCCL on ROCm
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
 
     from boa_hip import label_maps, synthetic
@@ -113,7 +117,7 @@ def main():
     tile_shard = None
     if dist is not None and args.shard == "tiles":
         from boa_hip import tile_shard as ts
-        tile_shard = ts.TileShard(ts.ShardComm(dist, rank, world, f"cuda:{local_rank}"), args.shard_mode)
+        tile_shard = ts.TileShard(ts.ShardComm(dist, rank, world, f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"), args.shard_mode)
     ct = synthetic.ct_phantom(shape, seed=20260928 + (0 if tile_shard else rank))
     log(f"setup (synthetic weights + phantom {shape}) {time.perf_counter() - t0:.1f}s")
     nvox = int(np.prod(shape))
@@ -143,7 +147,7 @@ def main():
     def barrier():
         ctx.sync()
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize() if torch.cuda.is_available() else None
 
     for _ in range(args.warmup):
@@ -160,7 +164,7 @@ def main():
     ctx.prof_enable(False)
     prof = ctx.prof_get()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

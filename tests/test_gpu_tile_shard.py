@@ -3,7 +3,12 @@ tile rows, the overlap slab travels through torch.distributed (gloo here -- one 
 GPU), each rank finalises its planes and the label volumes are all-reduced.
 
 `exact` mode must give labels bit-identical to the single-process loop (which the other GPU tests pin to the oracle);
-`allreduce` mode may flip labels at fp16 near-ties inside the slabs only -- the flip fraction is printed and bounded."""
+`allreduce` mode may flip labels at fp16 near-ties inside the slabs only -- the flip fraction is printed and bounded.
+
+The comparison runs the conv stack one tile per launch (max_batch=1): the InstanceNorm statistics are fp32 sums whose
+grouping follows the persistent tile schedule, i.e. the composition of the tile batch, so a tile's logits are
+reproducible bit for bit only for the same batch composition ("determinism") -- and the ranks of a sharded
+run necessarily cut the tile list into different batches than one process does."""
 import os
 import socket
 import sys
@@ -48,7 +53,7 @@ def _ct():
 def _predict(ctx, shard=None):
     from boa_hip.task import SegmentationTask
     models, luts = _models()
-    task = SegmentationTask(ctx, "total", models, resample=1.5, multimodel=True, max_batch=4, part_luts=luts)
+    task = SegmentationTask(ctx, "total", models, resample=1.5, multimodel=True, max_batch=1, part_luts=luts)
     task.step_size = 0.5
     for _, _, p, _ in task.parts:
         p.tile_step_size = 0.5
