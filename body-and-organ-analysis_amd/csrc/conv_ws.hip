@@ -41,7 +41,9 @@
         }                                                                                       \
     } while (0)
 
-__device__ __forceinline__ int ws_plane_bytes(int HV) { return ((HV * 16 + 127) / 128) * 128 + 64; }
+// one k-octet plane of the halo: whole producer rounds of WS_PROD / 2 voxels (lanes past the halo store into the padding
+// instead of being masked: no per-item exec juggling), + 64 bytes of bank skew between the two planes
+__device__ __forceinline__ int ws_plane_bytes(int HV) { return ((HV + WS_PROD / 2 - 1) / (WS_PROD / 2)) * (WS_PROD / 2) * 16 + 64; }
 
 struct TileCoord {
     int n, cy, ox0, oy0, oz0;
@@ -197,6 +199,18 @@ __device__ __forceinline__ void prod_setup(const ConvArgs& p, const TileCoord& t
     }
 }
 
+// Global-memory accesses in the scalar-base form `global_{load,store} v_off, ..., s[base:base+1]`: a wave-uniform pointer
+// pinned in an SGPR pair (the empty asm also keeps hipcc from folding the lane offset into one 64-bit VGPR address, which
+// selects the slow VGPR-pair form again) + a 32-bit lane offset.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define WS_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ WS_GLOBAL unsigned char* sgpr_ptr(const void* p) {
+    WS_GLOBAL unsigned char* g = (WS_GLOBAL unsigned char*)p;  // explicit global address space: the asm hides the provenance
+    asm volatile("" : "+s"(g));
+    return g;
+}
+
 #define OPAQUE4(a) "+v"((a).x), "+v"((a).y), "+v"((a).z), "+v"((a).w)
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
@@ -269,7 +283,7 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
 #pragma unroll
         for (int b = 0; b < WS_WB; ++b) {
             const int i = min(q + b * WS_PROD, nw - 1);
-            rg.wv[b] = *(const uint4*)(wsrc + ((size_t)(i >> 5) * p.Cout + (i & 31)) * 8);
+            rg.wv[b] = *(const uint4*)((const unsigned char*)wsrc + ((unsigned)(i >> 5) * (unsigned)p.Cout + (unsigned)(i & 31)) * 16u);
         }
     }
     if (skip_halo) return;
@@ -277,16 +291,43 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
     rg.live = live;
     rg.has_ss = ss != nullptr;
     const unsigned cb2 = (unsigned)C * 2u;  // bytes per voxel record; per-sample offsets fit 32 bits (checked on the host)
-    const unsigned char* lbase = (const unsigned char*)base + (q & 1) * 16;
+    // wave-uniform 64-bit base (SGPR pair) + 32-bit lane offset: the `global_load v, v_off, s[base]` form.  The form with a
+    // 64-bit VGPR address is starved next to a wave that keeps the matrix pipe busy (tools/valu_under_mfma.hip: 660
+    // instead of 64 cycles per load instruction), the scalar-base form is not.
+    const unsigned char* sbase = (const unsigned char*)base;
+    const unsigned lane_off = (unsigned)(q & 1) * 16u;
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
         // unconditional: voxels beyond the halo / outside the tensor have gi == 0 (a valid address, data discarded)
-        rg.d[j] = *(const uint4*)(lbase + (unsigned)it.gi[j] * cb2);
+        // v_mad_u32_u24 (full rate; the plain 32-bit form compiled to the quarter-rate v_mad_u64_u32): voxel index and
+        // record size are below 2^24 (checked on the host)
+        rg.d[j] = *(const uint4*)(sbase + (__umul24((unsigned)it.gi[j], cb2) + lane_off));
     }
     if (ss) {
-        const unsigned* sl = ss + (q & 1) * 8;
+        unsigned so = (unsigned)(q & 1) * 32u;
+        asm volatile("" : "+v"(so));  // keep the 32 -> 64 bit extension in this block: scalar-base load form
+        const uint4 s0 = *(const uint4*)((const unsigned char*)ss + so);
+        const uint4 s1 = *(const uint4*)((const unsigned char*)ss + so + 16);
+        rg.ssw[0] = s0.x; rg.ssw[1] = s0.y; rg.ssw[2] = s0.z; rg.ssw[3] = s0.w;
+        rg.ssw[4] = s1.x; rg.ssw[5] = s1.y; rg.ssw[6] = s1.z; rg.ssw[7] = s1.w;
+    }
+}
+
+template <bool SS, bool EDGE>
+__device__ __forceinline__ void commit_items(const ChunkRegs& rg, unsigned char* d0, int nv, unsigned slope2) {
+    // distinct markers keep hipcc from merging the copies back into one path with per-item masks
+    if (EDGE)
+        asm volatile("; commit: edge tile");
+    else
+        asm volatile("; commit: interior tile");
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rg.ssw[j] = sl[j];
+    for (int j = 0; j < WS_MAXV; ++j) {
+        if (j < nv) {  // wave-uniform: whole rounds, lanes past the halo store into the plane's padding
+            uint4 o = rg.d[j];
+            if (SS) o = norm_act8_pk(o, rg.ssw, slope2);
+            if (EDGE && !((rg.ok >> j) & 1u)) o = make_uint4(0, 0, 0, 0);
+            *(uint4*)(d0 + j * (WS_PROD / 2 * 16)) = o;
+        }
     }
 }
 
@@ -311,16 +352,20 @@ __device__ __forceinline__ void prod_commit(const ConvArgs& p, ChunkRegs& rg, un
     sl2.v = h2_t{(_Float16)p.slope, (_Float16)p.slope};
     unsigned char* d0 = dst_in + (q & 1) * plane + (q >> 1) * 16;
     // padding voxels (outside the tensor) must read as zero AFTER the transform; tiles whose halo lies inside the tensor
-    // (rg.ok == rg.live for every lane, decided per wave) skip the per-voxel selects
+    // (rg.ok == rg.live for every lane, decided per wave) skip the per-voxel selects.  The four (transform, edge)
+    // combinations are separate straight-line copies: 13 instructions per item in the common one (12 packed ops +
+    // ds_write_b128 with an immediate offset) instead of ~35 with per-item masks and selects.
     const bool edge = __builtin_amdgcn_ballot_w64(rg.ok != rg.live) != 0;
-#pragma unroll
-    for (int j = 0; j < WS_MAXV; ++j) {
-        if (j < nv && ((rg.live >> j) & 1u)) {
-            uint4 o = rg.d[j];
-            if (rg.has_ss) o = norm_act8_pk(o, rg.ssw, sl2.u);
-            if (edge && !((rg.ok >> j) & 1u)) o = make_uint4(0, 0, 0, 0);
-            *(uint4*)(d0 + j * (WS_PROD / 2 * 16)) = o;
-        }
+    if (rg.has_ss) {
+        if (edge)
+            commit_items<true, true>(rg, d0, nv, sl2.u);
+        else
+            commit_items<true, false>(rg, d0, nv, sl2.u);
+    } else {
+        if (edge)
+            commit_items<false, true>(rg, d0, nv, sl2.u);
+        else
+            commit_items<false, false>(rg, d0, nv, sl2.u);
     }
 }
 
@@ -372,7 +417,73 @@ __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R
     }
 }
 
-template <int R, int K0, int K1, int K2>
+// Row-reuse form of the chunk loop (YR kernels: 3 taps along y, stride 1, the wave's R M-tiles are consecutive rows):
+// the B fragment of tap dy at output row r is the input row r + dy, so one (dx, dz) group reads R + 2 input rows and the
+// 3 weight fragments once and feeds 3 R MFMAs -- (R + 5) KiB of LDS reads per 3 R MFMAs instead of 3 (R + 1) KiB.
+// The per-tap form asks the LDS for 160 B/clk per CU at the full MFMA rate with R = 4 (4 waves x 5 KiB per 4 MFMAs of
+// 32 clk), more than the 128 B/clk it has; this form needs 96 B/clk.
+template <int R, int K0, int K2, bool FIRST>
+__device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const unsigned char* ap, int h1, int h2,
+                                                f32x16 (&acc)[R]) {
+    // MFMAs run in input-row order (row j feeds the pairs r + dy = j), so row j's registers are dead after its last
+    // MFMA and take the same row of the next (dx, dz) group straight away: one set of R + 2 row fragments streams
+    // through the groups, only the 3 weight fragments are double-buffered.
+    constexpr int G = K0 * K2;
+    constexpr int NB = R + 2;
+    f16x8 a[2][3];
+    f16x8 b[NB];
+    auto fetch_a = [&](int g, int slot) {
+        const int dz = g % K2, dx = g / K2;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) a[slot][dy] = *(const f16x8*)(ap + ((dx * 3 + dy) * K2 + dz) * 1024);
+    };
+    auto fetch_b = [&](int g, int jj) {
+        const int dz = g % K2, dx = g / K2;
+        b[jj] = *(const f16x8*)(b0p + ((dx * h1 + jj) * h2 + dz) * 16);
+    };
+    fetch_a(0, 0);
+#pragma unroll
+    for (int jj = 0; jj < NB; ++jj) fetch_b(0, jj);
+    __builtin_amdgcn_sched_group_barrier(0x100, NB + 3, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int cb = g & 1;
+        if (g + 1 < G) {
+            fetch_a(g + 1, cb ^ 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) {
+            int cnt = 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = jj - dy;
+                if (r < 0 || r >= R) continue;
+                ++cnt;
+                if (FIRST && g == 0 && dy == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][0], b[jj], zero, 0, 0, 0);
+                } else {
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][dy], b[jj], acc[r], 0, 0, 0);
+                }
+            }
+            // row jj is used by min(jj, R - 1) - max(jj - 2, 0) + 1 MFMAs (compile-time per unrolled iteration)
+            if (jj == 0 || jj == NB - 1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            else if (jj == 1 || jj == NB - 2)
+                __builtin_amdgcn_sched_group_barrier(0x008, R >= 2 ? 2 : 1, 0);
+            else
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            (void)cnt;
+            if (g + 1 < G) {
+                fetch_b(g + 1, jj);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    }
+}
+
+template <int R, int K0, int K1, int K2, bool YR>
 __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_tiles, int resident_w, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -566,7 +677,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             }
             const unsigned char* ap = (resident_w ? smem + cc * taps * 1024 : cur + 2 * plane) + (kh * 32 + l31) * 16;
             WS_STAMP(4);
-            if (cc == 0)
+            if constexpr (YR) {
+                if (cc == 0)
+                    consume_chunk_y<R, K0, K2, true>(bp[0], ap, p.h1, p.h2, acc);
+                else
+                    consume_chunk_y<R, K0, K2, false>(bp[0], ap, p.h1, p.h2, acc);
+            } else if (cc == 0)
                 consume_chunk<R, K0, K1, K2, true>(bp, ap, p.h1, p.h2, acc);
             else
                 consume_chunk<R, K0, K1, K2, false>(bp, ap, p.h1, p.h2, acc);
@@ -582,11 +698,19 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 }
                 const int cout0 = tc.cy * 32;
                 const bool full = tc.ox0 + p.b0 * p.w0 <= p.Do && tc.oy0 + p.b1 * p.w1 <= p.Ho && tc.oz0 + p.b2 * p.w2 <= p.Wo;
-                __half* obase = p.out + ((size_t)tc.n * out_vox + ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0 + srel0) * p.Cout + cout0 + kh * 16;
+                // wave-uniform base + 32-bit lane offset (scalar-base global_store / global_load forms, see prod_issue)
+                const size_t obase = ((size_t)tc.n * out_vox + ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * p.Cout + cout0;
+                const unsigned olane = ((unsigned)srel0 * (unsigned)p.Cout + (unsigned)kh * 16u) * 2u;
                 // the tile's 16 bias values of this lane (4 independent loads, one wait)
                 float4 bq[4];
+                const WS_GLOBAL unsigned char* bbase = sgpr_ptr(p.bias + cout0);
+                unsigned bl = (unsigned)kh * 16u;
+                asm volatile("" : "+v"(bl));
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) bq[gq] = *(const float4*)(p.bias + cout0 + 8 * gq + 4 * kh);
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4_t bv = *(const WS_GLOBAL f32x4_t*)(bbase + bl + 32 * gq);
+                    bq[gq] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+                }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int m = cw * R + r;  // wave-uniform M-tile origin within the block tile
@@ -646,9 +770,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                         c.h[0] = __float2half_rn(hi4[2]); c.h[1] = __float2half_rn(hi4[3]); w[pr * 4 + 3] = c.u;
                     }
                     if (ok && !(dbg & 4)) {
-                        __half* dst = obase + (size_t)mrel * p.Cout;
-                        *(uint4*)dst = make_uint4(w[0], w[1], w[2], w[3]);
-                        *(uint4*)(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+                        WS_GLOBAL unsigned char* dst = sgpr_ptr(p.out + (obase + (size_t)mrel * p.Cout));
+                        unsigned ol = olane;
+                        asm volatile("" : "+v"(ol));  // keep the 32 -> 64 bit extension in this block (instruction selection is per block)
+                        *(WS_GLOBAL u32x4_t*)(dst + ol) = u32x4_t{w[0], w[1], w[2], w[3]};
+                        *(WS_GLOBAL u32x4_t*)(dst + ol + 16) = u32x4_t{w[4], w[5], w[6], w[7]};
                     }
                 }
             }
@@ -660,7 +786,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-static size_t ws_plane_host(int HV) { return ((size_t)(HV * 16 + 127) / 128) * 128 + 64; }
+static size_t ws_plane_host(int HV) { return ((size_t)(HV + WS_PROD / 2 - 1) / (WS_PROD / 2)) * (WS_PROD / 2) * 16 + 64; }
 
 // resident weights need every tile of the launch to use the same weights: Cout == 32 (one cout chunk)
 bool conv_ws_resident(int HV, int taps, int ncc, int Cout) {
@@ -680,12 +806,24 @@ bool conv_ws_supported(const int k[3], int HV) {
     return (k333 || k133) && 2 * HV <= WS_PROD * WS_MAXV;
 }
 
+template <int R, int K0, int K1, int K2, bool YR>
+static void launch_ws_y(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
+    static bool once = (hipFuncSetAttribute((const void*)k_conv_ws<R, K0, K1, K2, YR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR>), dim3(grid), dim3(WS_THREADS), t.lds_bytes, ctx->stream, a, total, resident,
+                       getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0);
+}
+
 template <int R, int K0, int K1, int K2>
 static void launch_ws_t(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
-    static bool once = (hipFuncSetAttribute((const void*)k_conv_ws<R, K0, K1, K2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
-    hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2>), dim3(grid), dim3(WS_THREADS), t.lds_bytes, ctx->stream, a, total, resident,
-                       getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0);
+    // row reuse: the R M-tiles of a wave are consecutive output rows (m = cw * R + r, my = m & (b1 - 1) when b2 == 1),
+    // one voxel high, stride 1 along y
+    static const bool off = getenv("BOA_WS_NO_YREUSE") != nullptr;
+    const bool yr = R > 1 && K1 == 3 && a.s1 == 1 && a.w1 == 1 && a.b2 == 1 && a.b1 % R == 0 && !off;
+    if (R > 1 && yr)
+        launch_ws_y<R, K0, K1, K2, (R > 1)>(ctx, a, t, total, grid, resident);
+    else
+        launch_ws_y<R, K0, K1, K2, false>(ctx, a, t, total, grid, resident);
 }
 
 template <int R>
@@ -708,6 +846,8 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     const int taps = a0.k0 * a0.k1 * a0.k2;
     const int HV = t.h[0] * t.h[1] * t.h[2];
     const int resident = conv_ws_resident(HV, taps, (a0.C0 + a0.C1) / 16, a0.Cout) ? 1 : 0;
+    BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi < 16777216.0 && std::max(a0.C0, a0.C1) * 2 < 16777216,
+                "conv_ws: more than 2^24 input voxels per sample (24-bit offset multiply)");
     BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi * std::max(a0.C0, a0.C1) * 2.0 < 4294967296.0,
                 "conv_ws: one sample of the input exceeds 4 GiB (32-bit voxel offsets)");
     static const bool want_trace = getenv("BOA_WS_TRACE") != nullptr;
