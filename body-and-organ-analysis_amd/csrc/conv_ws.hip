@@ -296,9 +296,11 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
     // instead of 64 cycles per load instruction), the scalar-base form is not.
     const unsigned char* sbase = (const unsigned char*)base;
     const unsigned lane_off = (unsigned)(q & 1) * 16u;
+    const int nrounds = (p.h0 * p.h1 * p.h2 + WS_PROD / 2 - 1) / (WS_PROD / 2);  // rounds that carry halo voxels (wave-uniform)
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
-        // unconditional: voxels beyond the halo / outside the tensor have gi == 0 (a valid address, data discarded)
+        // no per-lane test: voxels beyond the halo / outside the tensor have gi == 0 (a valid address, data discarded)
+        if (j < nrounds)
         // v_mad_u32_u24 (full rate; the plain 32-bit form compiled to the quarter-rate v_mad_u64_u32): voxel index and
         // record size are below 2^24 (checked on the host)
         rg.d[j] = *(const uint4*)(sbase + (__umul24((unsigned)it.gi[j], cb2) + lane_off));
@@ -856,7 +858,8 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     // statistics slots: one per (workgroup, consumer wave); waves that never touch an (n, cout chunk) leave zeros
     a.nslots = conv_ws_nslots(ctx->cu_count);
     a.cy_fast = ((a.C0 + a.C1) == 32 && a.Cout == 64 && t.R == 1 && !getenv("BOA_WS_NO_CYFAST")) ? 1 : 0;
-    BOA_HIP_TRY(hipMemsetAsync(a.partials, 0, (size_t)a.N * a.Cout * 2 * a.nslots * sizeof(float), ctx->stream));
+    // a.partials must be all zero on entry: the callers zero it once (allocation / test seam) and k_norm_finalize
+    // clears what it has read, so no per-launch memset is needed
     if (want_trace) {
         hipMalloc(&a.trace, WS_TRACE_SLOTS * 8);
         hipMemsetAsync(a.trace, 0, WS_TRACE_SLOTS * 8, ctx->stream);
