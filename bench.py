@@ -204,6 +204,19 @@ def main():
                                "launches": prof[k]["launches"]}
                            for k in ("head_accum", "finalize_argmax", "convT_mfma", "conv_first") if prof[k]["launches"]},
         }
+        # HBM traffic of the dominant kernel: FETCH_SIZE / WRITE_SIZE from the committed rocprofv3 --pmc passes
+        # (tools/profile_round.sh: separate passes, gfx950 FETCH correction; they cannot run inside this process), averaged over
+        # the k_conv_ws launches; per launch like `achieved` (bytes; compare with bytes_per_launch = algorithmic)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_256.json")))["kernels"]
+            rows = [v for k, v in pmc.items() if "k_conv_ws" in k]
+            nd = sum(v["dispatches"] for v in rows)
+            res["roofline"]["traffic"] = 1e6 * 1.048576 * sum(
+                v["dispatches"] * (v["fetch_MB_corrected_per_dispatch"] + v["write_MB_per_dispatch"]) for v in rows) / nd
+            res["roofline"]["traffic_unit"] = "HBM bytes per launch (PMC, profiles/r01_pmc_fetch_write_256.json)"
+            res["roofline"]["bytes_per_launch"] = conv["bytes"] / max(conv["launches"], 1)
+        except Exception:
+            pass
         if not args.no_cpu and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(models[0][3], args.cpu_tiles, tiles_per_volume, log)
         else:

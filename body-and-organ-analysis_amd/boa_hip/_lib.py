@@ -68,6 +68,7 @@ _PROTOS = {
     "boa_convtranspose_test": (i32, [vp, vp, i32, i32, ip, vp, vp, i32, ip, vp]),
     "boa_tissue_aggregate": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "boa_slice_label_presence": (i32, [vp, vp, i32, i32, i32, vp]),
+    "boa_tissue_projections": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, vp]),
     "boa_label_hu_histogram": (i32, [vp, vp, vp, vp, u64, i32, i32, vp]),
     "boa_label_hu_mask": (i32, [vp, vp, vp, vp, i32, i32, i32, u64, vp]),
     "boa_binary_erode": (i32, [vp, vp, vp, vp, i32, i32, i32, i32]),

@@ -85,6 +85,28 @@ def tissue_aggregate(ctx: Context, ct: DeviceBuffer, regions: DeviceBuffer, part
     return tis, counts, hu_sums
 
 
+HEATMAP_TISSUES = ("BONE", "MUSCLE", "IMAT", "SAT", "VAT", "PAT", "EAT")   # BCA/report/plots/heatmaps.py:38-46
+
+
+def tissue_projections(ctx: Context, tissues: DeviceBuffer, regions: DeviceBuffer, shape, values):
+    """create_tissue_heatmaps' reductions (BCA/report/plots/heatmaps.py:29-101) in one device pass:
+    -> (coronal uint32 [T,Z,X] = per-tissue sum over y, sagittal uint32 [T,Z,Y] = sum over x, body silhouettes bool [Z,X],
+    bool [Z,Y]) for the tissue label values `values`.  Normalisation to the maximum, colour map and resize are rendering."""
+    Z, Y, X = (int(s) for s in shape)
+    vals = np.ascontiguousarray(values, dtype=np.uint8)
+    T = int(vals.size)
+    d_c, d_s = ctx.alloc(T * Z * X * 4), ctx.alloc(T * Z * Y * 4)
+    d_mc, d_ms = ctx.alloc(Z * X), ctx.alloc(Z * Y)
+    try:
+        check(ctx.lib.boa_tissue_projections(ctx.h, tissues.vp, regions.vp, Z, Y, X, vals.ctypes.data_as(C.c_void_p), T,
+                                             d_c.vp, d_s.vp, d_mc.vp, d_ms.vp), "boa_tissue_projections")
+        return (d_c.download((T, Z, X), np.uint32), d_s.download((T, Z, Y), np.uint32),
+                d_mc.download((Z, X), np.uint8).astype(bool), d_ms.download((Z, Y), np.uint8).astype(bool))
+    finally:
+        for b in (d_c, d_s, d_mc, d_ms):
+            b.free()
+
+
 def slice_label_presence(ctx: Context, labels: DeviceBuffer, shape) -> np.ndarray:
     Z, Y, X = (int(s) for s in shape)
     d = ctx.alloc(Z * 256)

@@ -165,6 +165,86 @@ extern "C" int boa_slice_label_presence(boa_ctx* c, const uint8_t* dev_labels, i
 }
 
 // ------------------------------------------------------------------------------------------------------
+// tissue projections: the reductions behind the report's coronal / sagittal tissue heat maps
+// (BCA/report/plots/heatmaps.py:29-101): per selected tissue `tissue_mask.sum(axis=1)` and `.sum(axis=2)` of the (z,y,x)
+// tissue volume, and `((regions > 0) & (regions < 255)).any(axis)` for the body silhouette -- 2 B per voxel in one pass
+// (7 tissues x 2 axes = 14 full-volume numpy passes in the reference).  One block per z slice; a thread owns its x
+// columns (coronal counts need no atomics), the sagittal row counts are wave ballots + one LDS add per wave and tissue.
+struct ProjArgs {
+    const unsigned char* tissues;
+    const unsigned char* regions;
+    int Y, X, T;
+    unsigned int* cor;       // [T][Z][X]
+    unsigned int* sag;       // [T][Z][Y]
+    unsigned char* mcor;     // [Z][X]
+    unsigned char* msag;     // [Z][Y]
+    int Z;
+    unsigned char lut[256];  // tissue value -> index in [0, T) or 255
+};
+
+__global__ __launch_bounds__(256) void k_tissue_projections(ProjArgs a) {
+    extern __shared__ unsigned int sm[];
+    unsigned int* s_cor = sm;                               // [T][X]
+    unsigned int* s_sag = sm + (size_t)a.T * a.X;           // [T][Y]
+    unsigned int* s_mc = s_sag + (size_t)a.T * a.Y;         // [X]
+    unsigned int* s_ms = s_mc + a.X;                        // [Y]
+    const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int tot = a.T * (a.X + a.Y) + a.X + a.Y;
+    for (int i = tid; i < tot; i += 256) sm[i] = 0;
+    __syncthreads();
+    const size_t base = (size_t)z * a.Y * a.X;
+    const int xr = (a.X + 255) / 256 * 256;  // whole waves so that the ballots see every lane
+    for (int y = 0; y < a.Y; ++y) {
+        const unsigned char* trow = a.tissues + base + (size_t)y * a.X;
+        const unsigned char* rrow = a.regions + base + (size_t)y * a.X;
+        for (int x = tid; x < xr; x += 256) {
+            int idx = 255;
+            bool body = false;
+            if (x < a.X) {
+                idx = a.lut[trow[x]];
+                const unsigned char r = rrow[x];
+                body = r > 0 && r < 255;
+                if (idx < a.T) s_cor[idx * a.X + x] += 1;   // this thread is the only writer of column x
+                if (body) s_mc[x] = 1;
+            }
+            for (int t = 0; t < a.T; ++t) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(idx == t);
+                if (m && lane == 0) atomicAdd(&s_sag[t * a.Y + y], (unsigned)__builtin_popcountll(m));
+            }
+            if (__builtin_amdgcn_ballot_w64(body) && lane == 0) s_ms[y] = 1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < a.T * a.X; i += 256) a.cor[((size_t)(i / a.X) * a.Z + z) * a.X + i % a.X] = s_cor[i];
+    for (int i = tid; i < a.T * a.Y; i += 256) a.sag[((size_t)(i / a.Y) * a.Z + z) * a.Y + i % a.Y] = s_sag[i];
+    for (int i = tid; i < a.X; i += 256) a.mcor[(size_t)z * a.X + i] = (unsigned char)s_mc[i];
+    for (int i = tid; i < a.Y; i += 256) a.msag[(size_t)z * a.Y + i] = (unsigned char)s_ms[i];
+}
+
+extern "C" int boa_tissue_projections(boa_ctx* c, const uint8_t* dev_tissues, const uint8_t* dev_regions, int Z, int Y, int X,
+                                      const uint8_t* host_values, int n_values, uint32_t* dev_coronal, uint32_t* dev_sagittal,
+                                      uint8_t* dev_mask_coronal, uint8_t* dev_mask_sagittal) {
+    BOA_REQUIRE(c && dev_tissues && dev_regions && host_values && dev_coronal && dev_sagittal && dev_mask_coronal &&
+                    dev_mask_sagittal && Z > 0 && Y > 0 && X > 0,
+                "boa_tissue_projections: bad argument");
+    BOA_REQUIRE(n_values >= 1 && n_values <= 16, "boa_tissue_projections: %d tissue values (1..16)", n_values);
+    const size_t lds = ((size_t)n_values * (X + Y) + X + Y) * 4;
+    BOA_REQUIRE(lds <= 160 * 1024, "boa_tissue_projections: slice %dx%d with %d tissues needs %zu bytes of LDS", Y, X, n_values, lds);
+    ProjArgs a;
+    a.tissues = dev_tissues; a.regions = dev_regions; a.Y = Y; a.X = X; a.T = n_values; a.Z = Z;
+    a.cor = dev_coronal; a.sag = dev_sagittal; a.mcor = dev_mask_coronal; a.msag = dev_mask_sagittal;
+    for (int i = 0; i < 256; ++i) a.lut[i] = 255;
+    for (int t = 0; t < n_values; ++t) a.lut[host_values[t]] = (unsigned char)t;
+    static bool once = (hipFuncSetAttribute((const void*)k_tissue_projections, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    KernelTimer t(c, BOA_K_OTHER, 0, 2.0 * Z * Y * X);
+    hipLaunchKernelGGL(k_tissue_projections, dim3(Z), dim3(256), lds, c->stream, a);
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // per-label HU histogram (label 0 = background is never measured by the reference and is skipped)
 __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
                                                     const unsigned char* __restrict__ mask, size_t n, int hu_min,

@@ -210,6 +210,16 @@ int boa_tissue_aggregate(boa_ctx* ctx, const int16_t* dev_ct, const int16_t* dev
  * BCA/commands.py:24-45): present[z][label] = 1 if any voxel of slice z has that label. dev uint8 [Z][256]. */
 int boa_slice_label_presence(boa_ctx* ctx, const uint8_t* dev_labels, int Z, int Y, int X, uint8_t* dev_present);
 
+/* The reductions behind the report's coronal / sagittal tissue heat maps (BCA/report/plots/heatmaps.py:29-101), one pass
+ * over the (z,y,x) uint8 volumes: for each tissue value v_t (host_values, 1..16 of them)
+ *   coronal[t][z][x]  = #{y : tissues[z,y,x] == v_t}     (`tissue_mask.sum(axis=1)`)
+ *   sagittal[t][z][y] = #{x : tissues[z,y,x] == v_t}     (`tissue_mask.sum(axis=2)`)
+ * and the body silhouettes `((regions > 0) & (regions < 255)).any(axis)`: mask_coronal[z][x], mask_sagittal[z][y] (0/1).
+ * Colour mapping / resizing / contour drawing of the report stay on the host (out of scope). */
+int boa_tissue_projections(boa_ctx* ctx, const uint8_t* dev_tissues, const uint8_t* dev_regions, int Z, int Y, int X,
+                           const uint8_t* host_values, int n_values, uint32_t* dev_coronal, uint32_t* dev_sagittal,
+                           uint8_t* dev_mask_coronal, uint8_t* dev_mask_sagittal);
+
 /* One pass replacing the ~125 full-volume passes of metrics_for_each_region (BOA/compute/measurements.py:74-123,
  * 203-241): histogram of HU per label.  hist dev uint32 [256][nbins], bin = clamp(hu - hu_min, 0, nbins-1);
  * mask (optional dev uint8, same shape): only voxels with mask != 0 are counted (eroded / fat-window masks).

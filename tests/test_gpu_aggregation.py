@@ -276,3 +276,29 @@ def test_create_vertebrae_info_vs_oracle(ctx):
     for parts in (dict(abdomen=True, thorax=True, neck=True), dict(abdomen=True, thorax=False, neck=False),
                   dict(abdomen=False, thorax=False, neck=False)):
         assert bca.create_vertebrae_info(ctx, total, cm, parts) == obca.create_vertebrae_info(total, vmap, parts)
+
+
+def test_tissue_projections_match_numpy(ctx):
+    """create_tissue_heatmaps' reductions (BCA/report/plots/heatmaps.py:29-101): per-tissue sums over y and x, body
+    silhouettes -- bit-exact against the numpy statements of the reference, incl. a slice width that is not a multiple
+    of the wave size."""
+    from boa_hip import bca
+    rng = np.random.default_rng(11)
+    Z, Y, X = 9, 37, 83
+    tissues = rng.integers(0, 9, size=(Z, Y, X), dtype=np.uint8)
+    regions = rng.choice(np.array([0, 1, 2, 3, 11, 255], dtype=np.uint8), size=(Z, Y, X))
+    regions[3] = 0                                                      # an empty silhouette slice
+    regions[4, :, :40] = 255
+    vals = [v for n, v in bca.TISSUES if n in bca.HEATMAP_TISSUES]
+    vals = [dict(bca.TISSUES)[n] for n in bca.HEATMAP_TISSUES]            # the reference's tissue order
+    d_t, d_r = ctx.from_numpy(tissues), ctx.from_numpy(regions)
+    cor, sag, mcor, msag = bca.tissue_projections(ctx, d_t, d_r, (Z, Y, X), vals)
+    d_t.free()
+    d_r.free()
+    body = (regions > 0) & (regions < 255)
+    np.testing.assert_array_equal(mcor, body.any(axis=1))
+    np.testing.assert_array_equal(msag, body.any(axis=2))
+    for t, v in enumerate(vals):
+        m = tissues == v
+        np.testing.assert_array_equal(cor[t], m.sum(axis=1))
+        np.testing.assert_array_equal(sag[t], m.sum(axis=2))
