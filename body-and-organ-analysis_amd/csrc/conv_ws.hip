@@ -659,6 +659,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 
     TileCoord tc;
     tc.n = tc.cy = tc.ox0 = tc.oy0 = tc.oz0 = tc.sp = 0;
+    if (p.trace && blockIdx.x == 0 && tid == 0) {
+        p.trace[WS_TRACE_SLOTS - 4] = __builtin_readcyclecounter();
+        p.trace[WS_TRACE_SLOTS - 3] = __builtin_amdgcn_s_memrealtime();
+    }
     __syncthreads();  // chunk 0 staged (pairs with the producers' g = -1 barrier)
     for (int k = 0; k < walk.count; ++k) {
         if (k == 0)
@@ -784,6 +788,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             __syncthreads();
         }
     }
+    if (p.trace && blockIdx.x == 0 && tid == 0) {
+        p.trace[WS_TRACE_SLOTS - 2] = __builtin_readcyclecounter();
+        p.trace[WS_TRACE_SLOTS - 1] = __builtin_amdgcn_s_memrealtime();
+    }
     flush_stats();
 }
 
@@ -881,6 +889,10 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
         hipStreamSynchronize(ctx->stream);
         hipMemcpy(host, a.trace, sizeof(host), hipMemcpyDeviceToHost);
         hipFree(a.trace);
+        fprintf(stderr, "[ws-clock] Cin=%d Cout=%d in=%d: %llu cycles in %llu x10ns -> %.3f GHz, %d tiles per block\n", a0.C0 + a0.C1, a0.Cout, a0.Di,
+                host[WS_TRACE_SLOTS - 2] - host[WS_TRACE_SLOTS - 4], host[WS_TRACE_SLOTS - 1] - host[WS_TRACE_SLOTS - 3],
+                (double)(host[WS_TRACE_SLOTS - 2] - host[WS_TRACE_SLOTS - 4]) / (10.0 * (double)(host[WS_TRACE_SLOTS - 1] - host[WS_TRACE_SLOTS - 3])),
+                (total + grid - 1) / grid);
         for (int role = 0; role < 2; ++role) {
             const unsigned long long* h = host + role * (WS_TRACE_SLOTS / 2);
             fprintf(stderr, "[ws-trace] %s Cin=%d Cout=%d in=%d R=%d:", role ? "producer" : "consumer", a0.C0 + a0.C1, a0.Cout, a0.Di, t.R);
