@@ -250,7 +250,6 @@ __device__ __forceinline__ uint4 norm_act8_pk(uint4 raw, const unsigned* w /* 4 
 // instead of sitting on the producer's own critical path.
 struct ChunkRegs {
     uint4 d[WS_MAXV];     // this lane's channel octet of its halo voxels
-    uint4 wv[WS_WB];      // weight items (taps * 64 items per chunk), streamed-weights layers only
     unsigned ssw[8];      // this lane's octet: 4 channel pairs x {packed scales, packed shifts}
     unsigned ok;          // bit j: voxel j is inside the input tensor
     unsigned live;        // bit j: voxel j belongs to the halo (v < HV)
@@ -259,7 +258,7 @@ struct ChunkRegs {
 };
 
 __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& tc, const ProdItems& it, unsigned live, int cc,
-                                           bool want_w, bool skip_halo, int q, int taps, int dbg, ChunkRegs& rg) {
+                                           bool skip_halo, int q, int dbg, ChunkRegs& rg) {
     int cg = cc * 16;
     const size_t in_vox = (size_t)p.Di * p.Hi * p.Wi;
     const __half* base;
@@ -277,15 +276,6 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
     }
     if (dbg & 64) ss = nullptr;
     rg.skip_halo = skip_halo;
-    if (want_w) {
-        const int nw = taps * 64;
-        const __half* wsrc = p.wpk + ((size_t)cc * taps * 2) * p.Cout * 8 + (size_t)tc.cy * 32 * 8;
-#pragma unroll
-        for (int b = 0; b < WS_WB; ++b) {
-            const int i = min(q + b * WS_PROD, nw - 1);
-            rg.wv[b] = *(const uint4*)((const unsigned char*)wsrc + ((unsigned)(i >> 5) * (unsigned)p.Cout + (unsigned)(i & 31)) * 16u);
-        }
-    }
     if (skip_halo) return;
     rg.ok = it.ok;
     rg.live = live;
@@ -315,6 +305,29 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
     }
 }
 
+// The chunk's weights (taps KiB) straight from L2 into the LDS buffer with LDS-DMA: no staging VGPRs, no ds_write pass.
+// One global_load_lds_dwordx4 moves 64 lanes x 16 B to [M0 + lane * 16]; item i = q + b * WS_PROD lands at dst_w + i * 16,
+// i.e. every wave writes whole 1 KiB blocks.  Scalar-base source form (see prod_issue).  The caller waits (vmcnt) before
+// the chunk barrier: hipcc does not count these.
+__device__ __forceinline__ void dma_weights(const ConvArgs& p, int cc, int cy, unsigned char* dst_w, int q, int taps) {
+    const int nw = taps * 64;
+    const __half* wsrc = p.wpk + ((size_t)cc * taps * 2) * p.Cout * 8 + (size_t)cy * 32 * 8;
+    const unsigned lds0 = (unsigned)(size_t)dst_w + (unsigned)((q >> 6) * 64) * 16u;   // this wave's first block
+#pragma unroll
+    for (int b = 0; b < WS_WB; ++b) {
+        const int i = q + b * WS_PROD;
+        if (i < nw) {  // whole waves pass or fail together except in the last block (nw is a multiple of 64)
+            const unsigned voff = ((unsigned)(i >> 5) * (unsigned)p.Cout + (unsigned)(i & 31)) * 16u;
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(b * WS_PROD) * 16u);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(voff), "s"(wsrc), "s"(m0v)
+                         : "memory");
+        }
+    }
+}
+
 template <bool SS, bool EDGE>
 __device__ __forceinline__ void commit_items(const ChunkRegs& rg, unsigned char* d0, int nv, unsigned slope2) {
     // distinct markers keep hipcc from merging the copies back into one path with per-item masks
@@ -333,17 +346,9 @@ __device__ __forceinline__ void commit_items(const ChunkRegs& rg, unsigned char*
     }
 }
 
-__device__ __forceinline__ void prod_commit(const ConvArgs& p, ChunkRegs& rg, unsigned char* dst_in, unsigned char* dst_w, int q,
-                                            int HV, int plane, int taps, int dbg) {
+__device__ __forceinline__ void prod_commit(const ConvArgs& p, ChunkRegs& rg, unsigned char* dst_in, int q, int HV, int plane,
+                                            int dbg) {
     const int nv = (dbg & 32) ? 0 : (HV + WS_PROD / 2 - 1) / (WS_PROD / 2);
-    if (dst_w) {
-        const int nw = taps * 64;
-#pragma unroll
-        for (int b = 0; b < WS_WB; ++b) {
-            const int i = min(q + b * WS_PROD, nw - 1);  // clamped lanes rewrite item nw-1 with identical data
-            *(uint4*)(dst_w + i * 16) = rg.wv[b];
-        }
-    }
     if (rg.skip_halo) return;
     // the (scale, shift) words stay in VGPRs: a packed fp16 fma takes at most one scalar operand, so SGPR copies cost
     // a v_mov (+ hazard nops) per use -- more instructions than the transform itself
@@ -533,8 +538,6 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 #pragma unroll
         for (int j = 0; j < WS_MAXV; ++j) rg.d[j] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < WS_WB; ++j) rg.wv[j] = make_uint4(0, 0, 0, 0);
-#pragma unroll
         for (int j = 0; j < 8; ++j) rg.ssw[j] = 0;
         rg.ok = rg.live = 0;
         rg.has_ss = 0;
@@ -543,11 +546,13 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         bool reuse = false;
         const bool want_w = !(resident_w || (dbg & 16));
         int pcc = 0;  // chunk within the tile of the next chunk to issue
+        int w_cc = 0, w_cy = 0;  // (chunk, cout chunk) of the chunk issued last = the one committed next (its weights go by DMA)
         const bool live = !(dbg & 2);
         if (live && my_chunks > 0) {
             ptc = decode_tile(p, walk.first);
             prod_setup(p, ptc, pc, items);
-            prod_issue(p, ptc, items, pc.in_halo, 0, want_w, false, q, taps, dbg, rg);
+            prod_issue(p, ptc, items, pc.in_halo, 0, false, q, dbg, rg);
+            w_cy = ptc.cy;
             if (++pcc == ncc) pcc = 0;
         }
         for (int g = -1; g < my_chunks; ++g) {
@@ -558,7 +563,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     WS_STAMP(7);
                 }
-                prod_commit(p, rg, nxt, want_w ? nxt + 2 * plane : nullptr, q, HV, plane, taps, dbg);
+                if (want_w) dma_weights(p, w_cc, w_cy, nxt + 2 * plane, q, taps);
+                prod_commit(p, rg, nxt, q, HV, plane, dbg);
+                // the DMA was issued before the commit's ~2 000 cycles of work and nothing else of ours is in flight here.
+                // (Waiting at the end of the interval instead, with vmcnt(number of halo loads issued since), measured 6 %
+                // slower.)
+                if (want_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 WS_STAMP(2);
                 if (g + 2 < my_chunks) {
                     if (pcc == 0) {
@@ -567,7 +577,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                         if (!reuse) prod_setup(p, ptc, pc, items);
                         WS_STAMP(8);
                     }
-                    prod_issue(p, ptc, items, pc.in_halo, pcc, want_w, reuse, q, taps, dbg, rg);
+                    prod_issue(p, ptc, items, pc.in_halo, pcc, reuse, q, dbg, rg);
+                    w_cc = pcc;
+                    w_cy = ptc.cy;
                     if (++pcc == ncc) pcc = 0;
                 }
                 WS_STAMP(3);
