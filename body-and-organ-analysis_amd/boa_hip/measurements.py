@@ -81,7 +81,10 @@ def _metrics(st: Optional[dict], ml_per_voxel: float, auto_mean, auto_std, cnr_n
                            "min_hu": st["min"], "median_hu": st["median"], "max_hu": st["max"],
                            "25th_percentile_hu": st["p25"], "75th_percentile_hu": st["p75"]}
     if auto_mean is not None and auto_std is not None and not cnr_none:
-        out["cnr"] = (st["mean"] - auto_mean) / auto_std
+        # numpy scalar arithmetic like the reference (`np.mean(hu_region) - autochthon_mean) / autochthon_std`, :117-119): a
+        # constant-HU autochthon (std 0) gives inf / nan with a RuntimeWarning there, not a ZeroDivisionError
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out["cnr"] = (np.float64(st["mean"]) - auto_mean) / np.float64(auto_std)
     else:
         out["cnr"] = None
     return out

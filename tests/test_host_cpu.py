@@ -224,3 +224,13 @@ def test_measurement_label_maps_match_reference_tables():
     assert label_maps.class_map("total") == label_maps.CLASS_MAP_TOTAL
     assert label_maps.output_name("lung_vessels") == "lung_vessels_airways" and label_maps.output_name("total") == "total"
     assert label_maps.cnr_adjusted_regions() == {k: set(v) for k, v in g["cnr_adjusted_regions"].items()}
+
+
+def test_cnr_with_constant_autochthon_follows_numpy_semantics():
+    """BOA/compute/measurements.py:117-119 divides numpy scalars: std 0 of the autochthon gives inf / nan, no exception."""
+    from boa_hip import measurements as M
+    st = {"n": 10, "mean": 50.0, "std": 2.0, "min": 40.0, "median": 50.0, "max": 60.0, "p25": 45.0, "p75": 55.0}
+    assert M._metrics(st, 0.003375, 30.0, 4.0)["cnr"] == 5.0
+    assert np.isposinf(M._metrics(st, 0.003375, 30.0, 0.0)["cnr"])
+    assert np.isnan(M._metrics(st, 0.003375, 50.0, 0.0)["cnr"])
+    assert M._metrics(st, 0.003375, None, None)["cnr"] is None

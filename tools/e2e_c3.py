@@ -45,9 +45,25 @@ pipe = BcaPipelineHip(ctx, bca_models["body_parts"], bca_models["body_regions"],
 out = timed(f"bca (2 nets x {1 if fast else 5} folds, post-processing, tissues, JSON)", lambda: pipe.run(ct, aff, total_seg=total))
 pipe.close()
 lm = label_maps.measurement_label_map("total")
-ct_l = np.ascontiguousarray(ct.transpose(2, 1, 0))
-meas = timed("total-measurements (295 regions + pulmonary fat + CNR)", lambda: M.total_measurements(
-    ctx, ct_l, np.ascontiguousarray(total.transpose(2, 1, 0)), lm, (1.5, 1.5, 1.5)))
+# (z,y,x) views made on the device, as compute/measurements.py does (a host transpose of 201 M voxels costs ~0.5 s each)
+from boa_hip.devarray import DevArray  # noqa: E402
+
+
+def _measure():
+    d_f = DevArray.from_numpy(ctx, ct)
+    d_ct = d_f.transpose((2, 1, 0)).contiguous(np.int16, force_copy=True)
+    d_f.free()
+    d_s = DevArray.from_numpy(ctx, total)
+    d_lab = d_s.transpose((2, 1, 0)).contiguous(force_copy=True)
+    d_s.free()
+    try:
+        return M.total_measurements(ctx, None, None, lm, (1.5, 1.5, 1.5), d_ct=d_ct.buf, d_lab=d_lab.buf, shape=d_ct.shape)
+    finally:
+        d_ct.free()
+        d_lab.free()
+
+
+meas = timed("total-measurements (295 regions + pulmonary fat + CNR; upload + device transposes included)", _measure)
 print("labels in total:", len(np.unique(total)), "regions 255:", int((out["body_regions"] == 255).sum()),
       "tissue voxels:", int((out["tissues"] > 0).sum()), "groups:", list(out["bca_measurements"]["aggregated"])[:4])
 ctx.close()
