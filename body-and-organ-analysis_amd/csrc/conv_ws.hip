@@ -868,7 +868,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     const int taps = a0.k0 * a0.k1 * a0.k2;
     const int HV = t.h[0] * t.h[1] * t.h[2];
     const int resident = conv_ws_resident(HV, taps, (a0.C0 + a0.C1) / 16, a0.Cout) ? 1 : 0;
-    BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi < 16777216.0 && std::max(a0.C0, a0.C1) * 2 < 16777216,
+    BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi <= 16777216.0 && std::max(a0.C0, a0.C1) * 2 < 16777216,
                 "conv_ws: more than 2^24 input voxels per sample (24-bit offset multiply)");
     BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi * std::max(a0.C0, a0.C1) * 2.0 < 4294967296.0,
                 "conv_ws: one sample of the input exceeds 4 GiB (32-bit voxel offsets)");
