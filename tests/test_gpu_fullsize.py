@@ -1,0 +1,203 @@
+"""BASELINE.json's full sizes (configs[1] 512^3, configs[2] 512x512x768) on the GPU: the integer / fp16 stages against
+the oracle evaluated at the same size where it finishes in seconds (tile-loop accumulation order, normalise + argmax +
+merge, nearest resampling, voxel aggregation), and size-independent properties where it does not (constant logits survive
+the Gaussian-weighted aggregation; a whole `total` volume is reproducible run to run).  Everything here is bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from boa_hip.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def test_tile_loop_accumulation_order_512(ctx):
+    """configs[1] geometry: 512^3, patch 128^3, step 0.8 -> 125 tiles in the reference's x->y->z order.  One head with
+    per-tile constant logits: the fp16 accumulator and n_predictions must equal the oracle's sequential fp16 `+=`
+    (NN/inference/predict_from_raw_data.py:611-614) bit for bit at every one of the 134 M voxels, and the normalised
+    logits (fp16 divide) too."""
+    from boa_hip import sliding_window as sw
+    from boa_hip._lib import check
+    from oracle import sliding_window as osw
+    V, P = [512, 512, 512], [128, 128, 128]
+    origins = sw.get_sliding_window_origins(V, P, 0.8)
+    assert len(origins) == 125
+    g16 = np.ascontiguousarray(sw.compute_gaussian(tuple(P), 1. / 8, 10))
+    rng = np.random.default_rng(3)
+    vals = rng.normal(0, 7, size=len(origins)).astype(np.float32)
+    nv = 512 ** 3
+    acc, n = ctx.zeros(nv * 2), ctx.zeros(nv * 2)
+    d_g = ctx.from_numpy(g16.view(np.uint16))
+    d_p = ctx.alloc(128 ** 3 * 4)
+    o_acc = np.zeros((1, *V), dtype=np.float16)
+    o_n = np.zeros(V, dtype=np.float16)
+    for v, o in zip(vals, origins):
+        d_p.upload(np.full(128 ** 3, v, dtype=np.float32))
+        check(ctx.lib.boa_accumulate_tile(ctx.h, d_p.vp, d_g.vp, acc.vp, n.vp, 1, _i3(P), _i3(V), _i3(o)))
+        osw.accumulate_tile(o_acc, o_n, np.full((1, *P), v, dtype=np.float32), g16, tuple(int(x) for x in o))
+    ctx.sync()
+    np.testing.assert_array_equal(n.download(tuple(V), np.uint16), o_n.view(np.uint16))
+    np.testing.assert_array_equal(acc.download((1, *V), np.uint16), o_acc.view(np.uint16))
+    flag = ctx.zeros(4)
+    check(ctx.lib.boa_finalize_labels(ctx.h, acc.vp, n.vp, 1, _i3(V), None, 0, 0, 1, None, 0, None, None, None, flag.vp))
+    want = osw.finalize_logits(o_acc, o_n)
+    np.testing.assert_array_equal(acc.download((1, *V), np.uint16), want.view(np.uint16))
+    assert int(flag.download((1,), np.int32)[0]) == 0
+    for b in (acc, n, d_g, d_p, flag):
+        b.free()
+
+
+def test_constant_logits_survive_aggregation_512(ctx):
+    """Size-independent property at 512^3: when every tile predicts the same constant per class, acc / n gives that
+    constant back at every voxel up to the fp16 roundings of the sums (<= 125 half-ulp steps are far below the class
+    gaps), so the argmax is the largest class everywhere and the merge writes its global label."""
+    from boa_hip import sliding_window as sw
+    from boa_hip._lib import check
+    V, P, Cn = [512, 512, 512], [128, 128, 128], 3
+    origins = sw.get_sliding_window_origins(V, P, 0.8)
+    nv = 512 ** 3
+    acc, n = ctx.zeros(Cn * nv * 2), ctx.zeros(nv * 2)
+    d_g = ctx.from_numpy(np.ascontiguousarray(sw.compute_gaussian(tuple(P), 1. / 8, 10)).view(np.uint16))
+    consts = np.array([0.25, 3.0, -1.5], dtype=np.float32)
+    d_p = ctx.from_numpy(np.repeat(consts, 128 ** 3))
+    for o in origins:
+        check(ctx.lib.boa_accumulate_tile(ctx.h, d_p.vp, d_g.vp, acc.vp, n.vp, Cn, _i3(P), _i3(V), _i3(o)))
+    lab = ctx.alloc(nv)
+    check(ctx.lib.boa_memset(ctx.h, lab.vp, 7, nv))
+    flag = ctx.zeros(4)
+    lut = np.zeros(256, dtype=np.uint8)
+    lut[:3] = [0, 42, 99]
+    check(ctx.lib.boa_finalize_labels(ctx.h, acc.vp, n.vp, Cn, _i3(V), None, 0, 0, 1, lut.ctypes.data_as(C.c_void_p), 1, lab.vp,
+                                      None, None, flag.vp))
+    got = lab.download((nv,), np.uint8)
+    assert np.all(got == 42)
+    # the logits themselves: where the summed weight is well inside the fp16 normal range (towards the volume's edges and
+    # corners the Gaussian weights fall to 1e-6 ... 6e-8, where constant x weight rounds to a few subnormal steps -- in the
+    # reference's fp16 buffers too; the argmax above is right even there)
+    w = n.download((nv,), np.uint16).view(np.float16).astype(np.float32) >= 1e-3
+    assert w.mean() > 0.85
+    logits = acc.download((Cn, nv), np.uint16).view(np.float16).astype(np.float32)
+    for c in range(Cn):
+        assert np.abs(logits[c][w] - consts[c]).max() <= 4e-3 * max(1.0, abs(float(consts[c])))
+    for b in (acc, n, d_g, d_p, lab, flag):
+        b.free()
+
+
+def test_finalize_argmax_merge_vs_numpy_512(ctx):
+    """normalise + argmax + lut + merge at 512^3 against numpy on the same fp16 bit patterns (`torch.div` in fp32 rounded to
+    fp16, numpy argmax = first maximum; TS/nnunet.py:553-556 merge: background never overwrites)."""
+    from boa_hip._lib import check
+    V, Cn = [512, 512, 512], 4
+    nv = 512 ** 3
+    rng = np.random.default_rng(9)
+    acc = rng.normal(0, 4, size=(Cn, nv)).astype(np.float16)
+    acc[:, ::7] = acc[0, ::7]                                           # ties -> lowest index
+    n = rng.uniform(0.5, 30, size=nv).astype(np.float16)
+    prev = rng.integers(0, 200, size=nv, dtype=np.uint8)
+    d_acc, d_n, d_lab = ctx.from_numpy(acc.view(np.uint16)), ctx.from_numpy(n.view(np.uint16)), ctx.from_numpy(prev)
+    flag = ctx.zeros(4)
+    lut = np.zeros(256, dtype=np.uint8)
+    lut[:Cn] = [0, 17, 3, 250]
+    check(ctx.lib.boa_finalize_labels(ctx.h, d_acc.vp, d_n.vp, Cn, _i3(V), None, 0, 0, 0, lut.ctypes.data_as(C.c_void_p), 1,
+                                      d_lab.vp, None, None, flag.vp))
+    got = d_lab.download((nv,), np.uint8)
+    q = (acc.astype(np.float32) / n.astype(np.float32)[None]).astype(np.float16)
+    am = np.argmax(q, axis=0)
+    want = np.where(am != 0, lut[am], prev)
+    np.testing.assert_array_equal(got, want)
+    for b in (d_acc, d_n, d_lab, flag):
+        b.free()
+
+
+def test_nearest_resample_512_vs_oracle(ctx):
+    """Label volume 512^3 @1.5 mm -> 3 mm grid and a non-integer zoom back (TS/resampling.py order 0): bit-exact against the
+    explicit index formula of scipy.ndimage.zoom(order=0, mode="nearest")."""
+    from boa_hip import resample as R
+    from oracle import resample as oresample
+    rng = np.random.default_rng(2)
+    lab = rng.integers(0, 118, size=(64, 64, 64), dtype=np.uint8).repeat(8, 0).repeat(8, 1).repeat(8, 2)
+    d_in = ctx.from_numpy(lab)
+    for out_shape in ((256, 256, 256), (341, 300, 427)):
+        d_out = R.resample_nearest_device(ctx, d_in, lab.shape, out_shape)
+        got = d_out.download(out_shape, np.uint8)
+        d_out.free()
+        want = oresample.spline_zoom_explicit(lab, out_shape, order=0)
+        np.testing.assert_array_equal(got, want)
+    d_in.free()
+
+
+def test_voxel_aggregation_config3_vs_numpy(ctx):
+    """configs[2] size (768 x 512 x 512 = 201 M voxels): per-label HU histogram (counts, exact HU sums) against
+    numpy.bincount, and the slice-wise tissue counts against the whole-volume counts."""
+    from boa_hip import bca
+    from boa_hip import measurements as M
+    from boa_hip import synthetic
+    shape = (768, 512, 512)
+    ct = np.ascontiguousarray(synthetic.ct_phantom((512, 512, 768), seed=3).transpose(2, 1, 0))
+    rng = np.random.default_rng(0)
+    lab = rng.integers(0, 118, size=(48, 32, 32), dtype=np.uint8).repeat(16, 0).repeat(16, 1).repeat(16, 2)
+    n = ct.size
+    d_ct, d_lab = ctx.from_numpy(ct), ctx.from_numpy(lab)
+    hist = M.label_hu_histogram(ctx, d_ct, d_lab, n)
+    counts = np.bincount(lab.ravel(), minlength=256)
+    counts[0] = 0                                                       # background is never measured
+    np.testing.assert_array_equal(hist.sum(axis=1), counts)
+    hu = np.arange(hist.shape[1], dtype=np.int64) + M.HU_MIN
+    sums = np.bincount(lab.ravel(), weights=ct.ravel().astype(np.float64), minlength=256)   # exact: |sum| < 2^53
+    np.testing.assert_array_equal((hist.astype(np.int64) * hu[None]).sum(axis=1)[1:], sums[1:].astype(np.int64))
+    # tissues: regions from the label pattern (values 1..11), parts all TORSO -> slice tables must add up to the volume
+    regions = (lab % 12).astype(np.uint8)
+    d_reg = ctx.from_numpy(regions)
+    tis, cnt, hsum = bca.tissue_aggregate(ctx, d_ct, d_reg, None, shape)
+    t = tis.download(shape, np.uint8)
+    whole = np.bincount(t.ravel(), minlength=8)[:8]
+    np.testing.assert_array_equal(cnt[:, 0, 1:].sum(axis=0).astype(np.int64), whole[1:])   # (tissue 0 = none: not counted)
+    per_tissue_hu = np.bincount(t.ravel(), weights=ct.ravel().astype(np.float64), minlength=8)[:8]
+    np.testing.assert_array_equal(hsum[:, 0, 1:].sum(axis=0), per_tissue_hu[1:].astype(np.int64))
+    for b in (d_ct, d_lab, d_reg, tis):
+        b.free()
+
+
+def test_total_512_is_reproducible(ctx):
+    """Two runs of the whole configs[1] volume (5 synthetic part models, 625 tile forwards) give the same label volume:
+    atomics-free statistics and a fixed tile schedule make the result a function of (input, weights, tile batch)."""
+    from boa_hip import label_maps, synthetic
+    from boa_hip._lib import check
+    from boa_hip.predictor import HipPredictor
+    shape = [512, 512, 512]
+    nvox = 512 ** 3
+    ct = synthetic.ct_phantom(shape, seed=20260928)
+    d_ct, d_vol, d_lab = ctx.from_numpy(ct), ctx.alloc(nvox * 4), ctx.alloc(nvox)
+    models = synthetic.total_part_models()
+    preds = []
+    for tid, cfg, blob, _ in models:
+        p = HipPredictor(ctx, cfg.geometry, tile_step_size=0.8, max_batch=8)
+        p.set_parameters([blob])
+        preds.append((tid, p))
+    ip = models[0][1].intensity_properties["0"]
+    work = {}
+    runs = []
+    for _ in range(2):
+        check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, 0, d_vol.vp, nvox, ip["mean"], ip["std"], ip["percentile_00_5"],
+                                       ip["percentile_99_5"]))
+        d_lab.zero()
+        for tid, p in preds:
+            p.predict_segmentation_device(d_vol, shape, d_lab, lut=label_maps.part_lut(tid), merge=True, work=work)
+        runs.append(d_lab.download((nvox,), np.uint8))
+    np.testing.assert_array_equal(runs[0], runs[1])
+    assert len(np.unique(runs[0])) > 50
+    for _, p in preds:
+        p.close()
+    for b in list(work.values()) + [d_ct, d_vol, d_lab]:
+        b.free()
