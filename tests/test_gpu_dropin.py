@@ -99,3 +99,57 @@ def test_compute_all_models_total_bca(tmp_path, monkeypatch):
     # writes: the model is (silently, as in the reference) absent from total-measurements.json
     with open(out / "total-measurements.json") as f:
         assert "lung_vessels" not in json.load(f)["segmentations"]
+
+
+def test_error_conventions(tmp_path, monkeypatch):
+    """SURVEY 8b "Error conventions": the exception types of the reference's path -- ValueError for a non-3-D CT
+    (BOA/compute/inference.py:37-38), ValueError for a 2-D array and TypeError for a structured dtype
+    (TS/nnunet.py:403-411), ValueError when segmentation and CT spacing differ (BOA/compute/measurements.py:272-278),
+    RuntimeError when the normalised logits contain inf (predict_from_raw_data.py:622-625), ValueError for unknown models."""
+    from boa_hip import model_store, nifti, plans
+    from boa_hip.compute.config import resolve_models
+    from boa_hip.compute.inference import compute_all_models, get_context
+    from boa_hip.compute.measurements import compute_measurements
+    from boa_hip.predictor import HipPredictor
+    from boa_hip.task import SegmentationTask
+    root = tmp_path / "results"
+    _write_models(str(root), (1.5, 1.5, 1.5), (5.0, 1.5, 1.5))
+    monkeypatch.setenv("nnUNet_results", str(root))
+    params = {"preview": False, "fast": False, "ml": True, "nr_thr_resamp": 1, "nr_thr_saving": 1, "quiet": True,
+              "verbose": False, "device": "gpu", "license_number": None}
+    aff = np.diag([1.5, 1.5, 1.5, 1.0])
+    ct4 = np.zeros((8, 8, 8, 2), dtype=np.int16)
+    nifti.save(tmp_path / "ct4d.nii.gz", ct4, aff)
+    with pytest.raises(ValueError, match="Only 3D CT scans"):
+        compute_all_models(tmp_path / "ct4d.nii.gz", tmp_path / "o1", ["total"], params)
+    with pytest.raises(ValueError, match="Unknown model"):
+        resolve_models("total+nonsense", strict=True)
+    assert resolve_models("total+nonsense") == {"total"}            # non-strict: logged and ignored, as in the reference
+    ctx = get_context("gpu")
+    t = SegmentationTask(ctx, "total", model_store.load_task_models("total"), resample=1.5, multimodel=True)
+    with pytest.raises(ValueError, match="2D images"):
+        t.predict_image(np.zeros((16, 16), dtype=np.int16), aff)
+    with pytest.raises(TypeError, match="structured"):
+        t.predict_image(np.zeros((8, 8, 8), dtype=[("a", np.int16), ("b", np.int16)]), aff)
+    t.close()
+    # spacing mismatch between CT and segmentation
+    ct = np.full((16, 16, 16), 30, dtype=np.int16)
+    nifti.save(tmp_path / "ct.nii.gz", ct, aff)
+    seg_dir = tmp_path / "seg"
+    seg_dir.mkdir()
+    nifti.save(seg_dir / "total.nii.gz", np.ones((16, 16, 16), dtype=np.uint8), np.diag([3.0, 3.0, 3.0, 1.0]))
+    with pytest.raises(ValueError, match="spacing of the image and of the segmentation"):
+        compute_measurements(tmp_path / "ct.nii.gz", seg_dir, ["total"], cnr_adjustment=False, ctx=ctx)
+    # inf in the normalised logits: weights that overflow fp16
+    pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=3, spacing=(1.5, 1.5, 1.5))
+    cfg = plans.model_config_from_plans(pj, dj)
+    sd = plans.synthetic_state_dict(cfg.geometry, seed=1)
+    for k in sd:
+        if "seg_layers" in k and k.endswith("weight"):
+            sd[k] = sd[k] * 1e6
+    p = HipPredictor(ctx, cfg.geometry, tile_step_size=0.5)
+    p.set_parameters([plans.weight_blob_from_state_dict(cfg.geometry, sd)])
+    x = np.random.default_rng(0).normal(0, 1, size=(1, 40, 36, 33)).astype(np.float32)
+    with pytest.raises(RuntimeError, match="inf"):
+        p.predict_sliding_window_return_logits(x)
+    p.close()
