@@ -75,9 +75,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=4)
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events (measures their overhead; roofline fields become 0)")
-    ap.add_argument("--shard", choices=["volumes", "tiles"], default="volumes",
+    ap.add_argument("--shard", choices=["volumes", "tiles", "models"], default="volumes",
                     help="N>1: 'volumes' = one volume per GPU, no data-path collective (weak scaling, default); 'tiles' = all "
-                         "GPUs share each volume: tile rows split, overlap slabs over RCCL (strong scaling, latency mode)")
+                         "GPUs share each volume: tile rows split, overlap slabs over RCCL (strong scaling, latency mode); "
+                         "'models' = all GPUs share each volume: the five part models dealt out to the ranks, label volumes "
+                         "all-reduced and merged in part order (strong scaling, bit-identical at any tile batch)")
     ap.add_argument("--shard-mode", choices=["exact", "allreduce"], default="exact",
                     help="--shard tiles: ordered send/recv hand-over (bit-exact) or pairwise fp16 all-reduce of the slabs")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -118,12 +120,18 @@ def main():
     if dist is not None and args.shard == "tiles":
         from boa_hip import tile_shard as ts
         tile_shard = ts.TileShard(ts.ShardComm(dist, rank, world, f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"), args.shard_mode)
-    ct = synthetic.ct_phantom(shape, seed=20260928 + (0 if tile_shard else rank))
+    model_comm = None
+    if dist is not None and args.shard == "models":
+        from boa_hip import tile_shard as ts
+        model_comm = ts.ShardComm(dist, rank, world, f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+    shared = tile_shard is not None or model_comm is not None          # all ranks work on the same volume
+    ct = synthetic.ct_phantom(shape, seed=20260928 + (0 if shared else rank))
     log(f"setup (synthetic weights + phantom {shape}) {time.perf_counter() - t0:.1f}s")
     nvox = int(np.prod(shape))
     d_ct = ctx.from_numpy(ct)
     d_vol = ctx.alloc(nvox * 4)
     d_lab = ctx.alloc(nvox)
+    d_part = ctx.alloc(nvox) if args.shard == "models" else None
     work = {}
     ip = models[0][1].intensity_properties["0"]
     tiles_per_volume = 0
@@ -140,6 +148,15 @@ def main():
         check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, 0, d_vol.vp, nvox, ip["mean"], ip["std"], ip["percentile_00_5"],
                                        ip["percentile_99_5"]))
         d_lab.zero()
+        if model_comm is not None:
+            from boa_hip import tile_shard as ts
+            for k, (tid, cfg, p) in enumerate(predictors):
+                check(ctx.lib.boa_memset(ctx.h, d_part.vp, 0, nvox))
+                if k % world == rank:
+                    p.predict_segmentation_device(d_vol, shape, d_part, lut=label_maps.part_lut(tid), merge=False, work=work)
+                ts.all_reduce_labels(ctx, model_comm, d_part, nvox)
+                check(ctx.lib.boa_label_overlay(ctx.h, d_part.vp, nvox, d_lab.vp))
+            return
         for tid, cfg, p in predictors:
             p.predict_segmentation_device(d_vol, shape, d_lab, lut=label_maps.part_lut(tid), merge=True, work=work,
                                           shard=tile_shard)
@@ -181,13 +198,14 @@ def main():
         log(f"  sum of kernel times {total_ms:.1f} ms of {elapsed * 1e3:.1f} ms wall; label checksum {labels_sum}")
         res = {
             "metric": "CT volumes/sec (512^3 @1.5 mm, total) on MI355X",
-            "value": (1 if tile_shard else n_gpus) * args.steps / elapsed, "unit": "volumes/s", "n_gpus": n_gpus, "steps": args.steps,
+            "value": (1 if shared else n_gpus) * args.steps / elapsed, "unit": "volumes/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
-            "scaling": "strong" if tile_shard else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "scaling": "strong" if shared else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"configs[1]: single {shape[0]}x{shape[1]}x{shape[2]} @1.5 mm volume, `total` "
                                    f"(5 part models, {tiles_per_volume} tile forwards of 128^3, step 0.8), " +
-                                   (f"each volume tile-sharded over {n_gpus} GPUs ({args.shard_mode} slab exchange)"
-                                    if tile_shard else "1 volume per GPU"),
+                                   (f"each volume tile-sharded over {n_gpus} GPUs ({args.shard_mode} slab exchange)" if tile_shard
+                                    else f"the part models of each volume dealt out to {n_gpus} GPUs" if model_comm
+                                    else "1 volume per GPU"),
                        "tiles_per_volume": tiles_per_volume, "tile_batch": args.batch,
                        "tflop_per_volume": flops_per_volume / 1e12,
                        "precision": "fp16 activations/weights, fp32 MFMA accumulate, fp16 logit accumulators (reference semantics)"},

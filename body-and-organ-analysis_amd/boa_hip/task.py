@@ -97,6 +97,10 @@ class SegmentationTask:
         # tile_shard.TileShard: several ranks share every volume (tile rows split, overlap slabs exchanged); each rank
         # must be given the same input and ends with the same labels.  None = this process handles whole volumes.
         self.shard = None
+        # tile_shard.ShardComm: the part models of a multi-model task are dealt out to the ranks (model k -> rank k mod
+        # world, SURVEY 8e granularity 2); every rank must be given the same input and ends with the same labels.  Each
+        # model runs exactly as on one GPU (same tiles, same batches), so the result is bit-identical to the one-GPU run.
+        self.model_shard = None
 
     def close(self):
         for _, _, p, _ in self.parts:
@@ -116,6 +120,8 @@ class SegmentationTask:
                 vol.free()
             vol = self._work["vol"] = ctx.alloc(n * 4)
         d_labels.zero()
+        if self.model_shard is not None and self.model_shard.world > 1 and self.multimodel:
+            return self._predict_zyx_model_sharded(d_ct, shape, d_labels, in_dtype, vol, n)
         for task_id, cfg, p, lut in self.parts:
             ip = cfg.intensity_properties["0"]
             # every model normalises with its own plans' intensity properties (default_preprocessor.py:336-348)
@@ -123,6 +129,26 @@ class SegmentationTask:
                                            ip["percentile_00_5"], ip["percentile_99_5"]), "boa_ct_normalize")
             p.predict_segmentation_device(vol, list(shape), d_labels, lut=lut, merge=self.multimodel, work=self._work,
                                           shard=self.shard)
+
+    def _predict_zyx_model_sharded(self, d_ct, shape, d_labels, in_dtype, vol, n):
+        from . import tile_shard as ts
+        ctx, comm = self.ctx, self.model_shard
+        part = self._work.get("part")
+        if part is None or part.nbytes < n:
+            if part is not None:
+                part.free()
+            part = self._work["part"] = ctx.alloc(n)
+        for k, (task_id, cfg, p, lut) in enumerate(self.parts):
+            check(ctx.lib.boa_memset(ctx.h, part.vp, 0, n), "boa_memset")
+            if k % comm.world == comm.rank:
+                ip = cfg.intensity_properties["0"]
+                check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, in_dtype, vol.vp, n, ip["mean"], ip["std"],
+                                               ip["percentile_00_5"], ip["percentile_99_5"]), "boa_ct_normalize")
+                p.predict_segmentation_device(vol, list(shape), part, lut=lut, merge=False, work=self._work)
+            # the owner's label volume reaches every rank (sum over disjoint supports), then the reference's merge in part
+            # order: `seg_combined[seg == jdx] = class_map_inv[name]` (TS/nnunet.py:553-556)
+            ts.all_reduce_labels(ctx, comm, part, n)
+            check(ctx.lib.boa_label_overlay(ctx.h, part.vp, n, d_labels.vp), "boa_label_overlay")
 
     def _check_plan_spacing(self, spacing_xyz):
         sp_zyx = [float(s) for s in spacing_xyz[::-1]]

@@ -50,10 +50,11 @@ def _ct():
     return ct
 
 
-def _predict(ctx, shard=None):
+def _predict(ctx, shard=None, model_shard=None, max_batch=1):
     from boa_hip.task import SegmentationTask
     models, luts = _models()
-    task = SegmentationTask(ctx, "total", models, resample=1.5, multimodel=True, max_batch=1, part_luts=luts)
+    task = SegmentationTask(ctx, "total", models, resample=1.5, multimodel=True, max_batch=max_batch, part_luts=luts)
+    task.model_shard = model_shard
     task.step_size = 0.5
     for _, _, p, _ in task.parts:
         p.tile_step_size = 0.5
@@ -78,7 +79,11 @@ def _worker(rank, world, port, mode, q):
     from boa_hip.device import Context
     dist = D.init("gloo", rank, world)
     ctx = Context(0)
-    lab = _predict(ctx, ts.TileShard(ts.ShardComm(dist, rank, world, "cpu"), mode))
+    comm = ts.ShardComm(dist, rank, world, "cpu")
+    if mode == "models":
+        lab = _predict(ctx, model_shard=comm, max_batch=4)
+    else:
+        lab = _predict(ctx, ts.TileShard(comm, mode))
     q.put((rank, lab))
     dist.barrier()
     ctx.close()
@@ -130,6 +135,18 @@ def test_allreduce_mode_flips_only_near_ties(single):
     outside[lo:hi] = False
     assert not flips[outside].any()
     assert flips.mean() < 2e-3
+
+
+def test_model_sharding_bit_identical_at_any_batch():
+    """SURVEY 8e granularity 2: the part models dealt out to the ranks; each model runs exactly as on one GPU (same tile
+    batches), so the merged labels equal the one-GPU result bit for bit also with a tile batch > 1."""
+    from boa_hip.device import Context
+    c = Context(0)
+    want = _predict(c, max_batch=4)
+    c.close()
+    got = _run(2, "models")
+    np.testing.assert_array_equal(got[0], want)
+    np.testing.assert_array_equal(got[1], want)
 
 
 def test_rccl_plumbing_single_rank(single):
