@@ -85,11 +85,14 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
     bool found = false;
     const int force = conv_variant_override();
     // wave M-tile shapes: 32 voxels = w0 x w1 x w2 (powers of two), contiguous axis as long as possible first
+    // (second pass: extents so small that no wave tile fits without overhang -- e.g. a last axis of 2 -- take any shape; the
+    // kernels mask the overhang)
+    for (int relax = 0; relax < 2 && !found; ++relax)
     for (int w2 = 32; w2 >= 4; w2 >>= 1) {
-        if (w2 > next_pow2(dims[2])) continue;
+        if (!relax && w2 > next_pow2(dims[2])) continue;
         for (int w1 = 1; w1 * w2 <= 32; w1 <<= 1) {
             const int w0 = 32 / (w2 * w1);
-            if (w1 > next_pow2(dims[1]) || w0 > next_pow2(dims[0])) continue;
+            if (!relax && (w1 > next_pow2(dims[1]) || w0 > next_pow2(dims[0]))) continue;
             const int w[3] = {w0, w1, w2};
             for (int variant : {1, 0}) {
                 if (force >= 0 && variant != force) continue;

@@ -188,6 +188,9 @@ def _conv_case(ctx, N, Cin, dims, Cout, k, s, norm, seed):
     (1, 320, (4, 4, 4), 320, (3, 3, 3), (1, 1, 1)),        # bottleneck
     (1, 256, (8, 8, 8), 320, (3, 3, 3), (2, 2, 2)),
     (1, 32, (5, 7, 9), 32, (3, 3, 3), (1, 1, 1)),          # odd sizes
+    (3, 640, (5, 9, 2), 128, (1, 3, 3), (1, 1, 1)),        # last axis shorter than any wave tile (found by tools/fuzz_conv.py)
+    (1, 320, (8, 6, 2), 128, (3, 3, 3), (2, 1, 1)),
+    (3, 64, (3, 2, 4), 320, (3, 3, 3), (1, 2, 1)),
 ])
 def test_conv_mfma_raw(ctx, N, Cin, dims, Cout, k, s):
     """Raw conv (+bias) on f16 MFMA vs torch-CPU fp32 on the same fp16-rounded operands.
