@@ -1,7 +1,7 @@
 // Resampling of TS/resampling.change_spacing on the device (fp64):
 //   order 3: scipy.ndimage.zoom(data, zoom, order=3, mode="nearest") restated -- edge-pad by 12, separable cubic
 //            B-spline prefilter (pole sqrt(3)-2, gain 6, 'reflect' boundary initialisation, which is what scipy uses for
-//            mode="nearest"), then the 4x4x4 tap interpolation with coordinate in = out * (n_in-1)/(n_out-1) clamped to
+//            mode="nearest"), then the 4x4x4 tap interpolation with coordinate in = out * (n_in-1)/(n_out-1) inside
 //            the unpadded extent, terms accumulated in scipy's order (first axis outermost), `.astype(int32)`
 //            truncation (TS/resampling.py:36-37,211,216-217);
 //   order 0: nearest gather, index floor(in + 0.5) clamped.
@@ -80,9 +80,11 @@ __global__ __launch_bounds__(256) void k_zoom_cubic(const double* __restrict__ c
     const int PY = Y + 2 * NPAD, PZ = Z + 2 * NPAD;
     double wx[4], wy[4], wz[4];
     int sx, sy, sz;
-    cubic_weights(fmin(fmax((double)ox * zx, 0.0), (double)(X - 1)) + NPAD, &sx, wx);
-    cubic_weights(fmin(fmax((double)oy * zy, 0.0), (double)(Y - 1)) + NPAD, &sy, wy);
-    cubic_weights(fmin(fmax((double)oz * zz_, 0.0), (double)(Z - 1)) + NPAD, &sz, wz);
+    // no clamp to [0, n_in - 1]: the last coordinate (n_out - 1) * fl((n_in - 1) / (n_out - 1)) can land one ulp above n_in - 1
+    // (e.g. 42 * (46 / 42) = 46.00000000000001); scipy evaluates the spline there inside its 12-sample edge padding, and so do we
+    cubic_weights((double)ox * zx + NPAD, &sx, wx);
+    cubic_weights((double)oy * zy + NPAD, &sy, wy);
+    cubic_weights((double)oz * zz_ + NPAD, &sz, wz);
     double t = 0.0;
 #pragma unroll
     for (int a = 0; a < 4; ++a)

@@ -67,7 +67,7 @@ def _filter_axis_reflect(a: np.ndarray, axis: int) -> np.ndarray:
 def spline_zoom_explicit(data: np.ndarray, out_shape, order: int = 3) -> np.ndarray:
     """Operation-level restatement of scipy.ndimage.zoom(mode="nearest", grid_mode=False): the blueprint of the device
     kernels (csrc/resample.hip).  order 3: edge-pad by 12 (scipy._prepad_for_spline_filter), separable prefilter,
-    4x4x4-tap interpolation with in = out * (n_in-1)/(n_out-1) clamped to the unpadded extent, terms accumulated with the
+    4x4x4-tap interpolation with in = out * (n_in-1)/(n_out-1) (unclamped, see below), terms accumulated with the
     first axis outermost.  Bit-identical to ndimage.zoom (scipy 1.15.3) on every case of the tests, including the
     `.astype(int32)` truncation of G5.  order 0: index floor(in + 0.5), clamped."""
     if order == 0:
@@ -85,7 +85,7 @@ def spline_zoom_explicit(data: np.ndarray, out_shape, order: int = 3) -> np.ndar
     idxs, ws = [], []
     for n_in, n_out in zip(data.shape, out_shape):
         zf = (n_in - 1) / (n_out - 1) if n_out > 1 else 1.0
-        cc = np.clip(np.arange(n_out) * zf, 0, n_in - 1) + npad
+        cc = np.arange(n_out) * zf + npad    # (not clipped: an overshoot of one ulp past n_in - 1 is evaluated in the padding)
         fl = np.floor(cc)
         x = cc - fl
         y, zz = x, 1.0 - x

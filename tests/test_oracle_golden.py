@@ -168,3 +168,9 @@ def test_explicit_spline_zoom_matches_scipy():
         lab = rng.integers(0, 9, size=x.shape).astype(np.uint8)
         np.testing.assert_array_equal(resample.spline_zoom_explicit(lab, ref.shape, 0),
                                       ndimage.zoom(lab, zf, order=0, mode="nearest"))
+    # 47 -> 43 samples: the last coordinate 42 * fl(46 / 42) = 46.00000000000001 overshoots the input by one ulp; scipy does
+    # not clamp it (found by tools/fuzz_voxel.py)
+    x = rng.normal(size=(10, 47, 14)) * 500
+    ref = ndimage.zoom(x, (0.589242864991995, 0.9166715392459119, 1.27427627251354), order=3, mode="nearest")
+    assert ref.shape == (6, 43, 18)
+    np.testing.assert_array_equal(resample.spline_zoom_explicit(x, ref.shape, 3).view(np.uint64), ref.view(np.uint64))
