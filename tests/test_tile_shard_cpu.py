@@ -173,3 +173,57 @@ def test_plan_rows_properties():
                 if lo_b and up_b:
                     assert lo_b[1] <= up_b[0]
             assert all(plan.owned_planes(r) == (0, 0) and len(plan.tiles(r)) == 0 for r in range(plan.active, world))
+
+
+class _MailboxComm:
+    """In-process stand-in for ShardComm (exact mode only): ranks are run one after the other in ascending order, a rank's
+    upward slab is parked until the next rank picks it up.  Legal because a rank's send never depends on what it receives."""
+
+    def __init__(self, world):
+        self.world, self.rank, self.box = world, 0, {}
+
+    def shift_up(self, send, recv):
+        if send is not None:
+            self.box[self.rank + 1] = send.clone()
+        if recv is not None:
+            recv.copy_(self.box.pop(self.rank))
+
+    def pair_group(self, k):
+        raise AssertionError("exact mode only")
+
+
+def test_exact_protocol_random_geometries():
+    """Many random (volume, patch, step, world) combinations through the protocol with the numpy engine, incl. the small
+    volumes whose tile rows two apart still overlap (deferral on more than the first row, fewer active ranks)."""
+    from boa_hip import tile_shard as ts
+    from oracle import sliding_window as osw
+    rng = np.random.default_rng(42)
+    seen_multi_defer = seen_reduced = 0
+    for case in range(40):
+        patch = (int(rng.choice([8, 12, 16])), int(rng.choice([6, 8])), int(rng.choice([6, 8])))
+        shape = (int(rng.integers(patch[0], 6 * patch[0])), int(rng.integers(patch[1], 2 * patch[1] + 1)),
+                 int(rng.integers(patch[2], 2 * patch[2] + 1)))
+        step = float(rng.choice([0.5, 0.8, 1.0]))
+        world = int(rng.integers(2, 7))
+        data = np.random.default_rng(case).normal(0, 1.5, size=(1, *shape)).astype(np.float32)
+        origins = np.array([[s[0], s[1], s[2]] for s in osw.get_sliding_window_slicers(shape, patch, step)])
+        single = NumpyEngine(data, origins, patch, HEADS)
+        single.begin()
+        single.run(range(len(origins)), [0] * len(origins))
+        plan = ts.plan_rows(origins, patch[0], shape[0], world)
+        seen_reduced += plan.active < min(world, len(plan.rows))
+        comm = _MailboxComm(world)
+        covered = 0
+        for r in range(world):
+            comm.rank = r
+            eng = NumpyEngine(data, origins, patch, HEADS)
+            d = plan.defer_planes(r)
+            seen_multi_defer += len(set(plan.row_of_tile[plan.tiles(r)][d > 0])) > 1
+            lo, hi = ts.run_fold_sharded(eng, plan, comm, "exact")
+            if hi:
+                assert lo == covered
+                covered = hi
+                np.testing.assert_array_equal(eng.acc[:, lo:hi].view(np.uint16), single.acc[:, lo:hi].view(np.uint16))
+                np.testing.assert_array_equal(eng.n[lo:hi].view(np.uint16), single.n[lo:hi].view(np.uint16))
+        assert covered == shape[0] and not comm.box
+    assert seen_reduced > 0          # the plan had to give up ranks at least once
