@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
 // same 32 voxels per instruction (64 contiguous bytes each).
 typedef _Float16 hh2_t __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void k_head_mfma(HeadArgs p) {
+__global__ __launch_bounds__(256, 5) void k_head_mfma(HeadArgs p) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
     f16x8 a0, a1;
 #pragma unroll
@@ -1157,32 +1157,47 @@ __global__ __launch_bounds__(256) void k_head_mfma(HeadArgs p) {
         a0[i] = l31 < p.C ? (_Float16)p.w[l31 * 32 + 8 * kh + i] : (_Float16)0.f;
         a1[i] = l31 < p.C ? (_Float16)p.w[l31 * 32 + 16 + 8 * kh + i] : (_Float16)0.f;
     }
-    hh2_t sc0[4], sh0[4], sc1[4], sh1[4];  // packed (scale, shift) of this lane's channels, steps 0 and 1
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c0 = 8 * kh + 2 * i, c1 = 16 + 8 * kh + 2 * i;
-        sc0[i] = hh2_t{(_Float16)p.ss[2 * c0], (_Float16)p.ss[2 * c0 + 2]};
-        sh0[i] = hh2_t{(_Float16)p.ss[2 * c0 + 1], (_Float16)p.ss[2 * c0 + 3]};
-        sc1[i] = hh2_t{(_Float16)p.ss[2 * c1], (_Float16)p.ss[2 * c1 + 2]};
-        sh1[i] = hh2_t{(_Float16)p.ss[2 * c1 + 1], (_Float16)p.ss[2 * c1 + 3]};
+    // The per-lane constants -- packed (scale, shift) of this lane's 16 input channels and the 16 biases of its D rows --
+    // depend on the k-half only; they live in LDS (2 x 32 words) and are re-read per M-tile instead of occupying 32 VGPRs:
+    // the kernel waits on HBM round trips, and 114 -> ~80 VGPRs doubles the waves in flight (3 -> 6 per SIMD).
+    __shared__ __attribute__((aligned(16))) unsigned s_ss[2][16];   // [kh][step 0: sc x4, sh x4 | step 1: sc x4, sh x4]
+    __shared__ __attribute__((aligned(16))) float s_bz[2][16];
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        union {
+            unsigned u;
+            hh2_t v;
+        } cv;
+        for (int i = 0; i < 4; ++i) {
+            const int c0 = 8 * k + 2 * i, c1 = 16 + 8 * k + 2 * i;
+            cv.v = hh2_t{(_Float16)p.ss[2 * c0], (_Float16)p.ss[2 * c0 + 2]};
+            s_ss[k][i] = cv.u;
+            cv.v = hh2_t{(_Float16)p.ss[2 * c0 + 1], (_Float16)p.ss[2 * c0 + 3]};
+            s_ss[k][4 + i] = cv.u;
+            cv.v = hh2_t{(_Float16)p.ss[2 * c1], (_Float16)p.ss[2 * c1 + 2]};
+            s_ss[k][8 + i] = cv.u;
+            cv.v = hh2_t{(_Float16)p.ss[2 * c1 + 1], (_Float16)p.ss[2 * c1 + 3]};
+            s_ss[k][12 + i] = cv.u;
+        }
+        for (int i = 0; i < 16; ++i) {
+            const int c = 8 * (i >> 2) + 4 * k + (i & 3);
+            s_bz[k][i] = c < p.C ? p.bias[c] : 0.f;
+        }
     }
+    __syncthreads();
     const hh2_t sl = hh2_t{(_Float16)p.slope, (_Float16)p.slope};
-    float bz[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
-        bz[i] = c < p.C ? p.bias[c] : 0.f;
-    }
-    auto xform = [&](uint4 raw, const hh2_t* sc, const hh2_t* sh) {
+    auto xform = [&](uint4 raw, int step) {
         union {
             uint4 u;
             hh2_t v[4];
             f16x8 f;
-        } x;
+        } x, sc, sh;
         x.u = raw;
+        sc.u = *(const uint4*)&s_ss[kh][8 * step];
+        sh.u = *(const uint4*)&s_ss[kh][8 * step + 4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const hh2_t y = __builtin_elementwise_fma(x.v[i], sc[i], sh[i]);
+            const hh2_t y = __builtin_elementwise_fma(x.v[i], sc.v[i], sh.v[i]);
             x.v[i] = __builtin_elementwise_max(y, y * sl);
         }
         return x.f;
@@ -1216,10 +1231,10 @@ __global__ __launch_bounds__(256) void k_head_mfma(HeadArgs p) {
             }
         }
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xform(r0, sc0, sh0), zero, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xform(r1, sc1, sh1), d, 0, 0, 0);
+        f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xform(r0, 0), zero, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xform(r1, 1), d, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) slab[(8 * (i >> 2) + 4 * kh + (i & 3)) * 36 + l31] = d[i] + bz[i];
+        for (int i = 0; i < 16; ++i) slab[(8 * (i >> 2) + 4 * kh + (i & 3)) * 36 + l31] = d[i] + s_bz[kh][i];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
