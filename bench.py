@@ -84,6 +84,9 @@ def main():
                     help="--shard tiles: ordered send/recv hand-over (bit-exact) or pairwise fp16 all-reduce of the slabs")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo lets several ranks share one GPU for validation)")
+    ap.add_argument("--with-bca", dest="with_bca", action="store_true", default=True,
+                    help="N=1: also time the BCA half of `total+bca` on the same volume (extra field total_plus_bca; default on)")
+    ap.add_argument("--no-bca", dest="with_bca", action="store_false")
     ap.add_argument("--dump", type=str, default=None, help="write per-kernel-class timings to this JSON file")
     args = ap.parse_args()
 
@@ -239,6 +242,37 @@ def main():
             res["cpu_baseline"] = cpu_baseline(models[0][3], args.cpu_tiles, tiles_per_volume, log)
         else:
             res["cpu_baseline"] = None
+        if args.with_bca and n_gpus == 1:
+            # BASELINE.json's metric names `total+bca`: the BCA half (body_parts + body_regions nets, 5 folds each at 5 mm
+            # slices, CC / contour-fill post-processing, tissues, per-slice tables, JSON) on the same volume, host to host
+            # (uploads the CT, downloads three label volumes), timed once after one warm-up; not part of `value`.
+            try:
+                from boa_hip import plans
+                from boa_hip.pipeline import BcaPipelineHip
+                bm = {}
+                for name, nc, seed in (("body_parts", 7, 543), ("body_regions", 12, 542)):
+                    pj, dj = plans.synthetic_plans(num_classes=nc, spacing=(5.0, 1.5, 1.5))
+                    cfg = plans.model_config_from_plans(pj, dj)
+                    bm[name] = (cfg, [plans.weight_blob_from_state_dict(cfg.geometry, plans.synthetic_state_dict(cfg.geometry, seed + f))
+                                      for f in range(5)])
+                pipe = BcaPipelineHip(ctx, bm["body_parts"], bm["body_regions"], fast_bca=False)
+                total_lab = d_lab.download(tuple(shape), np.uint8)
+                aff = np.diag([-1.5, -1.5, 1.5, 1.0])
+                pipe.run(ct, aff, total_seg=total_lab)
+                ctx.sync()
+                tb = time.perf_counter()
+                out = pipe.run(ct, aff, total_seg=total_lab)
+                ctx.sync()
+                t_bca = time.perf_counter() - tb
+                pipe.close()
+                t_total = elapsed / args.steps
+                res["total_plus_bca"] = {"bca_s": t_bca, "total_s": t_total, "value": 1.0 / (t_total + t_bca), "unit": "volumes/s",
+                                         "note": "bca = 2 nets x 5 folds at 5 mm slices + post-processing + tissues + tables, host to "
+                                                 "host, one run after one warm-up; synthetic weights",
+                                         "tissue_voxels": int((out["tissues"] > 0).sum())}
+                log(f"total+bca: total {t_total:.3f} s + bca {t_bca:.3f} s -> {1.0 / (t_total + t_bca):.3f} volumes/s")
+            except Exception as e:  # noqa: BLE001  (the extra must never cost the headline line)
+                res["total_plus_bca"] = {"error": f"{type(e).__name__}: {e}"}
         if args.dump:
             os.makedirs(os.path.dirname(os.path.abspath(args.dump)), exist_ok=True)
             with open(args.dump, "w") as f:
