@@ -337,13 +337,38 @@ def postprocess_part_segmentation(ctx: Context, seg: np.ndarray, threshold: int 
         d_seg.free()
 
 
+def _fill_holes_2d_cropped(ctx: Context, d_mask: DeviceBuffer, shape, d_i32: DeviceBuffer, d_s1: DeviceBuffer, d_s2: DeviceBuffer,
+                           d_out: DeviceBuffer):
+    """boa_fill_holes_2d restricted to the mask's bounding box (+ 1 pixel in-plane where the slice is larger): a background
+    pixel reaches the slice border through background iff it reaches the border of that box (everything outside the box is
+    background, and where the box has no margin its border IS the slice border), so the result is identical while the
+    union-find only sees the box -- body-part masks fill a fraction of the volume.  d_s1 / d_s2: uint8 scratch of the
+    volume's size, d_i32: int32 scratch; d_mask is left unchanged."""
+    from .devarray import DevArray
+    Z, Y, X = (int(v) for v in shape)
+    bb = (C.c_int * 6)()
+    check(ctx.lib.boa_nonzero_bbox(ctx.h, d_mask.vp, 0, (C.c_int * 3)(Z, Y, X), bb), "boa_nonzero_bbox")
+    box = [[bb[0], bb[1]], [max(bb[2] - 1, 0), min(bb[3] + 1, Y)], [max(bb[4] - 1, 0), min(bb[5] + 1, X)]]
+    cz, cy, cx = (b[1] - b[0] for b in box)
+    if cz * cy * cx > 0.7 * Z * Y * X:
+        check(ctx.lib.boa_fill_holes_2d(ctx.h, d_mask.vp, Z, Y, X, d_i32.vp, d_s1.vp, d_out.vp), "boa_fill_holes_2d")
+        return
+    full = DevArray(ctx, d_mask, (Z, Y, X), np.uint8)
+    cin = DevArray(ctx, d_s1, (cz, cy, cx), np.uint8)
+    full.box(box).copy_to(cin)
+    # (d_out doubles as the uint8 scratch of the cropped call; its box is rewritten below, the rest cleared)
+    check(ctx.lib.boa_fill_holes_2d(ctx.h, d_s1.vp, cz, cy, cx, d_i32.vp, d_out.vp, d_s2.vp), "boa_fill_holes_2d")
+    d_out.zero()
+    DevArray(ctx, d_s2, (cz, cy, cx), np.uint8).copy_to(DevArray(ctx, d_out, (Z, Y, X), np.uint8).box(box))
+
+
 def postprocess_part_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shape, threshold: int = 3000) -> DeviceBuffer:
     """Resident uint8 (z,y,x) labels -> new resident buffer with the cleaned labels."""
     shape = tuple(int(v) for v in shape)
     Z, Y, X = shape
     n = Z * Y * X
     d_out = ctx.zeros(n)
-    d_mask, d_fill, d_tmp = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    d_mask, d_fill, d_tmp, d_box = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
     d_roots, d_sizes = ctx.alloc(n * 4), ctx.alloc(n * 4)
     ncomp = C.c_int()
     try:
@@ -351,7 +376,7 @@ def postprocess_part_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shap
         for label in labels[labels > 0]:
             v = (C.c_int * 3)(int(label), 0, 0)
             check(ctx.lib.boa_label_select(ctx.h, d_seg.vp, n, 0, v, d_mask.vp))
-            check(ctx.lib.boa_fill_holes_2d(ctx.h, d_mask.vp, Z, Y, X, d_roots.vp, d_tmp.vp, d_fill.vp), "boa_fill_holes_2d")
+            _fill_holes_2d_cropped(ctx, d_mask, shape, d_roots, d_tmp, d_box, d_fill)
             # small foreground objects
             check(ctx.lib.boa_ccl26(ctx.h, d_fill.vp, Z, Y, X, d_roots.vp, d_sizes.vp, C.byref(ncomp)))
             check(ctx.lib.boa_ccl_remove_small(ctx.h, d_roots.vp, d_sizes.vp, n, threshold - 1, d_fill.vp))
@@ -366,5 +391,5 @@ def postprocess_part_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shap
         d_out.free()
         raise
     finally:
-        for b in (d_mask, d_fill, d_tmp, d_roots, d_sizes):
+        for b in (d_mask, d_fill, d_tmp, d_box, d_roots, d_sizes):
             b.free()

@@ -278,10 +278,11 @@ extern "C" int boa_nonzero_bbox(boa_ctx* c, const void* dev_in, int dtype, const
     c->prof_break = true;
     if (n) {
         switch (dtype) {
+            case 0: hipLaunchKernelGGL(k_nonzero_bbox<uint8_t>, dim3(grid), dim3(256), 0, c->stream, (const uint8_t*)dev_in, dims[0], dims[1], dims[2], d_bb); break;
             case 1: hipLaunchKernelGGL(k_nonzero_bbox<int16_t>, dim3(grid), dim3(256), 0, c->stream, (const int16_t*)dev_in, dims[0], dims[1], dims[2], d_bb); break;
             case 2: hipLaunchKernelGGL(k_nonzero_bbox<int32_t>, dim3(grid), dim3(256), 0, c->stream, (const int32_t*)dev_in, dims[0], dims[1], dims[2], d_bb); break;
             case 3: hipLaunchKernelGGL(k_nonzero_bbox<float>, dim3(grid), dim3(256), 0, c->stream, (const float*)dev_in, dims[0], dims[1], dims[2], d_bb); break;
-            default: hipFree(d_bb); boa_set_error("boa_nonzero_bbox: dtype %d (1 int16, 2 int32, 3 float32)", dtype); return BOA_EINVAL;
+            default: hipFree(d_bb); boa_set_error("boa_nonzero_bbox: dtype %d (0 uint8, 1 int16, 2 int32, 3 float32)", dtype); return BOA_EINVAL;
         }
     }
     int bb[6];

@@ -286,7 +286,7 @@ int boa_copy3(boa_ctx* ctx, const void* dev_in, int in_dtype, long long in_off, 
               const int dims[3], void* dev_out, int out_dtype, long long out_off, const long long out_step[3]);
 /* Bounding box of data != 0 (crop_to_nonzero, NN/preprocessing/cropping/cropping.py:6-29; binary_fill_holes cannot
  * change it): host_bbox = {lo0, hi0, lo1, hi1, lo2, hi2} with hi exclusive; [0, dim) when all zero.
- * dtype: 1 int16, 2 int32, 3 float32.  Synchronous. */
+ * dtype: 0 uint8, 1 int16, 2 int32, 3 float32.  Synchronous. */
 int boa_nonzero_bbox(boa_ctx* ctx, const void* dev_in, int dtype, const int dims[3], int host_bbox[6]);
 
 /* ------------------------------------------------------------------ resampling (TS/resampling.py) --- */
