@@ -72,6 +72,85 @@ __global__ __launch_bounds__(256) void k_bg_fill(const unsigned char* __restrict
     out[i] = v;
 }
 
+// Slice-wise fill as a bit-parallel flood in LDS: one workgroup per slice keeps the background and the "reached from the
+// border" sets as bitmasks (Y x ceil(X / 32) words each) and alternates (a) a horizontal run fill per row -- adding the
+// seed word to the background word makes the carry ripple through each run of ones that contains a seed, across word
+// boundaries and in both directions (bit-reversed words) -- with (b) a vertical step `reach |= (up | down) & background`,
+// until nothing changes.  Every iteration is a few thousand word operations; the global traffic is one read of the mask and
+// one write of the result.  (The union-find form below needs ~75 ms for a 512^3 mask, this one well under a millisecond.)
+__global__ __launch_bounds__(256) void k_fill_holes_bits(const unsigned char* __restrict__ mask, int Y, int X, int W,
+                                                         unsigned char* __restrict__ out) {
+    extern __shared__ unsigned int fsm[];
+    unsigned int* bg = fsm;                 // [Y][W]
+    unsigned int* rc = fsm + (size_t)Y * W; // [Y][W]
+    __shared__ int changed;
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * Y * X;
+    const int nw = Y * W;
+    for (int idx = tid; idx < nw; idx += 256) {
+        const int y = idx / W, w = idx - y * W;
+        const unsigned char* row = mask + base + (size_t)y * X + w * 32;
+        const int cnt = min(32, X - w * 32);
+        unsigned int b = 0;
+        for (int i = 0; i < cnt; ++i) b |= (row[i] == 0 ? 1u : 0u) << i;
+        unsigned int r = 0;
+        if (y == 0 || y == Y - 1) r = b;
+        if (w == 0) r |= b & 1u;
+        if (w == W - 1) r |= b & (1u << ((X - 1) & 31));
+        bg[idx] = b;
+        rc[idx] = r;
+    }
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        int ch = 0;
+        for (int y = tid; y < Y; y += 256) {
+            unsigned int* rr = rc + y * W;
+            const unsigned int* bb = bg + y * W;
+            unsigned int carry = 0;
+            for (int w = 0; w < W; ++w) {          // towards higher x
+                const unsigned int b = bb[w];
+                unsigned int sd = rr[w] | (carry ? (b & 1u) : 0u);
+                const unsigned long long sum = (unsigned long long)b + sd;
+                const unsigned int nr = sd | ((b ^ (unsigned int)sum) & b);
+                carry = (unsigned int)(sum >> 32);
+                if (nr != rr[w]) { rr[w] = nr; ch = 1; }
+            }
+            carry = 0;
+            for (int w = W - 1; w >= 0; --w) {     // towards lower x: the same on bit-reversed words
+                const unsigned int b = __brev(bb[w]);
+                unsigned int sd = __brev(rr[w]) | (carry ? (b & 1u) : 0u);
+                const unsigned long long sum = (unsigned long long)b + sd;
+                const unsigned int nr = __brev(sd | ((b ^ (unsigned int)sum) & b));
+                carry = (unsigned int)(sum >> 32);
+                if (nr != rr[w]) { rr[w] = nr; ch = 1; }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nw; idx += 256) {   // vertical step (each word has one writer; neighbours are only read)
+            const int y = idx / W;
+            const unsigned int r = rc[idx];
+            const unsigned int up = y > 0 ? rc[idx - W] : 0u, dn = y < Y - 1 ? rc[idx + W] : 0u;
+            const unsigned int nr = r | ((up | dn) & bg[idx]);
+            if (nr != r) { rc[idx] = nr; ch = 1; }
+        }
+        if (ch) changed = 1;
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    for (int idx = tid; idx < nw; idx += 256) {
+        const int y = idx / W, w = idx - y * W;
+        const unsigned int hole = bg[idx] & ~rc[idx];
+        const unsigned int fg = ~bg[idx];
+        unsigned char* orow = out + base + (size_t)y * X + w * 32;
+        const int cnt = min(32, X - w * 32);
+        const unsigned int v = hole | fg;
+        for (int i = 0; i < cnt; ++i) orow[i] = (unsigned char)((v >> i) & 1u);
+    }
+}
+
 extern "C" int boa_fill_holes_2d(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int X, int32_t* dev_scratch_i32,
                                  uint8_t* dev_scratch_u8, uint8_t* dev_out) {
     BOA_REQUIRE(c && dev_mask && dev_scratch_i32 && dev_scratch_u8 && dev_out && Z > 0 && Y > 0 && X > 0,
@@ -79,6 +158,18 @@ extern "C" int boa_fill_holes_2d(boa_ctx* c, const uint8_t* dev_mask, int Z, int
     BOA_REQUIRE(dev_out != dev_scratch_u8 && dev_out != dev_mask, "boa_fill_holes_2d: out must not alias mask/scratch");
     const size_t n = (size_t)Z * Y * X;
     BOA_REQUIRE(n < (1ull << 31), "boa_fill_holes_2d: volume too large for int32 indices");
+    const int W = (X + 31) / 32;
+    const size_t lds = (size_t)Y * W * 8;
+    static const bool bits_off = getenv("BOA_FILL_BITS") && atoi(getenv("BOA_FILL_BITS")) == 0;
+    if (!bits_off && lds <= 150 * 1024) {
+        static bool once = (hipFuncSetAttribute((const void*)k_fill_holes_bits, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256), true);
+        (void)once;
+        KernelTimer tb(c, BOA_K_OTHER, 0, (double)n * 2.0);
+        hipLaunchKernelGGL(k_fill_holes_bits, dim3(Z), dim3(256), lds, c->stream, dev_mask, Y, X, W, dev_out);
+        tb.stop();
+        BOA_HIP_TRY(hipGetLastError());
+        return BOA_OK;
+    }
     const unsigned grid = (unsigned)((n + 255) / 256);
     KernelTimer t(c, BOA_K_OTHER, 0, (double)n * 12.0);
     hipLaunchKernelGGL(k_bg_init, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, dev_scratch_i32, dev_scratch_u8);
