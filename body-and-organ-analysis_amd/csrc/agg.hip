@@ -387,10 +387,14 @@ extern "C" int boa_binary_erode(boa_ctx* c, const uint8_t* dev_mask, uint8_t* de
 #define AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 __device__ __forceinline__ int uf_find(int* L, int i) {
+    // path halving: every node on the way is re-pointed to its grandparent (a plain store: parents only ever move towards
+    // the root, so a racing walker at worst takes the longer way)
     int p = AGENT_LOAD(&L[i]);
     while (p != i) {
+        const int gp = AGENT_LOAD(&L[p]);
+        if (gp != p) L[i] = gp;
         i = p;
-        p = AGENT_LOAD(&L[i]);
+        p = gp;
     }
     return i;
 }
@@ -423,49 +427,103 @@ __global__ __launch_bounds__(256) void k_ccl_merge(const unsigned char* __restri
     const int x = (int)(i % X);
     const int y = (int)((i / X) % Y);
     const int z = (int)(i / ((size_t)X * Y));
-    // the 13 neighbours with larger linear index
+    // The 13 neighbours with larger linear index: (x+1) in this row and the x-1, x, x+1 triples of the four "later" rows
+    // (dz,dy) = (0,1), (1,-1), (1,0), (1,1).  When the left neighbour (x-1) of this row is foreground it is in our component
+    // and has already linked itself to the x-2, x-1, x voxels of those rows, so only their x+1 voxel is new information;
+    // likewise within a triple one link is enough when consecutive voxels of the later row are foreground (they are linked to
+    // each other by that row's own x+1 link).  This cuts the unions from up to 13 to ~5 per voxel without changing the
+    // components.
+    const bool left = x > 0 && mask[i - 1];
+    if (x + 1 < X && mask[i + 1]) uf_union(L, (int)i, (int)(i + 1));
 #pragma unroll
-    for (int dz = 0; dz <= 1; ++dz)
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                if (dz == 0 && (dy < 0 || (dy == 0 && dx <= 0))) continue;
-                const int zz = z + dz, yy = y + dy, xx = x + dx;
-                if (zz >= Z || yy < 0 || yy >= Y || xx < 0 || xx >= X) continue;
-                const size_t j = ((size_t)zz * Y + yy) * X + xx;
-                if (mask[j]) uf_union(L, (int)i, (int)j);
+    for (int r = 0; r < 4; ++r) {
+        const int dz = r == 0 ? 0 : 1, dy = r == 0 ? 1 : r - 2;
+        const int zz = z + dz, yy = y + dy;
+        if (zz >= Z || yy < 0 || yy >= Y) continue;
+        const size_t row = ((size_t)zz * Y + yy) * X;
+        const bool m0 = x > 0 && mask[row + x - 1], m1 = mask[row + x] != 0, m2 = x + 1 < X && mask[row + x + 1];
+        if (!left) {
+            if (m1) {
+                uf_union(L, (int)i, (int)(row + x));            // x-1 and x+1 of that row hang on its x voxel
+            } else {
+                if (m0) uf_union(L, (int)i, (int)(row + x - 1));
+                if (m2) uf_union(L, (int)i, (int)(row + x + 1));
             }
+        } else if (m2 && !m1) {
+            uf_union(L, (int)i, (int)(row + x + 1));            // (with m1 set, x+1 is linked to x, which the left voxel linked)
+        }
+    }
 }
 
+#define CCL_VPT 8
 __global__ __launch_bounds__(256) void k_ccl_compress(size_t n, int* L, unsigned int* sizes, int* n_comp) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    int root = -1;
-    if (i < n && L[i] >= 0) {
-        root = (int)i;
-        int p = L[root];
-        while (p != root) {
-            root = p;
-            p = L[root];
+    // Each thread resolves CCL_VPT voxels (256 apart, so the loads stay coalesced) and run-length merges their roots; the wave
+    // then adds each distinct root's count with ONE atomic.  With one voxel per thread a single giant component (the inverted
+    // body mask: 90 % of 134 M voxels) meant 2 M atomics on the same address, which alone took ~20 ms.
+    const size_t base = (size_t)blockIdx.x * 256 * CCL_VPT + threadIdx.x;
+    int roots[CCL_VPT];
+    unsigned int cnts[CCL_VPT];
+    int np = 0, ncomp = 0;
+#pragma unroll
+    for (int k = 0; k < CCL_VPT; ++k) {
+        roots[k] = -1;
+        cnts[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < CCL_VPT; ++k) {
+        const size_t i = base + (size_t)k * 256;
+        if (i < n && L[i] >= 0) {
+            int root = (int)i;
+            int p = L[root];
+            while (p != root) {
+                root = p;
+                p = L[root];
+            }
+            L[i] = root;  // values only ever move towards the root: a concurrent walker through i just gets there sooner
+            if (root == (int)i) ++ncomp;
+            bool merged = false;
+#pragma unroll
+            for (int q = 0; q < CCL_VPT; ++q)
+                if (!merged && q < np && roots[q] == root) {
+                    ++cnts[q];
+                    merged = true;
+                }
+            if (!merged) {
+#pragma unroll
+                for (int q = 0; q < CCL_VPT; ++q)
+                    if (q == np) {
+                        roots[q] = root;
+                        cnts[q] = 1;
+                    }
+                ++np;
+            }
         }
     }
-    // wave-aggregated size counting: one atomic per distinct root per wave
-    unsigned long long active = __ballot(root >= 0);
     const int lane = threadIdx.x & 63;
-    bool mine = root >= 0;
-    while (active) {
-        const int leader = __ffsll((long long)active) - 1;
-        const int r = __shfl(root, leader);
-        const unsigned long long same = __ballot(mine && root == r);
-        if (lane == leader) {
-            atomicAdd(&sizes[r], (unsigned int)__popcll(same));
+#pragma unroll
+    for (int q = 0; q < CCL_VPT; ++q) {
+        bool mine = q < np;
+        const int root = roots[q];
+        const unsigned int cnt = cnts[q];
+        unsigned long long active = __ballot(mine);
+        while (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const int r = __shfl(root, leader);
+            const bool match = mine && root == r;
+            const unsigned long long same = __ballot(match);
+            unsigned int v = match ? cnt : 0u;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+            if (lane == leader) atomicAdd(&sizes[r], v);
+            if (match) mine = false;
+            active &= ~same;
         }
-        if (mine && root == r) mine = false;
-        active &= ~same;
     }
-    if (i < n && root >= 0 && root == (int)i) atomicAdd(n_comp, 1);
-    __syncthreads();
-    if (i < n) L[i] = root;  // safe: every thread of the grid only reads parents towards smaller indices ... see note
+    // number of components: wave sum, one atomic per wave
+    unsigned int nc = (unsigned int)ncomp;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) nc += __shfl_xor(nc, m);
+    if (lane == 0 && nc) atomicAdd(n_comp, (int)nc);
 }
 
 // note on k_ccl_compress: path compression writes L[i] = root while other threads may still walk through i.
@@ -484,7 +542,8 @@ extern "C" int boa_ccl26(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int 
     KernelTimer t(c, BOA_K_OTHER, 0, (double)n * 14.0);
     hipLaunchKernelGGL(k_ccl_init, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, dev_roots);
     hipLaunchKernelGGL(k_ccl_merge, dim3(grid), dim3(256), 0, c->stream, dev_mask, Z, Y, X, dev_roots);
-    hipLaunchKernelGGL(k_ccl_compress, dim3(grid), dim3(256), 0, c->stream, n, dev_roots, dev_sizes, d_count);
+    hipLaunchKernelGGL(k_ccl_compress, dim3((unsigned)((n + 256 * CCL_VPT - 1) / (256 * CCL_VPT))), dim3(256), 0, c->stream, n, dev_roots,
+                       dev_sizes, d_count);
     t.stop();
     int cnt = 0;
     hipError_t e = hipMemcpyAsync(&cnt, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
