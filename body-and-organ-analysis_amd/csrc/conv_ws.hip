@@ -626,8 +626,8 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     // InstanceNorm partial sums of this wave in the D-fragment layout: entry gq * 4 + e <-> cout 8 gq + 4 kh + e, summed
     // over the voxels (lane l31 of every M-tile) this lane produced since the last flush, from the fp32 accumulators;
     // one flush per (n, cout chunk) the wave works on.
-    // The conv bias is NOT added: every conv this kernel runs is followed by InstanceNorm, which removes any per-channel
-    // constant exactly ((x + b) - mean(x + b) = x - mean(x)); storing x keeps one fp16 rounding of a smaller magnitude.
+    // (The statistics are those of acc + bias, the value that is stored: the bias add is kept although the InstanceNorm that
+    // follows every conv of the stack cancels it -- dropping it was measured slower)
     // Two sets: with the cout-chunk-fastest tile order (p.cy_fast, 2 cout chunks, R == 1 kernels only) consecutive tiles
     // alternate between cout chunk 0 (set A) and 1 (set B); otherwise only set A is used.
     constexpr bool TWO_SETS = (R == 1);
