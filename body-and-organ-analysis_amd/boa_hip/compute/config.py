@@ -1,56 +1,78 @@
-"""Model / device resolution with the reference's semantics (BOA/compute/config.py:13-69, pinned by the
-reference's tests/test_config.py and by tests/golden/g10_config.json)."""
+"""Which models to run and on which device: the flag / environment conventions of the reference's `compute/config.py`
+(behaviour pinned by the reference's tests/test_config.py, restated here as tables in tests/golden/g10_config.json).
+Only the conventions are shared -- the implementation is table driven."""
 from __future__ import annotations
 
 import logging
 import os
+import re
 from typing import Callable, Optional, Set
 
-from .constants import ALL_MODELS, AVAILABLE_MODELS, LICENSE_MODELS
+from . import constants as K
 
 logger = logging.getLogger(__name__)
 
+_TRUE_WORDS = frozenset(("1", "true"))
+_UNSET_WORDS = frozenset(("", "todo"))                  # placeholder values of the shipped .env template count as "not set"
+_DEVICE_RE = re.compile(r"^(?P<kind>[^:]*)(?::(?P<index>.*))?$")
+_GPU_ALIASES = frozenset(("cuda", "hip"))               # "hip" is this engine's own alias
+
+
+def _env(name: str) -> Optional[str]:
+    value = os.getenv(name)
+    return None if value is None else value.strip()
+
 
 def env_bool(name: str, default: bool = False) -> bool:
-    raw = os.getenv(name)
-    return default if raw is None else raw.strip().lower() in {"1", "true"}
+    value = _env(name)
+    if value is None:
+        return default
+    return value.lower() in _TRUE_WORDS
 
 
 def env_str(name: str, default: Optional[str] = None) -> Optional[str]:
-    raw = os.getenv(name)
-    if raw is None or raw.strip().lower() in {"", "todo"}:
+    value = _env(name)
+    if value is None or value.lower() in _UNSET_WORDS:
         return default
-    return raw.strip()
+    return value
+
+
+def _all_models(license_number, is_valid_license) -> Set[str]:
+    licensed = bool(license_number) and is_valid_license is not None and bool(is_valid_license(license_number))
+    return set(K.ALL_MODELS) | (set(K.LICENSE_MODELS) if licensed else set())
 
 
 def resolve_models(spec: Optional[str], strict: bool = False, license_number: Optional[str] = None,
                    is_valid_license: Optional[Callable[[str], bool]] = None) -> Set[str]:
-    """`is_valid_license` stands in for totalsegmentator.config.is_valid_license (not part of the hot path)."""
-    if not spec or spec.lower() == "all":
-        models = set(ALL_MODELS)
-        if license_number and is_valid_license is not None and is_valid_license(license_number):
-            models |= LICENSE_MODELS
+    """'a+b+c' (dashes and underscores interchangeable), 'all' or nothing -> set of model names.  Unknown names raise
+    when `strict`, else they are logged and dropped.  `bca` implies `total` and subsumes its two networks.
+    (`is_valid_license` stands in for TotalSegmentator's licence check, which is not part of the hot path.)"""
+    wanted = (spec or "all")
+    if wanted.lower() == "all":
+        chosen = _all_models(license_number, is_valid_license)
     else:
-        models = {s.replace("-", "_") for s in spec.split("+")}
-        invalid = models - AVAILABLE_MODELS
-        if invalid:
-            if strict:
-                raise ValueError(f"Unknown model(s): {', '.join(sorted(invalid))}. "
-                                 f"Available: {', '.join(sorted(AVAILABLE_MODELS))}")
-            logger.error("Ignoring invalid model entries: %s. Available models are: %s.", invalid, sorted(AVAILABLE_MODELS))
-            models -= invalid
-    if "bca" in models:
-        models = (models | {"total"}) - {"body_regions", "body_parts"}
-    return models
+        tokens = [tok.replace("-", "_") for tok in wanted.split("+")]
+        unknown = sorted(set(tokens) - set(K.AVAILABLE_MODELS))
+        if unknown and strict:
+            raise ValueError(f"Unknown model(s): {', '.join(unknown)}. Available: {', '.join(sorted(K.AVAILABLE_MODELS))}")
+        if unknown:
+            logger.error("Ignoring invalid model entries: %s. Available models are: %s.", set(unknown), sorted(K.AVAILABLE_MODELS))
+        chosen = {tok for tok in tokens if tok in K.AVAILABLE_MODELS}
+    if "bca" in chosen:
+        chosen.add("total")
+        chosen.difference_update(("body_regions", "body_parts"))
+    return chosen
 
 
 def resolve_device(device: Optional[str] = None) -> str:
-    device_str = device or os.environ.get("DEVICE", "gpu")
-    device_str, _, gpu_id = device_str.partition(":")
-    if device_str in ("cuda", "hip"):  # "hip" is this engine's alias; the reference accepts "cuda"
-        device_str = "gpu"
-    gpu_id = gpu_id or os.environ.get("NVIDIA_ID", "")
-    if gpu_id and device_str == "gpu":
-        os.environ.setdefault("NVIDIA_VISIBLE_DEVICES", gpu_id)
-        device_str = f"gpu:{gpu_id}"
-    return device_str
+    """'gpu' | 'gpu:<id>' | 'cpu' ... from the argument or $DEVICE; 'cuda' / 'hip' mean 'gpu'; the index may also come from
+    $NVIDIA_ID and is exported as $NVIDIA_VISIBLE_DEVICES (kept for compatibility with the reference's deployments)."""
+    m = _DEVICE_RE.match(device or os.environ.get("DEVICE", "gpu"))
+    kind = m.group("kind")
+    index = m.group("index") or os.environ.get("NVIDIA_ID", "")
+    if kind in _GPU_ALIASES:
+        kind = "gpu"
+    if kind == "gpu" and index:
+        os.environ.setdefault("NVIDIA_VISIBLE_DEVICES", index)
+        return f"gpu:{index}"
+    return kind

@@ -100,68 +100,74 @@ def compute_all_models(
     ctx = get_context(totalsegmentator_params.get("device"))
     data, affine, hdr = nifti.load(ct_path)
     ct = _ct_array(data, hdr)
-
-    for chosen_task in measurement_models:
-        logger.info("Computing model %s...", chosen_task)
-        seg_file = segmentation_folder / f"{chosen_task}.nii.gz"
-        if not recompute and seg_file.is_file():
-            logger.info("The model was already computed, skipping...")
-            continue
-        fast = bool(totalsegmentator_params.get("fast", False))
-        if chosen_task == "total":
-            key = "total_fast" if fast else "total"
-            info = model_store.TASKS[key]
-            task = SegmentationTask(ctx, "total", model_store.load_task_models(key), resample=info["resample"],
-                                    multimodel=not fast)
-            try:
-                seg = task.predict_image(ct, affine)
-            finally:
-                task.close()
-            names = label_maps.CLASS_MAP_TOTAL
-        else:
-            if fast:
-                raise ValueError(f"task {chosen_task} does not work with option --fast")   # TS/python_api.py:242 ff.
-            info = model_store.TASKS[chosen_task]
-            seg = run_cascade_task(ctx, chosen_task, ct, affine, model_store.load_task_models("total_6mm"),
-                                   model_store.load_task_models(chosen_task), info["crop"], info["crop_addon"])
-            names = label_maps.class_map(chosen_task)
-        nifti.save(seg_file, seg, affine, like=hdr, extensions=[(0, nifti.label_xml(names))])
-
-    measurement_file = segmentation_folder / "total-measurements.json"
-    if measurement_models and (recompute or not measurement_file.is_file()):
-        json_data = compute_measurements(ct_path=ct_path, segmentation_folder=segmentation_folder,
-                                         models=measurement_models, cnr_adjustment=cnr_adjustment, ctx=ctx)
-        with measurement_file.open("w") as ofile:
-            json.dump(json_data, ofile, indent=2)
-    else:
-        logger.info("The total measurements were already computed, skipping...")
-
-    for boa_task in sorted(BASE_MODELS & set(models_to_compute)):
-        resampling_bca = convert_resampling_slices(slices=shape[-1], current_sampling=spacing[-1], target_resampling=5.0)
-        force_split = resampling_bca > force_split_threshold
-        if force_split:
-            logger.info("Splitting the image into parts as the number of slices %s is more than %s", resampling_bca,
-                        force_split_threshold)
-        pm = model_store.load_task_models("body_parts", fast_bca)[0]
-        rm = model_store.load_task_models("body_regions", fast_bca)[0]
-        pipe = BcaPipelineHip(ctx, (pm[1], pm[2]), (rm[1], rm[2]), fast_bca=fast_bca)
-        try:
-            if boa_task == "bca":
-                total_file = segmentation_folder / "total.nii.gz"
-                total = nifti.load(total_file)[0] if total_file.is_file() else None
-                out = pipe.run(ct, affine, total_seg=total, force_split=force_split,
-                               median_filtering=bool(bca_params.get("median_filtering", False)),
-                               examined_body_region=bca_params.get("examined_body_region"))
-                for name in ("body_parts", "body_regions", "tissues"):
-                    nifti.save(segmentation_folder / f"{name}.nii.gz", out[name], affine, like=hdr)
-                if out["vertebrae"]:
-                    with (segmentation_folder / "vertebrae.json").open("w") as ofile:
-                        json.dump(out["vertebrae"], ofile, indent=2)
-                with (segmentation_folder / "bca-measurements.json").open("w") as ofile:
-                    json.dump(out["bca_measurements"], ofile, indent=2, default=float)
-            else:
-                seg = pipe.inference(boa_task, ct, affine, force_split=force_split)
-                nifti.save(segmentation_folder / f"{boa_task}.nii.gz", seg, affine, like=hdr)
-        finally:
-            pipe.close()
+    fast = bool(totalsegmentator_params.get("fast", False))
+    for name in measurement_models:
+        _segment_one(ctx, name, ct, affine, hdr, segmentation_folder, fast, recompute)
+    _write_total_measurements(ctx, ct_path, segmentation_folder, measurement_models, cnr_adjustment, recompute)
+    bca_slices = convert_resampling_slices(slices=shape[-1], current_sampling=spacing[-1], target_resampling=5.0)
+    for name in sorted(BASE_MODELS & set(models_to_compute)):
+        _run_bca_model(ctx, name, ct, affine, hdr, segmentation_folder, fast_bca, bca_params,
+                       split=bca_slices > force_split_threshold, slices=bca_slices, threshold=force_split_threshold)
     return stats
+
+
+def _segment_one(ctx, name, ct, affine, hdr, folder, fast, recompute):
+    """One TotalSegmentator-style model -> `<name>.nii.gz` with the label table in the header extension."""
+    target = folder / f"{name}.nii.gz"
+    logger.info("Computing model %s...", name)
+    if target.is_file() and not recompute:
+        logger.info("The model was already computed, skipping...")
+        return
+    if name == "total":
+        key = "total_fast" if fast else "total"
+        task = SegmentationTask(ctx, "total", model_store.load_task_models(key), resample=model_store.TASKS[key]["resample"],
+                                multimodel=not fast)
+        try:
+            seg = task.predict_image(ct, affine)
+        finally:
+            task.close()
+        names = label_maps.CLASS_MAP_TOTAL
+    else:
+        if fast:
+            raise ValueError(f"task {name} does not work with option --fast")   # TS/python_api.py:242 ff.
+        info = model_store.TASKS[name]
+        seg = run_cascade_task(ctx, name, ct, affine, model_store.load_task_models("total_6mm"),
+                               model_store.load_task_models(name), info["crop"], info["crop_addon"])
+        names = label_maps.class_map(name)
+    nifti.save(target, seg, affine, like=hdr, extensions=[(0, nifti.label_xml(names))])
+
+
+def _write_total_measurements(ctx, ct_path, folder, models, cnr_adjustment, recompute):
+    target = folder / "total-measurements.json"
+    if not models or (target.is_file() and not recompute):
+        logger.info("The total measurements were already computed, skipping...")
+        return
+    table = compute_measurements(ct_path=ct_path, segmentation_folder=folder, models=models, cnr_adjustment=cnr_adjustment, ctx=ctx)
+    with target.open("w") as fh:
+        json.dump(table, fh, indent=2)
+
+
+def _run_bca_model(ctx, name, ct, affine, hdr, folder, fast_bca, bca_params, split, slices, threshold):
+    """`bca` (both nets + tissues + tables) or one of its two networks on its own."""
+    if split:
+        logger.info("Splitting the image into parts as the number of slices %s is more than %s", slices, threshold)
+    parts_model = model_store.load_task_models("body_parts", fast_bca)[0]
+    regions_model = model_store.load_task_models("body_regions", fast_bca)[0]
+    pipe = BcaPipelineHip(ctx, parts_model[1:3], regions_model[1:3], fast_bca=fast_bca)
+    try:
+        if name != "bca":
+            nifti.save(folder / f"{name}.nii.gz", pipe.inference(name, ct, affine, force_split=split), affine, like=hdr)
+            return
+        total_file = folder / "total.nii.gz"
+        out = pipe.run(ct, affine, total_seg=nifti.load(total_file)[0] if total_file.is_file() else None, force_split=split,
+                       median_filtering=bool(bca_params.get("median_filtering", False)),
+                       examined_body_region=bca_params.get("examined_body_region"))
+        for volume in ("body_parts", "body_regions", "tissues"):
+            nifti.save(folder / f"{volume}.nii.gz", out[volume], affine, like=hdr)
+        if out["vertebrae"]:
+            with (folder / "vertebrae.json").open("w") as fh:
+                json.dump(out["vertebrae"], fh, indent=2)
+        with (folder / "bca-measurements.json").open("w") as fh:
+            json.dump(out["bca_measurements"], fh, indent=2, default=float)
+    finally:
+        pipe.close()
