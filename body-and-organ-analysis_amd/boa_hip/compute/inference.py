@@ -107,7 +107,8 @@ def compute_all_models(
     bca_slices = convert_resampling_slices(slices=shape[-1], current_sampling=spacing[-1], target_resampling=5.0)
     for name in sorted(BASE_MODELS & set(models_to_compute)):
         _run_bca_model(ctx, name, ct, affine, hdr, segmentation_folder, fast_bca, bca_params,
-                       split=bca_slices > force_split_threshold, slices=bca_slices, threshold=force_split_threshold)
+                       split=bca_slices > force_split_threshold, slices=bca_slices, threshold=force_split_threshold,
+                       recompute=recompute)
     return stats
 
 
@@ -132,7 +133,7 @@ def _segment_one(ctx, name, ct, affine, hdr, folder, fast, recompute):
             raise ValueError(f"task {name} does not work with option --fast")   # TS/python_api.py:242 ff.
         info = model_store.TASKS[name]
         seg = run_cascade_task(ctx, name, ct, affine, model_store.load_task_models("total_6mm"),
-                               model_store.load_task_models(name), info["crop"], info["crop_addon"])
+                               model_store.load_task_models(name), info["crop"], model_store.effective_crop_addon(name))
         names = label_maps.class_map(name)
     nifti.save(target, seg, affine, like=hdr, extensions=[(0, nifti.label_xml(names))])
 
@@ -147,13 +148,23 @@ def _write_total_measurements(ctx, ct_path, folder, models, cnr_adjustment, reco
         json.dump(table, fh, indent=2)
 
 
-def _run_bca_model(ctx, name, ct, affine, hdr, folder, fast_bca, bca_params, split, slices, threshold):
-    """`bca` (both nets + tissues + tables) or one of its two networks on its own."""
+def _run_bca_model(ctx, name, ct, affine, hdr, folder, fast_bca, bca_params, split, slices, threshold, recompute=True):
+    """`bca` (both nets + tissues + tables) or one of its two networks on its own.  As BCA/infer/infer.py:58-61 an
+    existing `<task>.nii.gz` is reloaded instead of recomputed when `recompute` is False (it already went through the
+    task's post-processing when it was written), and only the network(s) that are needed get loaded."""
     if split:
         logger.info("Splitting the image into parts as the number of slices %s is more than %s", slices, threshold)
-    parts_model = model_store.load_task_models("body_parts", fast_bca)[0]
-    regions_model = model_store.load_task_models("body_regions", fast_bca)[0]
-    pipe = BcaPipelineHip(ctx, parts_model[1:3], regions_model[1:3], fast_bca=fast_bca)
+    wanted = ("body_parts", "body_regions") if name == "bca" else (name,)
+    done = {}
+    for task in wanted:
+        f = folder / f"{task}.nii.gz"
+        if not recompute and f.is_file():
+            logger.info("Loading already computed %s...", task)
+            done[task] = np.ascontiguousarray(nifti.load(f)[0], dtype=np.uint8)
+    if name != "bca" and name in done:
+        return
+    models = {t: (model_store.load_task_models(t, fast_bca)[0][1:3] if t not in done else None) for t in wanted}
+    pipe = BcaPipelineHip(ctx, models.get("body_parts"), models.get("body_regions"), fast_bca=fast_bca)
     try:
         if name != "bca":
             nifti.save(folder / f"{name}.nii.gz", pipe.inference(name, ct, affine, force_split=split), affine, like=hdr)
@@ -161,8 +172,11 @@ def _run_bca_model(ctx, name, ct, affine, hdr, folder, fast_bca, bca_params, spl
         total_file = folder / "total.nii.gz"
         out = pipe.run(ct, affine, total_seg=nifti.load(total_file)[0] if total_file.is_file() else None, force_split=split,
                        median_filtering=bool(bca_params.get("median_filtering", False)),
-                       examined_body_region=bca_params.get("examined_body_region"))
+                       examined_body_region=bca_params.get("examined_body_region"),
+                       done_parts=done.get("body_parts"), done_regions=done.get("body_regions"))
         for volume in ("body_parts", "body_regions", "tissues"):
+            if volume in done:
+                continue
             nifti.save(folder / f"{volume}.nii.gz", out[volume], affine, like=hdr)
         if out["vertebrae"]:
             with (folder / "vertebrae.json").open("w") as fh:

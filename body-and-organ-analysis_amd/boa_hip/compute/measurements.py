@@ -29,7 +29,9 @@ def compute_measurements(ct_path: pathlib.Path, segmentation_folder: pathlib.Pat
     segmentation_folder = pathlib.Path(segmentation_folder)
     data, _, hdr = nifti.load(ct_path)
     # SimpleITK view (z,y,x) of the file, int16 HU, made on the device (a 512^3 host transpose costs ~0.5 s)
-    d_file = DevArray.from_numpy(ctx, data if (data.dtype == np.int16 and not nifti.is_scaled(hdr)) else nifti.fdata(data, hdr))
+    from .util import require_int16_exact
+    d_file = DevArray.from_numpy(ctx, data if (data.dtype == np.int16 and not nifti.is_scaled(hdr))
+                                 else require_int16_exact(nifti.fdata(data, hdr), str(ct_path)))
     d_ct = d_file.transpose((2, 1, 0)).contiguous(np.int16, force_copy=True)
     d_file.free()
     spacing = tuple(float(v) for v in hdr.get_zooms())

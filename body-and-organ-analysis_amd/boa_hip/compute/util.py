@@ -17,10 +17,23 @@ def convert_resampling_slices(slices: int, current_sampling: float, target_resam
 
 
 def create_mask(region_data: np.ndarray, labels: Union[int, Iterable[int]]) -> np.ndarray:
-    """Boolean mask of the voxels whose label is `labels` (one label) or in `labels` (several)."""
+    """Boolean mask of the voxels whose label is `labels` (one label) or in `labels` (several), as the reference's
+    `np.isin` version (BOA/compute/util.py:25-33)."""
     data = np.asarray(region_data)
     if isinstance(labels, (int, np.integer)):
         return data == labels
-    wanted = np.zeros(int(max(int(data.max(initial=0)), max(labels, default=0))) + 1, dtype=bool)
-    wanted[[int(v) for v in labels if int(v) >= 0]] = True
-    return wanted[data] if np.issubdtype(data.dtype, np.integer) and data.min(initial=0) >= 0 else np.isin(data, list(labels))
+    return np.isin(data, list(labels))
+
+
+def require_int16_exact(values: np.ndarray, what: str = "CT") -> np.ndarray:
+    """The device HU statistics (histogram over the int16 range) need integer HU that fit int16.  The reference computes
+    its statistics on whatever SimpleITK / get_fdata hand over; a float-valued, scl_slope-scaled or out-of-range CT must
+    not be truncated or wrapped silently, so it is refused here."""
+    values = np.asarray(values)
+    if values.dtype == np.int16:
+        return values
+    as16 = values.astype(np.int16)
+    if not np.array_equal(values, as16):
+        raise ValueError(f"{what}: voxel values are not exactly representable as int16 HU (float-valued, scaled or out of "
+                         "range); the device HU statistics only support integer HU in [-32768, 32767]")
+    return as16

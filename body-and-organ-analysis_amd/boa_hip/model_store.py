@@ -40,6 +40,17 @@ TASKS: Dict[str, dict] = {
 CASCADE_MODELS = ("lung_vessels", "cerebral_bleed", "hip_implant", "pleural_pericard_effusion", "liver_vessels")
 
 
+def effective_crop_addon(task: str) -> List[int]:
+    """Crop margin (mm) the reference actually applies.  TASKS[task]["crop_addon"] is the value of the task table
+    (TS/python_api.py:236-259,311-329), but whenever the crop mask comes from the default rough `total` model
+    (`crop_model is None`, true for every task here: none of them names a `crop_model`) TS/python_api.py:726 overrides it:
+        crop_addon = [20,20,20] if crop_model is None else crop_addon"""
+    info = TASKS[task]
+    if "crop" not in info:
+        raise KeyError(f"{task} is not a crop-cascade task")
+    return [20, 20, 20] if info.get("crop_model") is None else list(info["crop_addon"])
+
+
 def results_dir() -> str:
     for var in ("nnUNet_results", "TOTALSEG_WEIGHTS_PATH"):
         if os.environ.get(var):

@@ -83,7 +83,10 @@ class BcaPipelineHip:
                  regions_model: Tuple[ModelConfig, Sequence[np.ndarray]], fast_bca: bool = False, max_batch: int = 8):
         self.ctx = ctx
         self.tasks: Dict[str, SegmentationTask] = {}
-        for name, (cfg, blobs) in (("body_parts", parts_model), ("body_regions", regions_model)):
+        for name, model in (("body_parts", parts_model), ("body_regions", regions_model)):
+            if model is None:      # this task's output is reloaded from an earlier run (recompute=False): no network needed
+                continue
+            cfg, blobs = model
             info = get_task_info(name, fast_bca)
             blobs = list(blobs)[:len(info["folds"])]
             if len(blobs) != len(info["folds"]):
@@ -95,9 +98,12 @@ class BcaPipelineHip:
         for t in self.tasks.values():
             t.close()
 
-    def _inference_device(self, task_name: str, d_ct: DevArray, affine: np.ndarray, force_split: bool, crop, raw) -> DevArray:
+    def _inference_device(self, task_name: str, d_ct: DevArray, affine: np.ndarray, force_split: bool, crop, raw,
+                          done=None) -> DevArray:
         """BCA/infer/infer.py:39-89 on resident data: network labels on the input grid (file axis order), then the task's
         post-processing applied to the SimpleITK view (z,y,x) of the file; returns the cleaned labels in file order."""
+        if done is not None:   # `inference(recompute=False)` found <task>.nii.gz: already post-processed (infer.py:58-61)
+            return DevArray.from_numpy(self.ctx, np.ascontiguousarray(done, dtype=np.uint8))
         if raw is None:
             with _Stage(self.ctx, f"{task_name}: networks"):
                 d_raw = self.tasks[task_name].predict_image(d_ct, affine, force_split=force_split, crop_mask=crop, return_device=True)
@@ -140,20 +146,24 @@ class BcaPipelineHip:
 
     def run(self, ct: np.ndarray, affine: np.ndarray, total_seg: Optional[np.ndarray] = None,
             median_filtering: bool = False, examined_body_region: Optional[str] = None, crop_body: bool = False,
-            force_split: bool = False, raw_parts: Optional[np.ndarray] = None, raw_regions: Optional[np.ndarray] = None) -> dict:
+            force_split: bool = False, raw_parts: Optional[np.ndarray] = None, raw_regions: Optional[np.ndarray] = None,
+            done_parts: Optional[np.ndarray] = None, done_regions: Optional[np.ndarray] = None) -> dict:
         """-> {"body_parts", "body_regions", "tissues" (file axis order, uint8), "bca_measurements" (dict),
         "vertebrae" (dict)}.  `total_seg`: the `total` label volume on the same grid (vertebra groups), optional.
         The CT is uploaded once; every stage (nets, post-processing, LPS reload, tissues, tables) works on resident
         buffers, the three label volumes are downloaded at the end."""
         ctx = self.ctx
         affine = np.asarray(affine, dtype=np.float64)
+        if np.asarray(ct).dtype != np.int16:
+            from .compute.util import require_int16_exact
+            require_int16_exact(ct, "bca: CT")    # tissue rules / HU sums run on int16 HU: never truncate or wrap silently
         d_ct = DevArray.from_numpy(ctx, SegmentationTask._supported(ct))
         live = [d_ct]
         try:
-            d_parts = self._inference_device("body_parts", d_ct, affine, force_split, None, raw_parts)
+            d_parts = self._inference_device("body_parts", d_ct, affine, force_split, None, raw_parts, done_parts)
             live.append(d_parts)
             crop = d_parts.download() if crop_body else None
-            d_regions = self._inference_device("body_regions", d_ct, affine, force_split, crop, raw_regions)
+            d_regions = self._inference_device("body_regions", d_ct, affine, force_split, crop, raw_regions, done_regions)
             live.append(d_regions)
             with _Stage(ctx, "LPS reload, body-part flags, vertebrae, tissues + tables, JSON"):
                 _, laff = orientation.with_axcodes(np.empty(d_ct.shape, dtype=np.uint8), affine, "LPS")

@@ -56,3 +56,29 @@ def test_env_helpers_and_slices():
         assert config.env_str("B", "d") == "d" and config.env_str("C") == "x"
     for s, c, t, want in _g()["convert_resampling_slices"]:
         assert util.convert_resampling_slices(s, c, t) == want
+
+
+def test_cascade_crop_margin_is_the_references_effective_value():
+    """TS/python_api.py:726: `crop_addon = [20,20,20] if crop_model is None else crop_addon`.  None of the five cascade
+    tasks BOA runs names a crop_model (python_api.py:236-259,311-329; only craniofacial tasks do, :460), so the margin
+    that reaches nnUNet_predict_image is 20 mm for all of them -- not the per-task table value."""
+    from boa_hip import model_store
+    for t in model_store.CASCADE_MODELS:
+        assert model_store.TASKS[t].get("crop_model") is None
+        assert model_store.effective_crop_addon(t) == [20, 20, 20], t
+    # the table itself keeps the reference's per-task values (what a task WITH a crop_model would use)
+    assert model_store.TASKS["pleural_pericard_effusion"]["crop_addon"] == [50, 50, 50]
+    with pytest.raises(KeyError):
+        model_store.effective_crop_addon("total")
+
+
+def test_create_mask_and_int16_guard():
+    import numpy as np
+    a = np.array([[0, 3, 7], [7, 200, 3]], dtype=np.uint8)
+    assert (util.create_mask(a, 7) == (a == 7)).all()
+    assert (util.create_mask(a, (v for v in [3, 200])) == np.isin(a, [3, 200])).all()     # generators are fine
+    assert (util.create_mask(a.astype(np.float64) * np.array([1, np.nan, 1]), [3]) == np.array([[0, 0, 0], [0, 0, 1]], bool)).all()
+    assert util.require_int16_exact(np.array([-1024.0, 3071.0])).dtype == np.int16
+    for bad in (np.array([0.5]), np.array([40000.0]), np.array([70000], dtype=np.int32)):
+        with pytest.raises(ValueError):
+            util.require_int16_exact(bad)

@@ -91,7 +91,7 @@ def test_compute_all_models_total_bca(tmp_path, monkeypatch):
     lv, _, lh = nifti.load(out / "lung_vessels.nii.gz")
     info = model_store.TASKS["lung_vessels"]
     want = run_cascade_task(ctx, "lung_vessels", ct, aff, model_store.load_task_models("total_6mm"),
-                            model_store.load_task_models("lung_vessels"), info["crop"], info["crop_addon"])
+                            model_store.load_task_models("lung_vessels"), info["crop"], model_store.effective_crop_addon("lung_vessels"))
     np.testing.assert_array_equal(lv, want)
     assert lv.any() and set(np.unique(lv)) <= {0, 1, 2}
     assert nifti.parse_label_xml(lh.extensions[0][1]) == {1: "lung_vessels", 2: "lung_trachea_bronchia"}
