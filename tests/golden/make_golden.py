@@ -14,6 +14,7 @@ import json
 import os
 import struct
 import sys
+import zlib
 
 import numpy as np
 
@@ -129,7 +130,7 @@ def g3_sliding_window():
         ("c", (40, 36, 33), (16, 16, 16), 0.8, 4), ("d", (24, 16, 31), (16, 16, 16), 0.5, 2),
     ]
     for name, shape, patch, step, heads in cases:
-        torch.manual_seed(hash(name) % 1000)
+        torch.manual_seed(zlib.crc32(name.encode()) % 1000)  # deterministic (hash() is salted per process)
         net = torch.nn.Conv3d(1, heads, 3, padding=1)
         with torch.no_grad():
             net.weight.mul_(3.0)
@@ -392,13 +393,60 @@ def g11_measurement_label_maps():
                "cnr_adjusted_regions": {k: sorted(v) for k, v in CNR_ADJUSTED_REGIONS.items()}})
 
 
+# ---------------------------------------------------------------------------------------------- G12
+def g12_cropping():
+    """Bounding-box helpers at the reference's call sites: TS/cropping.py get_bbox_from_mask (:11-38, called from
+    crop_to_mask :75-110 with the mm -> voxel addon) + crop_to_bbox (:41-49), and the nonzero mask of nnU-Net's
+    crop_to_nonzero (NN/preprocessing/cropping/cropping.py:6-17: data != 0 followed by binary_fill_holes; its bbox is what
+    the un-vendored acvl_utils helper turns into slices)."""
+    from totalsegmentator.cropping import get_bbox_from_mask, crop_to_bbox
+    from nnunetv2.preprocessing.cropping.cropping import create_nonzero_mask
+    rng = np.random.default_rng(12)
+    out = {}
+    cases = []
+    for i, (shape, addon, ov) in enumerate([((20, 17, 23), 0, 0), ((20, 17, 23), [3, 1, 2], 0), ((9, 30, 12), [13, 13, 33], 0),
+                                            ((16, 16, 16), 2, 0), ((12, 10, 8), [1, 1, 1], -900), ((7, 7, 7), [20, 20, 20], 0)]):
+        m = np.zeros(shape, dtype=np.uint8)
+        if i != 3:                                    # case 3: empty mask ("Could not crop")
+            lo = [int(rng.integers(0, s // 2)) for s in shape]
+            hi = [int(rng.integers(l + 1, s + 1)) for l, s in zip(lo, shape)]
+            blob = rng.random(tuple(h - l for l, h in zip(lo, hi))) > 0.6
+            blob.flat[0] = True
+            m[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = blob
+        if ov == -900:
+            m = (m.astype(np.int16) * 1000 - 950)     # HU-like image with the default outside_value
+        bbox = get_bbox_from_mask(m, outside_value=ov, addon=addon)
+        img = rng.integers(-1000, 1000, size=shape).astype(np.int16)
+        out[f"c{i}_mask"] = m
+        out[f"c{i}_img"] = img
+        out[f"c{i}_addon"] = np.array([addon] * 3 if isinstance(addon, int) else addon)
+        out[f"c{i}_outside"] = np.array(ov)
+        out[f"c{i}_bbox"] = np.array(bbox)
+        out[f"c{i}_crop"] = crop_to_bbox(img, bbox)
+        cases.append(i)
+    # crop_to_nonzero's mask: hollow shell (holes get filled, bbox unchanged), two blobs, all zero
+    for j, kind in enumerate(["shell", "blobs", "zero"]):
+        d = np.zeros((1, 14, 15, 16), dtype=np.float32)
+        if kind == "shell":
+            d[0, 3:11, 2:12, 4:13] = 1.5
+            d[0, 5:9, 4:10, 6:11] = 0.0
+        elif kind == "blobs":
+            d[0, 1:3, 1:4, 2:5] = -2.0
+            d[0, 9:13, 8:14, 10:15] = 7.0
+        mask = create_nonzero_mask(d)
+        out[f"n{j}_data"] = d
+        out[f"n{j}_mask"] = mask.astype(np.uint8)
+    out["n_cases"] = np.array([len(cases), 3])
+    save_npz("g12_cropping.npz", **out)
+
+
 if __name__ == "__main__":
     ct = load_example_ct()
     print("example ct", ct.shape, ct.dtype, ct.min(), ct.max())
     only = sys.argv[1:]
     fns = dict(g1=g1_steps, g2=g2_gaussian, g3=g3_sliding_window, g3b=g3b_fold_ensemble, g4=lambda: g4_ctnorm(ct),
                g5=lambda: g5_resample(ct), g67=g67_argmax_merge, g10=g10_config, g9=g9_measurements, g8=g8_bca,
-               g11=g11_measurement_label_maps)
+               g11=g11_measurement_label_maps, g12=g12_cropping)
     for k, f in fns.items():
         if not only or k in only:
             f()

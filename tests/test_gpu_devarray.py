@@ -57,3 +57,18 @@ def test_nonzero_bbox(ctx, dtype):
     a[3:15, 7:30, 2:9] = rng.integers(1, 5, size=(12, 23, 7))
     a[16, 31, 12] = -3
     assert DevArray.from_numpy(ctx, a).nonzero_bbox() == nonzero_bbox(a)
+
+
+def test_nonzero_bbox_g12(ctx):
+    """boa_nonzero_bbox against the masks nnU-Net's own create_nonzero_mask produced (golden G12)."""
+    import os
+    from conftest import GOLDEN
+    from boa_hip.devarray import DevArray
+    z = np.load(os.path.join(GOLDEN, "g12_cropping.npz"))
+    for j in range(int(z["n_cases"][1])):
+        d, mask = z[f"n{j}_data"][0], z[f"n{j}_mask"].astype(bool)
+        want = []
+        for ax in range(3):
+            nz = np.flatnonzero(mask.any(axis=tuple(a for a in range(3) if a != ax)))
+            want.append([0, mask.shape[ax]] if nz.size == 0 else [int(nz[0]), int(nz[-1]) + 1])
+        assert DevArray.from_numpy(ctx, d).nonzero_bbox() == want, j

@@ -174,3 +174,25 @@ def test_explicit_spline_zoom_matches_scipy():
     ref = ndimage.zoom(x, (0.589242864991995, 0.9166715392459119, 1.27427627251354), order=3, mode="nearest")
     assert ref.shape == (6, 43, 18)
     np.testing.assert_array_equal(resample.spline_zoom_explicit(x, ref.shape, 3).view(np.uint64), ref.view(np.uint64))
+
+
+def test_g12_cropping_helpers():
+    """TS get_bbox_from_mask / crop_to_bbox and nnU-Net's create_nonzero_mask, executed from the reference (G12): the
+    oracle's `nonzero_bbox` and the product's host helpers (`task.get_bbox_from_mask`, `task.nonzero_bbox`) agree."""
+    from boa_hip import task
+    z = _npz("g12_cropping.npz")
+    n_c, n_n = (int(v) for v in z["n_cases"])
+    for i in range(n_c):
+        m, ov, addon = z[f"c{i}_mask"], int(z[f"c{i}_outside"]), [int(v) for v in z[f"c{i}_addon"]]
+        bbox = task.get_bbox_from_mask(m, outside_value=ov, addon=addon)
+        assert bbox == z[f"c{i}_bbox"].tolist(), i
+        sl = tuple(slice(a, b) for a, b in bbox)
+        np.testing.assert_array_equal(z[f"c{i}_img"][sl], z[f"c{i}_crop"])
+    for j in range(n_n):
+        d, mask = z[f"n{j}_data"], z[f"n{j}_mask"].astype(bool)
+        want = []
+        for ax in range(3):
+            nz = np.flatnonzero(mask.any(axis=tuple(a for a in range(3) if a != ax)))
+            want.append([0, mask.shape[ax]] if nz.size == 0 else [int(nz[0]), int(nz[-1]) + 1])
+        assert labels.nonzero_bbox(d) == want, j
+        assert task.nonzero_bbox(d[0]) == want, j        # binary_fill_holes cannot change the bounding box
