@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libboa_hip.so")
 BOA_OK, BOA_EINVAL, BOA_EHIP, BOA_ENOMEM, BOA_EINF = 0, -1, -2, -3, -4
 K_CONV_MFMA, K_CONV_FIRST, K_CONVT, K_NORM_FINALIZE, K_HEAD_ACCUM, K_ARGMAX, K_OTHER, K_COUNT = range(8)
 K_NAMES = ["conv_mfma", "conv_first", "convT_mfma", "norm_finalize", "head_accum", "finalize_argmax", "other"]
+CNT_NAMES = ["head_mfma", "head_valu", "conv_ws", "conv_simple", "first_mfma", "first_valu", "f32"]
 MAX_STAGES = 8
 
 
@@ -51,6 +52,8 @@ _PROTOS = {
     "boa_prof_reset": (i32, [vp]),
     "boa_prof_get": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                            C.POINTER(C.c_double)]),
+    "boa_debug_counter": (C.c_longlong, [vp, i32, i32]),
+    "boa_head_tile": (i32, [vp, vp, vp, i32, ip, i32, vp, vp, f32, vp, vp, vp, vp, ip, ip]),
     "boa_ct_normalize": (i32, [vp, vp, i32, vp, u64, f32, f32, f32, f32]),
     "boa_accumulate_tile": (i32, [vp, vp, vp, vp, vp, i32, ip, ip, ip]),
     "boa_finalize_labels": (i32, [vp, vp, vp, i32, ip, vp, i32, i32, i32, vp, i32, vp, ip, ip, vp]),

@@ -126,6 +126,10 @@ class Context:
     def prof_reset(self):
         check(self.lib.boa_prof_reset(self.h))
 
+    def counters(self, reset: bool = False) -> dict:
+        """Launches per kernel variant since creation / the last reset (boa_debug_counter)."""
+        return {name: int(self.lib.boa_debug_counter(self.h, k, 1 if reset else 0)) for k, name in enumerate(_lib.CNT_NAMES)}
+
     def prof_get(self):
         out = {}
         for k, name in enumerate(_lib.K_NAMES):

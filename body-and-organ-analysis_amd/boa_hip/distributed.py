@@ -1,9 +1,13 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU).
 
-Round-1 sharding of the hot path is by VOLUME (SURVEY 8e granularity 1): CT volumes are independent in the
-reference (one CT per process, TS/python_api.py:54-72), so ranks take disjoint volumes and no data-path
-collective exists; the only communication is the timing barrier / max-reduce of bench.py and the gather of small
-result tables.  (Tile sharding of one volume with an RCCL exchange of the 32-voxel overlap slabs is the next step.)
+This module holds the process-group set-up and the VOLUME granularity (SURVEY 8e granularity 1): CT volumes are
+independent in the reference (one CT per process, TS/python_api.py:54-72), so ranks take disjoint volumes and no data-path
+collective exists; the only communication is the timing barrier / max-reduce of bench.py and the gather of small result
+tables.  The two granularities that share ONE volume between the ranks live in `tile_shard.py`: the part models dealt out
+to the ranks (label volumes all-reduced), and the tile rows of the sliding window split across the ranks with the overlap
+slabs of the fp16 accumulators exchanged over RCCL (`TileShard`, exact hand-over or pairwise all-reduce); the z-slab
+sharding of the aggregation stages is in `agg_shard.py`.  torch.distributed is used for the collectives only; the C ABI
+stays free of torch types (device pointers cross as integers).
 """
 from __future__ import annotations
 

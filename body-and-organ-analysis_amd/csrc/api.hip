@@ -188,6 +188,13 @@ int boa_prof_flush(boa_ctx* c) {
     return BOA_OK;
 }
 
+extern "C" long long boa_debug_counter(boa_ctx* c, int which, int reset) {
+    if (!c || which < 0 || which >= BOA_CNT_COUNT) return -1;
+    const long long v = c->counters[which];
+    if (reset) c->counters[which] = 0;
+    return v;
+}
+
 extern "C" int boa_prof_enable(boa_ctx* c, int on) {
     BOA_REQUIRE(c, "ctx is NULL");
     if (!on) boa_prof_flush(c);

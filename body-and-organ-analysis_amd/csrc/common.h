@@ -57,6 +57,7 @@ struct boa_ctx {
     long long prof_launches[BOA_K_COUNT] = {};
     double prof_flops[BOA_K_COUNT] = {};
     double prof_bytes[BOA_K_COUNT] = {};
+    long long counters[BOA_CNT_COUNT] = {};  // launches per kernel variant (boa_debug_counter)
 };
 
 // RAII-less explicit bracket: KernelTimer t(ctx, klass, flops, bytes); <launch>; t.stop();

@@ -92,6 +92,7 @@ struct ConvArgs {
     float slope;
     int cy_fast;                // k_conv_ws: cout chunk is the fastest tile index (halo reuse, 2-chunk inputs)
     int nslots;                 // k_conv_ws: statistics slots per (n, cout) in `partials`
+    int vw;                     // k_conv_ws: virtual workgroups per sample (<= nslots / 4)
     unsigned long long* trace;  // debug (BOA_WS_TRACE): per-chunk s_memtime stamps of block 0, else nullptr
 };
 

@@ -393,6 +393,7 @@ int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const Con
     const double flops = 2.0 * vox * taps * (s0.C + s1.C) * g.Cout;
     const double bytes = 2.0 * ((double)g.N * g.Di * g.Hi * g.Wi * (s0.C + s1.C) + vox * g.Cout);
     if (t.variant == 1) return launch_conv_ws(ctx, a, t, flops, bytes);
+    ctx->counters[BOA_CNT_CONV_SIMPLE]++;
     KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);
     switch (t.R) {
         case 4: {
@@ -624,6 +625,7 @@ struct FirstMfmaArgs {
     float* partials;  // [N][32][2][nslots]
     int nslots;
     int t0, t1, t2;  // block tiles per axis
+    int vw;          // virtual workgroups per sample
 };
 
 __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
@@ -653,8 +655,7 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
     int st_n = -1;
-    const int slot = (int)blockIdx.x * 4 + wave;
-    auto flush = [&]() {
+    auto flush = [&](int slot) {
         if (st_n < 0) return;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -676,19 +677,45 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
     };
-    const int nsp = p.t0 * p.t1 * p.t2, total = nsp * p.N;
+    const int nsp = p.t0 * p.t1 * p.t2;
     const size_t pvol = (size_t)p.PX * p.PY * p.PZ, ovox = (size_t)p.P0 * p.P1 * p.P2;
+    // Tile sequence: the spatial tiles of ONE sample are dealt out to vw = min(nsp, CUs) virtual workgroups (j takes
+    // sp = j, j + vw, ...), whose partial sums go to statistics slot 4 j + wave of that sample -- a function of the sample
+    // alone, not of the batch it shares the launch with (batch-invariant results, as in k_conv_ws).  Physical workgroup b
+    // executes the virtual workgroups b, b + G, ...
+    const int vw = p.vw, nvirt = p.N * vw;
+    struct Seq {
+        int v, n, j, sp;
+    };
+    auto seq_valid = [&](const Seq& q) { return q.v < nvirt; };
+    auto seq_first = [&]() {
+        Seq q;
+        q.v = (int)blockIdx.x;
+        q.n = q.v / vw;
+        q.j = q.v - q.n * vw;
+        q.sp = q.j;
+        return q;
+    };
+    auto seq_next = [&](Seq q) {
+        q.sp += vw;
+        if (q.sp >= nsp) {
+            q.v += (int)gridDim.x;
+            q.n = q.v / vw;
+            q.j = q.v - q.n * vw;
+            q.sp = q.j;
+        }
+        return q;
+    };
     // halo staging is split in two halves so that the global round trip of the NEXT tile overlaps this tile's compute:
     // fetch() issues the loads into registers, commit() converts and writes them to the other LDS buffer afterwards
     constexpr int NPRE = (HV + 255) / 256;
     float pre[NPRE];
-    auto fetch = [&](int t) {
-        const int n = t / nsp;
-        int sp = t % nsp;
+    auto fetch = [&](const Seq& q) {
+        int sp = q.sp;
         const int tz = sp % p.t2;
         sp /= p.t2;
         const int ty = sp % p.t1, tx = sp / p.t1;
-        const float* src = p.padded + (size_t)n * pvol + ((size_t)(tx * MF0) * p.PY + ty * MF1) * p.PZ + tz * MF2;
+        const float* src = p.padded + (size_t)q.n * pvol + ((size_t)(tx * MF0) * p.PY + ty * MF1) * p.PZ + tz * MF2;
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) {
             const int i = min(tid + 256 * j, HV - 1);
@@ -703,24 +730,28 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
             if (i < HV) halo[buf][i] = (_Float16)pre[j];
         }
     };
-    int t = blockIdx.x;
-    if (t < total) {
-        fetch(t);
+    Seq cur = seq_first();
+    if (seq_valid(cur)) {
+        fetch(cur);
         commit(0);
     }
     __syncthreads();
-    for (int it = 0; t < total; t += gridDim.x, ++it) {
+    int st_v = -1, slot = 0;
+    for (int it = 0; seq_valid(cur); ++it) {
         const int buf = it & 1;
-        const bool more = t + (int)gridDim.x < total;
-        if (more) fetch(t + gridDim.x);
-        const int n = t / nsp;
-        int sp = t % nsp;
+        const Seq nxt = seq_next(cur);
+        const bool more = seq_valid(nxt);
+        if (more) fetch(nxt);
+        const int n = cur.n;
+        int sp = cur.sp;
         const int tz = sp % p.t2;
         sp /= p.t2;
         const int ty = sp % p.t1, tx = sp / p.t1;
-        if (n != st_n) {
-            flush();
+        if (cur.v != st_v) {
+            flush(slot);
+            st_v = cur.v;
             st_n = n;
+            slot = cur.j * 4 + wave;
         }
         const _Float16* hb = halo[buf];
 #pragma unroll 2
@@ -775,8 +806,9 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
         }
         if (more) commit(buf ^ 1);
         __syncthreads();
+        cur = nxt;
     }
-    flush();
+    flush(slot);
 }
 
 static bool first_mfma_ok(int Cin, const int P[3], const int k[3], int Cout) {
@@ -818,8 +850,10 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
         m.N = N; m.P0 = P[0]; m.P1 = P[1]; m.P2 = P[2];
         m.w = w; m.bias = bias; m.out = out; m.partials = partials; m.nslots = nblk_tab;
         m.t0 = P[0] / MF0; m.t1 = P[1] / MF1; m.t2 = P[2] / MF2;
-        const int total = m.t0 * m.t1 * m.t2 * N;
-        hipLaunchKernelGGL(k_conv_first_mfma, dim3(std::min(total, ctx->cu_count)), dim3(256), 0, ctx->stream, m);
+        m.vw = std::min(m.t0 * m.t1 * m.t2, ctx->cu_count);
+        hipLaunchKernelGGL(k_conv_first_mfma, dim3((unsigned)std::min<long long>((long long)m.vw * N, ctx->cu_count)), dim3(256), 0,
+                           ctx->stream, m);
+        ctx->counters[BOA_CNT_FIRST_MFMA]++;
         tm.stop();
         BOA_HIP_TRY(hipGetLastError());
         return BOA_OK;
@@ -837,6 +871,7 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
         hipLaunchKernelGGL((k_conv_first<3, 3, 3>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
     else
         hipLaunchKernelGGL((k_conv_first<1, 3, 3>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
+    ctx->counters[BOA_CNT_FIRST_VALU]++;
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
@@ -1149,6 +1184,10 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
 // same 32 voxels per instruction (64 contiguous bytes each).
 typedef _Float16 hh2_t __attribute__((ext_vector_type(2)));
 
+// LOGITS = true: the same MFMA / bias / transpose path, but the fp32 logits [C][P0][P1][P2] are written out instead of
+// being accumulated (boa_net_forward, and the seam that proves the accumulate arithmetic of THIS kernel bit-exact: the
+// logits it writes are the values its accumulate mode multiplies by the Gaussian and adds).
+template <bool LOGITS>
 __global__ __launch_bounds__(256, 5) void k_head_mfma(HeadArgs p) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
     f16x8 a0, a1;
@@ -1208,8 +1247,9 @@ __global__ __launch_bounds__(256, 5) void k_head_mfma(HeadArgs p) {
     const int mpr = p.P2 / 32;                     // M-tiles per (x, y) row
     const int n_mt = p.P0 * p.P1 * mpr;
     const size_t vv = (size_t)p.V0 * p.V1 * p.V2;
+    const size_t pv = (size_t)p.P0 * p.P1 * p.P2;
     const int gw = (int)((blockIdx.x * 256 + threadIdx.x) >> 6), nw = (int)(gridDim.x * 4);
-    const int n_items = (p.C + 1) * 4;             // (class, group of 8 voxels); class index C = the n_predictions row
+    const int n_items = LOGITS ? p.C * 4 : (p.C + 1) * 4;  // (class, group of 8 voxels); class index C = the n_predictions row
     for (int mt = gw; mt < n_mt; mt += nw) {
         const int zb = (mt % mpr) * 32, row = mt / mpr, p1 = row % p.P1, p0 = row / p.P1;
         const size_t t0 = ((size_t)p0 * p.P1 + p1) * p.P2 + zb;       // first voxel of the M-tile within the tile
@@ -1218,16 +1258,18 @@ __global__ __launch_bounds__(256, 5) void k_head_mfma(HeadArgs p) {
         const uint4 r0 = rec[kh], r1 = rec[2 + kh];
         // the RMW operands of this lane's items: issued before the MFMAs so that their latency overlaps
         uint4 gq8[2], old8[2];
+        if (!LOGITS) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int item = lane + 64 * it;
-            const int c = item >> 2, grp = item & 3;
-            gq8[it] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);  // 1.0 (no Gaussian)
-            old8[it] = make_uint4(0, 0, 0, 0);
-            if (item < n_items) {
-                if (p.gauss) gq8[it] = *(const uint4*)(p.gauss + t0 + 8 * grp);
-                const unsigned short* src = (c < p.C ? p.acc + (size_t)c * vv : p.nacc) + v0 + 8 * grp;
-                old8[it] = *(const uint4*)src;
+            for (int it = 0; it < 2; ++it) {
+                const int item = lane + 64 * it;
+                const int c = item >> 2, grp = item & 3;
+                gq8[it] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);  // 1.0 (no Gaussian)
+                old8[it] = make_uint4(0, 0, 0, 0);
+                if (item < n_items) {
+                    if (p.gauss) gq8[it] = *(const uint4*)(p.gauss + t0 + 8 * grp);
+                    const unsigned short* src = (c < p.C ? p.acc + (size_t)c * vv : p.nacc) + v0 + 8 * grp;
+                    old8[it] = *(const uint4*)src;
+                }
             }
         }
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1241,26 +1283,32 @@ __global__ __launch_bounds__(256, 5) void k_head_mfma(HeadArgs p) {
             const int item = lane + 64 * it;
             const int c = item >> 2, grp = item & 3;
             if (item < n_items) {
-                union {
-                    uint4 u;
-                    unsigned short h[8];
-                } g, o;
-                g.u = gq8[it];
-                o.u = old8[it];
                 float4 lo = make_float4(1.f, 1.f, 1.f, 1.f), hi = lo;  // the n_predictions row adds the Gaussian itself
                 if (c < p.C) {
                     lo = *(const float4*)(slab + c * 36 + 8 * grp);
                     hi = *(const float4*)(slab + c * 36 + 8 * grp + 4);
                 }
-                const float sum[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (LOGITS) {
+                    float* dst = p.logits + (size_t)c * pv + t0 + 8 * grp;
+                    *(float4*)dst = lo;
+                    *(float4*)(dst + 4) = hi;
+                } else {
+                    union {
+                        uint4 u;
+                        unsigned short h[8];
+                    } g, o;
+                    g.u = gq8[it];
+                    o.u = old8[it];
+                    const float sum[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float gg = us2f(g.h[e]);
-                    const float pr = (p.gauss || c >= p.C) ? sum[e] * gg : sum[e];  // prediction *= gaussian (fp32); n += g
-                    o.h[e] = f2us(us2f(o.h[e]) + pr);                               // fp16 += fp32 (fp32 add, RTNE)
+                    for (int e = 0; e < 8; ++e) {
+                        const float gg = us2f(g.h[e]);
+                        const float pr = (p.gauss || c >= p.C) ? sum[e] * gg : sum[e];  // prediction *= gaussian (fp32); n += g
+                        o.h[e] = f2us(us2f(o.h[e]) + pr);                               // fp16 += fp32 (fp32 add, RTNE)
+                    }
+                    unsigned short* dst = (c < p.C ? p.acc + (size_t)c * vv : p.nacc) + v0 + 8 * grp;
+                    *(uint4*)dst = o.u;
                 }
-                unsigned short* dst = (c < p.C ? p.acc + (size_t)c * vv : p.nacc) + v0 + 8 * grp;
-                *(uint4*)dst = o.u;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1289,17 +1337,25 @@ int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const 
     double bytes = (double)pv * (2.0 * F0 + (logits_out ? 4.0 * C : (4.0 * (C + 1) + 2.0)));
     KernelTimer tm(ctx, BOA_K_HEAD_ACCUM, 2.0 * pv * F0 * C, bytes);
     static const bool mfma_off = getenv("BOA_HEAD_MFMA") && atoi(getenv("BOA_HEAD_MFMA")) == 0;
+    const bool mfma_shape = !mfma_off && F0 == 32 && C <= 31 && P[2] % 32 == 0 && ((uintptr_t)act) % 16 == 0;
+    const unsigned mfma_grid = (unsigned)std::min<size_t>(std::max<size_t>(pv / 32 / 4, 1), (size_t)ctx->cu_count * 8);
     // 16-byte accumulator accesses: the tile's z origin, the volume's z extent and the buffers must be 8-voxel aligned
-    if (!logits_out && !mfma_off && F0 == 32 && C <= 31 && P[2] % 32 == 0 && start[2] % 8 == 0 && PV[2] % 8 == 0 &&
-        ((uintptr_t)acc) % 16 == 0 && ((uintptr_t)nacc) % 16 == 0 && (!gauss || ((uintptr_t)gauss) % 16 == 0))
-        hipLaunchKernelGGL(k_head_mfma, dim3((unsigned)std::min<size_t>(pv / 32 / 4, (size_t)ctx->cu_count * 8)), dim3(256), 0,
-                           ctx->stream, a);
-    else if (pair)
-        hipLaunchKernelGGL((k_head<32, 2>), dim3((unsigned)((pv / 2 + 255) / 256)), dim3(256), lds, ctx->stream, a);
-    else if (F0 == 32)
-        hipLaunchKernelGGL((k_head<32, 1>), dim3((unsigned)((pv + 255) / 256)), dim3(256), lds, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((k_head<64, 1>), dim3((unsigned)((pv + 255) / 256)), dim3(256), lds, ctx->stream, a);
+    if (!logits_out && mfma_shape && start[2] % 8 == 0 && PV[2] % 8 == 0 && ((uintptr_t)acc) % 16 == 0 &&
+        ((uintptr_t)nacc) % 16 == 0 && (!gauss || ((uintptr_t)gauss) % 16 == 0)) {
+        hipLaunchKernelGGL(k_head_mfma<false>, dim3(mfma_grid), dim3(256), 0, ctx->stream, a);
+        ctx->counters[BOA_CNT_HEAD_MFMA]++;
+    } else if (logits_out && mfma_shape && ((uintptr_t)logits_out) % 16 == 0) {
+        hipLaunchKernelGGL(k_head_mfma<true>, dim3(mfma_grid), dim3(256), 0, ctx->stream, a);
+        ctx->counters[BOA_CNT_HEAD_MFMA]++;
+    } else {
+        if (pair)
+            hipLaunchKernelGGL((k_head<32, 2>), dim3((unsigned)((pv / 2 + 255) / 256)), dim3(256), lds, ctx->stream, a);
+        else if (F0 == 32)
+            hipLaunchKernelGGL((k_head<32, 1>), dim3((unsigned)((pv + 255) / 256)), dim3(256), lds, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_head<64, 1>), dim3((unsigned)((pv + 255) / 256)), dim3(256), lds, ctx->stream, a);
+        ctx->counters[BOA_CNT_HEAD_VALU]++;
+    }
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

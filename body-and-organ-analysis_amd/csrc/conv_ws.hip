@@ -110,25 +110,30 @@ __device__ __forceinline__ void next_tile(const ConvArgs& p, TileCoord& c) {
     }
 }
 
-// Tile sequence of a workgroup.  Workgroup b is observed to run on XCD b % 8 (each XCD has a private 4 MiB L2):
-// the tile list is cut into 8 contiguous ranges, one per XCD, and the 32 workgroups of an XCD walk their range
-// together (stride = workgroups per XCD), so the halos an XCD re-reads are the ones its own L2 just fetched.
-// Placement only changes speed, never results.
+// Tile sequence of a workgroup.  The tiles of ONE sample (spatial tiles x cout chunks, in decode_tile's order) are cut
+// into `vw` contiguous runs, one per VIRTUAL workgroup j of that sample (vw = min(tiles per sample, CUs): a function of the
+// layer geometry only).  Virtual workgroup (n, j) accumulates the InstanceNorm partial sums of its run and writes them to
+// statistics slot 4 j + wave of sample n, so the set of partial sums of a sample -- and with it the sample's (scale, shift)
+// and every later activation -- does not depend on how many other samples share the launch (batch-invariant results: the
+// same tile gives the same logits at tile batch 1, 4 or 8 and in a tile-sharded run).  A physical workgroup b executes the
+// virtual workgroups b, b + G, b + 2G, ... one after the other; which physical workgroup runs a virtual one only affects
+// speed.  Workgroup b is observed to run on XCD b % 8 (each XCD has a private 4 MiB L2): a sample's tile list is cut into 8
+// contiguous ranges, one per XCD (j % 8 == b % 8), and the virtual workgroups of an XCD take contiguous runs of that range,
+// so the halos an XCD re-reads are the ones its own L2 just fetched.
 struct TileWalk {
-    int first, count;  // a contiguous run of tile indices
+    int first, count;  // a contiguous run of sample-local tile indices
 };
 
-__device__ __forceinline__ TileWalk tile_walk(int total_tiles) {
+__device__ __forceinline__ TileWalk tile_walk(int tiles_per_sample, int vw, int j) {
     TileWalk w;
-    const int G = (int)gridDim.x, b = (int)blockIdx.x;
-    if (G % 8 != 0) {
-        const int q = total_tiles / G, r = total_tiles % G;
-        w.first = b * q + min(b, r);
-        w.count = q + (b < r ? 1 : 0);
+    if (vw % 8 != 0) {
+        const int q = tiles_per_sample / vw, r = tiles_per_sample % vw;
+        w.first = j * q + min(j, r);
+        w.count = q + (j < r ? 1 : 0);
         return w;
     }
-    const int xcd = b & 7, slot = b >> 3, per = G >> 3;  // per = workgroups per XCD
-    const int q = total_tiles / 8, rem = total_tiles % 8;
+    const int xcd = j & 7, slot = j >> 3, per = vw >> 3;  // per = virtual workgroups per XCD
+    const int q = tiles_per_sample / 8, rem = tiles_per_sample % 8;
     const int lo = xcd * q + min(xcd, rem);
     const int len = q + (xcd < rem ? 1 : 0);
     // contiguous run per workgroup: consecutive tiles of a workgroup are neighbours along x (x-fastest tile order),
@@ -138,6 +143,44 @@ __device__ __forceinline__ TileWalk tile_walk(int total_tiles) {
     w.first = lo + slot * cq + min(slot, cr);
     w.count = cq + (slot < cr ? 1 : 0);
     return w;
+}
+
+// virtual workgroup index v (global over the samples of the launch) -> (sample, j).  The rotation by the sample index
+// spreads the runs that are one tile longer over the physical workgroups (j % 8 is kept: XCD affinity).
+__device__ __forceinline__ void virt_decode(int v, int vw, int& n, int& j) {
+    n = v / vw;
+    j = v - n * vw;
+    if (vw % 8 == 0 && vw >= 16) {
+        const int per = vw >> 3;
+        j = (j + 8 * ((n * 5) % per)) % vw;
+    }
+}
+
+struct TileSeq {
+    int v;     // current virtual workgroup
+    int left;  // tiles left in its run, the current one included
+    int j;     // its index within the sample (statistics slot = 4 j + wave)
+    TileCoord tc;
+};
+
+__device__ __forceinline__ void seq_run(const ConvArgs& p, int tiles_per_sample, int v, TileSeq& s) {
+    int n, j;
+    virt_decode(v, p.vw, n, j);
+    const TileWalk w = tile_walk(tiles_per_sample, p.vw, j);
+    s.v = v;
+    s.j = j;
+    s.left = w.count;
+    s.tc = decode_tile(p, n * tiles_per_sample + w.first);
+}
+
+// next tile of this workgroup's sequence; true when it is the first tile of a new virtual workgroup
+__device__ __forceinline__ bool seq_next(const ConvArgs& p, int tiles_per_sample, TileSeq& s) {
+    if (--s.left > 0) {
+        next_tile(p, s.tc);
+        return false;
+    }
+    seq_run(p, tiles_per_sample, s.v + (int)gridDim.x, s);
+    return true;
 }
 
 // ---- producer ----------------------------------------------------------------------------------------
@@ -509,8 +552,15 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     const int buf_bytes = resident_w ? 2 * plane : 2 * plane + taps * 1024;
     unsigned char* bufs = smem + wres_bytes;
 
-    const TileWalk walk = tile_walk(total_tiles);
-    const int my_chunks = walk.count * ncc;
+    // this workgroup's tiles: the runs of the virtual workgroups b, b + G, ... (total_tiles = tiles per sample here)
+    const int tiles_per_sample = total_tiles;
+    int my_tiles = 0;
+    for (int v = (int)blockIdx.x; v < p.N * p.vw; v += (int)gridDim.x) {
+        int n_, j_;
+        virt_decode(v, p.vw, n_, j_);
+        my_tiles += tile_walk(tiles_per_sample, p.vw, j_).count;
+    }
+    const int my_chunks = my_tiles * ncc;
 
     if (resident_w) {
         // (only used when Cout == 32: every tile of the launch uses the same weights)
@@ -528,7 +578,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         if (dbg & 256) __builtin_amdgcn_s_setprio(1);
         if (dbg & 512) __builtin_amdgcn_s_setprio(3);
         const ProdConst pc = prod_const(p, q, HV);
-        TileCoord ptc;
+        TileSeq pseq;
+        pseq.v = pseq.left = pseq.j = 0;
+        TileCoord& ptc = pseq.tc;
         ptc.n = ptc.cy = ptc.ox0 = ptc.oy0 = ptc.oz0 = ptc.sp = 0;
         ProdItems items;
 #pragma unroll
@@ -549,7 +601,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         int w_cc = 0, w_cy = 0;  // (chunk, cout chunk) of the chunk issued last = the one committed next (its weights go by DMA)
         const bool live = !(dbg & 2);
         if (live && my_chunks > 0) {
-            ptc = decode_tile(p, walk.first);
+            seq_run(p, tiles_per_sample, (int)blockIdx.x, pseq);
             prod_setup(p, ptc, pc, items);
             prod_issue(p, ptc, items, pc.in_halo, 0, false, q, dbg, rg);
             w_cy = ptc.cy;
@@ -572,8 +624,8 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 WS_STAMP(2);
                 if (g + 2 < my_chunks) {
                     if (pcc == 0) {
-                        next_tile(p, ptc);
-                        reuse = p.cy_fast && ptc.cy != 0;  // same spatial tile as the previous tile of this run
+                        const bool new_run = seq_next(p, tiles_per_sample, pseq);
+                        reuse = p.cy_fast && ptc.cy != 0 && !new_run;  // same spatial tile as the previous tile of this run
                         if (!reuse) prod_setup(p, ptc, pc, items);
                         WS_STAMP(8);
                     }
@@ -622,7 +674,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     }
     const size_t out_vox = (size_t)p.Do * p.Ho * p.Wo;
     const int nslots = p.nslots;
-    const int slot = (int)blockIdx.x * 4 + cw;
+    int slot = 0;  // 4 j + wave of the virtual workgroup whose run is being accumulated
     // InstanceNorm partial sums of this wave in the D-fragment layout: entry gq * 4 + e <-> cout 8 gq + 4 kh + e, summed
     // over the voxels (lane l31 of every M-tile) this lane produced since the last flush, from the fp32 accumulators;
     // one flush per (n, cout chunk) the wave works on.
@@ -669,18 +721,26 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         }
     };
 
-    TileCoord tc;
+    TileSeq cseq;
+    cseq.v = cseq.left = cseq.j = 0;
+    TileCoord& tc = cseq.tc;
     tc.n = tc.cy = tc.ox0 = tc.oy0 = tc.oz0 = tc.sp = 0;
     if (p.trace && blockIdx.x == 0 && tid == 0) {
         p.trace[WS_TRACE_SLOTS - 4] = __builtin_readcyclecounter();
         p.trace[WS_TRACE_SLOTS - 3] = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();  // chunk 0 staged (pairs with the producers' g = -1 barrier)
-    for (int k = 0; k < walk.count; ++k) {
+    for (int k = 0; k < my_tiles; ++k) {
+        bool new_run = true;
         if (k == 0)
-            tc = decode_tile(p, walk.first);
+            seq_run(p, tiles_per_sample, (int)blockIdx.x, cseq);
         else
-            next_tile(p, tc);
+            new_run = seq_next(p, tiles_per_sample, cseq);
+        if (new_run) {  // the partial sums of a virtual workgroup go to its own slot
+            flush_stats();
+            st_n = -1;
+            slot = cseq.j * 4 + cw;
+        }
         f32x16 acc[R];
         for (int cc = 0; cc < ncc; ++cc) {
             const int g = k * ncc + cc;
@@ -863,8 +923,10 @@ static int launch_ws_r(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int t
 
 int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes) {
     const ConvArgs& a0 = a_in;
-    const int total = t.tiles[0] * t.tiles[1] * t.tiles[2] * (a0.Cout / 32) * a0.N;
-    const int grid = std::min(total, ctx->cu_count);
+    // tiles of one sample; its virtual workgroups (batch-invariant statistics, see tile_walk); physical grid
+    const int total = t.tiles[0] * t.tiles[1] * t.tiles[2] * (a0.Cout / 32);
+    const int vw = std::min(total, ctx->cu_count);
+    const int grid = (int)std::min<long long>((long long)vw * a0.N, ctx->cu_count);
     const int taps = a0.k0 * a0.k1 * a0.k2;
     const int HV = t.h[0] * t.h[1] * t.h[2];
     const int resident = conv_ws_resident(HV, taps, (a0.C0 + a0.C1) / 16, a0.Cout) ? 1 : 0;
@@ -877,6 +939,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     a.trace = nullptr;
     // statistics slots: one per (workgroup, consumer wave); waves that never touch an (n, cout chunk) leave zeros
     a.nslots = conv_ws_nslots(ctx->cu_count);
+    a.vw = vw;
     a.cy_fast = ((a.C0 + a.C1) == 32 && a.Cout == 64 && t.R == 1 && !getenv("BOA_WS_NO_CYFAST")) ? 1 : 0;
     // a.partials must be all zero on entry: the callers zero it once (allocation / test seam) and k_norm_finalize
     // clears what it has read, so no per-launch memset is needed
@@ -885,6 +948,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
         hipMemsetAsync(a.trace, 0, WS_TRACE_SLOTS * 8, ctx->stream);
     }
     KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);
+    ctx->counters[BOA_CNT_CONV_WS]++;
     int rc;
     switch (t.R) {
         case 4: rc = launch_ws_r<4>(ctx, a, t, total, grid, resident); break;
@@ -904,7 +968,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
         fprintf(stderr, "[ws-clock] Cin=%d Cout=%d in=%d: %llu cycles in %llu x10ns -> %.3f GHz, %d tiles per block\n", a0.C0 + a0.C1, a0.Cout, a0.Di,
                 host[WS_TRACE_SLOTS - 2] - host[WS_TRACE_SLOTS - 4], host[WS_TRACE_SLOTS - 1] - host[WS_TRACE_SLOTS - 3],
                 (double)(host[WS_TRACE_SLOTS - 2] - host[WS_TRACE_SLOTS - 4]) / (10.0 * (double)(host[WS_TRACE_SLOTS - 1] - host[WS_TRACE_SLOTS - 3])),
-                (total + grid - 1) / grid);
+                (total * a0.N + grid - 1) / grid);
         for (int role = 0; role < 2; ++role) {
             const unsigned long long* h = host + role * (WS_TRACE_SLOTS / 2);
             fprintf(stderr, "[ws-trace] %s Cin=%d Cout=%d in=%d R=%d:", role ? "producer" : "consumer", a0.C0 + a0.C1, a0.Cout, a0.Di, t.R);

@@ -653,6 +653,16 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     return rc;
 }
 
+extern "C" int boa_head_tile(boa_ctx* ctx, const uint16_t* dev_act, const float* dev_ss, int F0, const int P[3], int C,
+                             const float* dev_w, const float* dev_b, float slope, float* dev_logits_out,
+                             const uint16_t* dev_gauss, uint16_t* dev_acc, uint16_t* dev_n, const int PV[3],
+                             const int start[3]) {
+    BOA_REQUIRE(ctx && dev_act && dev_ss && P && dev_w && dev_b, "boa_head_tile: NULL argument");
+    BOA_REQUIRE(dev_logits_out || (dev_acc && dev_n && PV && start), "boa_head_tile: neither logits_out nor accumulators given");
+    return launch_head(ctx, (const __half*)dev_act, dev_ss, F0, P, C, dev_w, dev_b, slope, dev_logits_out, dev_gauss, dev_acc,
+                       dev_n, PV, start);
+}
+
 extern "C" int boa_convtranspose_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, const int dims[3],
                                       const float* host_w, const float* host_b, int Cout, const int stride[3],
                                       float* dev_out) {

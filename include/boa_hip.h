@@ -69,6 +69,18 @@ int boa_timer_stop(boa_ctx* ctx, int slot, float* ms_out);
 int boa_prof_enable(boa_ctx* ctx, int on);
 int boa_prof_reset(boa_ctx* ctx);
 int boa_prof_get(boa_ctx* ctx, int kclass, double* total_ms, long long* launches, double* flops, double* bytes);
+/* Which kernel VARIANT ran (always on, independent of profiling): number of launches since the context was created or the
+ * counter was last reset.  The parity tests assert with these that the kernel they check is the one the product path and
+ * bench.py launch (e.g. the MFMA head, not its fp32 VALU fallback).  Returns the count, < 0 on a bad argument. */
+#define BOA_CNT_HEAD_MFMA 0       /* k_head_mfma (accumulate or logits mode)                           */
+#define BOA_CNT_HEAD_VALU 1       /* k_head<F0, VPT> fallback (unaligned z origin / P2 % 32 / F0 = 64) */
+#define BOA_CNT_CONV_WS 2         /* k_conv_ws (wave-specialised persistent conv)                     */
+#define BOA_CNT_CONV_SIMPLE 3     /* k_conv_mfma (fallback for kernel shapes k_conv_ws lacks)          */
+#define BOA_CNT_FIRST_MFMA 4      /* k_conv_first_mfma                                                 */
+#define BOA_CNT_FIRST_VALU 5      /* k_conv_first<K> fallback                                          */
+#define BOA_CNT_F32 6             /* any kernel of the fp32 "exact" network mode (precision = 1)       */
+#define BOA_CNT_COUNT 8
+long long boa_debug_counter(boa_ctx* ctx, int which, int reset);
 
 /* ------------------------------------------------------------------ sliding-window arithmetic seams -- */
 /* CTNormalization.run (NN/preprocessing/normalization/default_normalization_schemes.py:53-67):
@@ -188,6 +200,18 @@ int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, const
                         const float* host_w, const float* host_b, const float* host_gamma, const float* host_beta,
                         int Cout, const int kernel[3], const int stride[3], int with_norm_act, int impl,
                         float* dev_out); /* impl must be 0 */
+/* Unit-test seam: the fused 1x1x1 head + Gaussian-weighted fp16 accumulation of ONE tile, launched exactly as the tile
+ * loop of boa_net_predict_sliding_window launches it (same kernel selection: the MFMA head when F0 == 32, C <= 31,
+ * P[2] % 32 == 0 and the z origin / extent are 8-voxel aligned, else the fp32 VALU head; boa_debug_counter tells which).
+ *   act  dev fp16 [P0][P1][P2][F0]: the last decoder conv's raw output;  ss dev fp32 [F0][2] its InstanceNorm (scale, shift)
+ *   w    dev fp32 [C][F0], b dev fp32 [C]
+ *   logits_out != NULL: write the tile's fp32 logits [C][P0][P1][P2] (what `self.network(x)` returns, :543);
+ *   logits_out == NULL: `pred *= gauss; acc[sl] += pred; n[sl] += gauss` (:611-614) on acc [C][PV] / n [PV] at `start`.
+ * The two modes run the same instruction sequence up to the logit, so accumulating tiles and comparing with the oracle's
+ * accumulate step applied to the logits-mode output checks the production accumulate arithmetic bit for bit. */
+int boa_head_tile(boa_ctx* ctx, const uint16_t* dev_act, const float* dev_ss, int F0, const int P[3], int C,
+                  const float* dev_w, const float* dev_b, float slope, float* dev_logits_out, const uint16_t* dev_gauss,
+                  uint16_t* dev_acc, uint16_t* dev_n, const int PV[3], const int start[3]);
 int boa_convtranspose_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, const int dims[3],
                            const float* host_w, const float* host_b, int Cout, const int stride[3], float* dev_out);
 

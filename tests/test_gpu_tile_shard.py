@@ -5,10 +5,12 @@ GPU), each rank finalises its planes and the label volumes are all-reduced.
 `exact` mode must give labels bit-identical to the single-process loop (which the other GPU tests pin to the oracle);
 `allreduce` mode may flip labels at fp16 near-ties inside the slabs only -- the flip fraction is printed and bounded.
 
-The comparison runs the conv stack one tile per launch (max_batch=1): the InstanceNorm statistics are fp32 sums whose
-grouping follows the persistent tile schedule, i.e. the composition of the tile batch, so a tile's logits are
-reproducible bit for bit only for the same batch composition ("determinism") -- and the ranks of a sharded
-run necessarily cut the tile list into different batches than one process does."""
+The ranks of a sharded run cut the tile list into different tile batches than one process does; the comparison therefore
+also proves that a tile's logits do not depend on the batch it shares a launch with (the InstanceNorm partial sums are
+reduced per sample over virtual workgroups whose tile runs are a function of the layer geometry alone, DESIGN.md
+"determinism"): the single-process reference runs at tile batch 4, the ranks at tile batch 3.
+
+With two or more GPUs visible the same protocol also runs over RCCL with one GPU per rank (skipped on one-GPU boxes)."""
 import os
 import socket
 import sys
@@ -70,32 +72,38 @@ def _predict(ctx, shard=None, model_shard=None, max_batch=1):
         task.close()
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, backend="gloo"):
     sys.path[:0] = [HERE, os.path.join(HERE, "body-and-organ-analysis_amd")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from boa_hip import distributed as D
     from boa_hip import tile_shard as ts
     from boa_hip.device import Context
-    dist = D.init("gloo", rank, world)
-    ctx = Context(0)
-    comm = ts.ShardComm(dist, rank, world, "cpu")
+    if backend == "nccl":           # RCCL: one GPU per rank, device tensors alias the engine's buffers
+        dist = D.init("nccl", rank, world, rank)
+        ctx = Context(rank)
+        comm = ts.ShardComm(dist, rank, world, f"cuda:{rank}")
+    else:                           # gloo: the ranks share cuda:0, slabs are staged through the host
+        dist = D.init("gloo", rank, world)
+        ctx = Context(0)
+        comm = ts.ShardComm(dist, rank, world, "cpu")
     if mode == "models":
         lab = _predict(ctx, model_shard=comm, max_batch=4)
     else:
-        lab = _predict(ctx, ts.TileShard(comm, mode))
+        lab = _predict(ctx, ts.TileShard(comm, mode), max_batch=3)
     q.put((rank, lab))
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
 
 
-def _run(world, mode):
+def _run(world, mode, backend="gloo"):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, mode, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=300) for _ in range(world))
@@ -109,7 +117,7 @@ def _run(world, mode):
 def single():
     from boa_hip.device import Context
     c = Context(0)
-    lab = _predict(c)
+    lab = _predict(c, max_batch=4)
     c.close()
     assert len(np.unique(lab)) > 3
     return lab
@@ -120,6 +128,31 @@ def test_exact_mode_labels_bit_identical(single, world):
     got = _run(world, "exact")
     for r in range(world):
         np.testing.assert_array_equal(got[r], single)       # every rank ends with the full, identical label volume
+
+
+def test_single_process_labels_do_not_depend_on_the_tile_batch(single):
+    from boa_hip.device import Context
+    c = Context(0)
+    try:
+        for mb in (1, 8):
+            np.testing.assert_array_equal(_predict(c, max_batch=mb), single)
+    finally:
+        c.close()
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("mode", ["exact", "models"])
+def test_rccl_two_gpus_bit_identical(single, mode):
+    """One GPU per rank over RCCL / xGMI (the mode bench.py --shard tiles|models uses on a multi-GPU node)."""
+    if _n_gpus() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    got = _run(2, mode, backend="nccl")
+    np.testing.assert_array_equal(got[0], single)
+    np.testing.assert_array_equal(got[1], single)
 
 
 def test_allreduce_mode_flips_only_near_ties(single):
