@@ -53,6 +53,7 @@ _PROTOS = {
     "boa_prof_get": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                            C.POINTER(C.c_double)]),
     "boa_debug_counter": (C.c_longlong, [vp, i32, i32]),
+    "boa_net_debug_activation": (i32, [vp, i32, i32, i32, i32, vp, ip, ip]),
     "boa_head_tile": (i32, [vp, vp, vp, i32, ip, i32, vp, vp, f32, vp, vp, vp, vp, ip, ip]),
     "boa_ct_normalize": (i32, [vp, vp, i32, vp, u64, f32, f32, f32, f32]),
     "boa_accumulate_tile": (i32, [vp, vp, vp, vp, vp, i32, ip, ip, ip]),

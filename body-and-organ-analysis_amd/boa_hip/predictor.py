@@ -26,7 +26,7 @@ from .plans import NetGeometry
 
 class HipPredictor:
     def __init__(self, ctx: Context, geometry: NetGeometry, tile_step_size: float = 0.5, use_gaussian: bool = True,
-                 use_mirroring: bool = False, max_batch: int = 4, verbose: bool = False):
+                 use_mirroring: bool = False, max_batch: int = 4, verbose: bool = False, precision: Optional[str] = None):
         if use_mirroring:
             # BOA runs every model with tta=False / *NoMirroring trainers (TS/python_api.py:753)
             raise NotImplementedError("test-time mirroring is not used by BOA and is not implemented on device")
@@ -37,6 +37,14 @@ class HipPredictor:
         self.use_gaussian = use_gaussian
         self.verbose = verbose
         self.max_batch = int(max_batch)
+        # "fp16" (default): fp16 weights / activations on the f16 matrix cores, fp32 accumulation = what the reference's CUDA
+        # path computes under autocast (predict_from_raw_data.py:648); "fp32": the exact mode = what its CPU path computes.
+        # $BOA_NET_PRECISION selects it for code that does not pass the argument (the compute/ drop-in surface).
+        import os
+        precision = precision or os.environ.get("BOA_NET_PRECISION", "fp16")
+        if precision not in ("fp16", "fp32"):
+            raise ValueError(f"precision must be 'fp16' or 'fp32', got {precision!r}")
+        self.precision = precision
         self.list_of_parameters: List[np.ndarray] = []
         self._desc = geometry.to_desc()
         self._net = None
@@ -63,7 +71,7 @@ class HipPredictor:
         if self._net is None:
             h = C.c_void_p()
             check(self.lib.boa_net_create(self.ctx.h, C.byref(self._desc), w.ctypes.data_as(C.c_void_p), w.size,
-                                          self.max_batch, 0, C.byref(h)), "boa_net_create")
+                                          self.max_batch, 1 if self.precision == "fp32" else 0, C.byref(h)), "boa_net_create")
             self._net = h
             self._loaded_fold = fold
         elif self._loaded_fold != fold:

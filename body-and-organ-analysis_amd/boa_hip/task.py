@@ -72,7 +72,7 @@ class SegmentationTask:
 
     def __init__(self, ctx: Context, task_name: str, models: Sequence[Tuple[int, ModelConfig, Sequence[np.ndarray]]],
                  resample: Optional[float] = None, resample_only_thickness: bool = False, multimodel: Optional[bool] = None,
-                 max_batch: int = 8, part_luts: Optional[Dict[int, np.ndarray]] = None):
+                 max_batch: int = 8, part_luts: Optional[Dict[int, np.ndarray]] = None, precision: Optional[str] = None):
         self.ctx = ctx
         self.task_name = task_name
         self.resample = None if resample is None else float(resample)
@@ -86,7 +86,7 @@ class SegmentationTask:
                 raise ValueError(f"Dataset{task_id}: only CTNormalization is supported on device")
             if list(cfg.transpose_forward) != [0, 1, 2]:
                 raise NotImplementedError("plans with a non-identity transpose_forward")
-            p = HipPredictor(ctx, cfg.geometry, tile_step_size=self.step_size, max_batch=max_batch)
+            p = HipPredictor(ctx, cfg.geometry, tile_step_size=self.step_size, max_batch=max_batch, precision=precision)
             p.set_parameters(list(blobs))
             if self.multimodel:
                 lut = part_luts[task_id] if part_luts is not None else label_maps.part_lut(task_id)

@@ -113,6 +113,22 @@ __device__ __forceinline__ uint4 norm_act8(uint4 raw, const float* sc, const flo
 
 int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double flops, double bytes);
 
+// ---- fp32 "exact" mode (net_f32.hip): channels-last fp32 activations, weights [tap][Cin][Cout] fp32 -------------------
+int launch_conv_f32(boa_ctx* ctx, const float* src0, const float* ss0, int C0, const float* src1, const float* ss1, int C1, int N,
+                    const int din[3], const int dout[3], const int k[3], const int s[3], int Cout, const float* w,
+                    const float* bias, float slope, float* out);
+int launch_convt_f32(boa_ctx* ctx, const float* src, const float* ss, int Cin, int N, const int din[3], const int s[3], int Cout,
+                     const float* w, const float* bias, float slope, float* out);
+int launch_stats_f32(boa_ctx* ctx, const float* act, int N, size_t vox, int C, const float* gamma, const float* beta, float eps,
+                     float* ss_out);
+int launch_gather_tiles_f32(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins, int N,
+                            int Cin, const int P[3], float* out);
+int launch_head_f32(boa_ctx* ctx, const float* act, const float* ss, int F0, const int P[3], int C, const float* w,
+                    const float* bias, float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc, uint16_t* nacc,
+                    const int PV[3], const int start[3]);
+
+int launch_ndhwc32_to_nchw_f32(boa_ctx* ctx, const float* in, const float* ss, float slope, int C, size_t vox, float* out);
+
 // layout helpers (tests / debug)
 int launch_nchw_to_ndhwc_f16(boa_ctx* ctx, const float* in, int N, int C, size_t vox, __half* out);
 int launch_ndhwc_to_nchw_f32(boa_ctx* ctx, const __half* in, const float* ss, float slope, int N, int C, size_t vox,

@@ -21,6 +21,8 @@ struct ConvLayer {
     bool first = false;      // stage-0 conv-0: fp32 VALU kernel reading the volume
     __half* wpk = nullptr;   // MFMA layers
     float* wfirst = nullptr; // first layer [Cin][taps][Cout]
+    float* w32 = nullptr;    // fp32 mode: [taps][Cin][Cout]
+    float* out32 = nullptr;  // fp32 mode: raw conv output [N][vox][Cout]
     float *bias = nullptr, *gamma = nullptr, *beta = nullptr;
     __half* out = nullptr;
     float* partials = nullptr;
@@ -35,8 +37,10 @@ struct UpLayer {
     int s[3] = {1, 1, 1};
     int din[3] = {0, 0, 0};
     __half* wpk = nullptr;
+    float* w32 = nullptr;    // fp32 mode: [taps][Cin][Cout]
     float* bias = nullptr;
     __half* out = nullptr;
+    float* out32 = nullptr;  // fp32 mode
 };
 
 }  // namespace
@@ -45,6 +49,8 @@ struct boa_net {
     boa_ctx* ctx = nullptr;
     boa_net_desc d{};
     int maxN = 1;
+    int precision = 0;         // 0: fp16 storage + f16 MFMA (production); 1: fp32 "exact" mode (net_f32.hip)
+    float* tiles32 = nullptr;  // fp32 mode: gathered input tiles [N][P][Cin]
     std::vector<std::vector<ConvLayer>> enc;  // [stage][conv]
     std::vector<UpLayer> up;                  // decoder order (deepest first)
     std::vector<std::vector<ConvLayer>> dec;  // [d][conv]
@@ -127,6 +133,13 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
     L.g.Do = dout[0]; L.g.Ho = dout[1]; L.g.Wo = dout[2];
     const int taps = k[0] * k[1] * k[2];
     L.w_elems = (size_t)cout * (cin0 + cin1) * taps;
+    if (net->precision == 1) {
+        BOA_REQUIRE(cout % 32 == 0, "conv %d+%d -> %d: Cout must be a multiple of 32", cin0, cin1, cout);
+        size_t vox32 = (size_t)dout[0] * dout[1] * dout[2];
+        BOA_TRY(net_alloc(net, (size_t)N * vox32 * cout * sizeof(float), (void**)&L.out32));
+        BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * sizeof(float), (void**)&L.ss));
+        return BOA_OK;
+    }
     if (first) {
         BOA_REQUIRE(s[0] == 1 && s[1] == 1 && s[2] == 1, "first conv must have stride 1");
         L.nblk = conv_first_nblk(dout, net->ctx->cu_count);
@@ -155,6 +168,9 @@ template <typename F>
 static void for_each_weight_piece(boa_net* net, F&& f) {
     auto conv = [&](ConvLayer& L) {
         const int cin = L.Cin0 + L.Cin1, cout = L.g.Cout;
+        if (net->precision == 1)
+            f(9, &L, nullptr, L.w_elems * sizeof(float));
+        else
         f(L.first ? 0 : 1, &L, nullptr, L.first ? L.w_elems * sizeof(float) : conv_wpk_halves(cin, cout, L.g.k) * sizeof(__half));
         f(2, &L, nullptr, cout * sizeof(float));  // bias
         f(3, &L, nullptr, cout * sizeof(float));  // gamma
@@ -164,7 +180,10 @@ static void for_each_weight_piece(boa_net* net, F&& f) {
         for (auto& L : st) conv(L);
     for (size_t k = 0; k < net->up.size(); ++k) {
         UpLayer& U = net->up[k];
-        f(5, nullptr, &U, convt_wpk_halves(U.Cin, U.Cout, U.s) * sizeof(__half));
+        if (net->precision == 1)
+            f(10, nullptr, &U, (size_t)U.Cin * U.Cout * U.s[0] * U.s[1] * U.s[2] * sizeof(float));
+        else
+            f(5, nullptr, &U, convt_wpk_halves(U.Cin, U.Cout, U.s) * sizeof(__half));
         f(6, nullptr, &U, U.Cout * sizeof(float));
         for (auto& L : net->dec[k]) conv(L);
     }
@@ -185,6 +204,8 @@ static void point_layers_at(boa_net* net, unsigned char* arena) {
             case 5: U->wpk = (__half*)p; break;
             case 6: U->bias = (float*)p; break;
             case 7: net->head_w = (float*)p; break;
+            case 9: L->w32 = (float*)p; break;
+            case 10: U->w32 = (float*)p; break;
             default: net->head_b = (float*)p; break;
         }
         off += align256(bytes);
@@ -237,6 +258,24 @@ extern "C" int boa_net_load_weights(boa_net* net, const float* w, size_t n_float
                 pack_convt_weights(p, U->Cin, U->Cout, U->s, (__half*)dst);
                 p += (size_t)U->Cin * U->Cout * U->s[0] * U->s[1] * U->s[2];
                 break;
+            case 9: {  // fp32 mode conv: [cout][cin][taps] -> [tap][cin][cout]
+                const int cin = L->Cin0 + L->Cin1, cout = L->g.Cout, taps = L->g.k[0] * L->g.k[1] * L->g.k[2];
+                float* wf = (float*)dst;
+                for (int co = 0; co < cout; ++co)
+                    for (int ci = 0; ci < cin; ++ci)
+                        for (int t = 0; t < taps; ++t) wf[((size_t)t * cin + ci) * cout + co] = p[((size_t)co * cin + ci) * taps + t];
+                p += L->w_elems;
+                break;
+            }
+            case 10: {  // fp32 mode convT: [cin][cout][taps] -> [tap][cin][cout]
+                const int taps = U->s[0] * U->s[1] * U->s[2];
+                float* wf = (float*)dst;
+                for (int ci = 0; ci < U->Cin; ++ci)
+                    for (int co = 0; co < U->Cout; ++co)
+                        for (int t = 0; t < taps; ++t) wf[((size_t)t * U->Cin + ci) * U->Cout + co] = p[((size_t)ci * U->Cout + co) * taps + t];
+                p += (size_t)U->Cin * U->Cout * taps;
+                break;
+            }
             default:  // fp32 vectors / head matrix, copied as they are
                 memcpy(dst, p, bytes);
                 p += bytes / sizeof(float);
@@ -273,7 +312,8 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
                               int max_batch, int precision, boa_net** out) {
     BOA_REQUIRE(ctx && desc && out, "boa_net_create: NULL argument");
     BOA_REQUIRE(desc_ok(desc), "boa_net_create: invalid network geometry");
-    BOA_REQUIRE(precision == 0, "boa_net_create: precision %d not supported (0 = f16 MFMA / fp32 accumulate)", precision);
+    BOA_REQUIRE(precision == 0 || precision == 1,
+                "boa_net_create: precision %d not supported (0 = f16 MFMA / fp32 accumulate, 1 = fp32 exact mode)", precision);
     BOA_REQUIRE(max_batch >= 1 && max_batch <= 64, "boa_net_create: max_batch %d out of range", max_batch);
     BOA_HIP_TRY(hipSetDevice(ctx->device));
     boa_net* net = new boa_net();
@@ -282,6 +322,7 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
     if (net->d.norm_eps <= 0.f) net->d.norm_eps = 1e-5f;
     if (net->d.lrelu_slope == 0.f) net->d.lrelu_slope = 0.01f;
     net->maxN = max_batch;
+    net->precision = precision;
     const boa_net_desc& d = net->d;
     int rc = BOA_OK;
     auto fail = [&](int r) {
@@ -325,12 +366,15 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
                               dup[a], net->dims[sb - 1][a]);
                 return fail(BOA_EINVAL);
             }
-        if (U.Cin % 16 || U.Cout % 32) {
+        if ((precision == 0 && U.Cin % 16) || U.Cout % 32) {
             boa_set_error("transposed conv %d -> %d: unsupported channel counts", U.Cin, U.Cout);
             return fail(BOA_EINVAL);
         }
         size_t vox = (size_t)dup[0] * dup[1] * dup[2];
-        if ((rc = net_alloc(net, (size_t)max_batch * vox * U.Cout * sizeof(__half), (void**)&U.out))) return fail(rc);
+        if (precision == 1) {
+            if ((rc = net_alloc(net, (size_t)max_batch * vox * U.Cout * sizeof(float), (void**)&U.out32))) return fail(rc);
+        } else if ((rc = net_alloc(net, (size_t)max_batch * vox * U.Cout * sizeof(__half), (void**)&U.out)))
+            return fail(rc);
         net->dec[k].resize(d.n_conv_dec[k]);
         int one[3] = {1, 1, 1};
         for (int i = 0; i < d.n_conv_dec[k]; ++i) {
@@ -340,7 +384,11 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
         }
     }
     if ((rc = net_alloc(net, (size_t)max_batch * 3 * sizeof(int), (void**)&net->dev_origins))) return fail(rc);
-    {
+    if (precision == 1) {
+        if ((rc = net_alloc(net, (size_t)max_batch * d.in_channels * d.patch[0] * d.patch[1] * d.patch[2] * sizeof(float),
+                            (void**)&net->tiles32)))
+            return fail(rc);
+    } else {
         int PD[3];
         conv_first_padded_dims(d.patch, d.kernel[0], PD);
         if ((rc = net_alloc(net, (size_t)max_batch * d.in_channels * PD[0] * PD[1] * PD[2] * sizeof(float),
@@ -355,9 +403,74 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
     return BOA_OK;
 }
 
+// fp32 mode: the same layer sequence through net_f32.hip; leaves the last decoder activation in dec.back().back().out32
+static int net_forward_stack_f32(boa_net* net, const float* volume, const int V[3], const int vol_off[3],
+                                 const int* host_origins, int N) {
+    boa_ctx* c = net->ctx;
+    const boa_net_desc& d = net->d;
+    BOA_REQUIRE(N >= 1 && N <= net->maxN, "forward: batch %d exceeds max_batch %d", N, net->maxN);
+    BOA_HIP_TRY(hipMemcpyAsync(net->dev_origins, host_origins, (size_t)N * 3 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->prof_break = true;
+    BOA_TRY(launch_gather_tiles_f32(c, volume, V, vol_off, net->dev_origins, N, d.in_channels, d.patch, net->tiles32));
+    struct Src {
+        const float* data = nullptr;
+        const float* ss = nullptr;
+        int C = 0;
+    };
+    auto run_conv = [&](ConvLayer& L, const Src& a, const Src& b) -> int {
+        const int din[3] = {L.g.Di, L.g.Hi, L.g.Wi}, dout[3] = {L.g.Do, L.g.Ho, L.g.Wo};
+        BOA_TRY(launch_conv_f32(c, a.data, a.ss, a.C, b.data, b.ss, b.C, N, din, dout, L.g.k, L.g.s, L.g.Cout, L.w32, L.bias,
+                                d.lrelu_slope, L.out32));
+        return launch_stats_f32(c, L.out32, N, (size_t)dout[0] * dout[1] * dout[2], L.g.Cout, L.gamma, L.beta, d.norm_eps, L.ss);
+    };
+    Src cur, none;
+    cur.data = net->tiles32;
+    cur.C = d.in_channels;
+    for (int s = 0; s < d.n_stages; ++s)
+        for (size_t i = 0; i < net->enc[s].size(); ++i) {
+            ConvLayer& L = net->enc[s][i];
+            BOA_TRY(run_conv(L, cur, none));
+            cur.data = L.out32; cur.ss = L.ss; cur.C = L.g.Cout;
+        }
+    for (int k = 0; k < d.n_stages - 1; ++k) {
+        int sb = d.n_stages - 1 - k;
+        UpLayer& U = net->up[k];
+        BOA_TRY(launch_convt_f32(c, cur.data, cur.ss, U.Cin, N, U.din, U.s, U.Cout, U.w32, U.bias, d.lrelu_slope, U.out32));
+        ConvLayer& SK = net->enc[sb - 1].back();
+        Src upsrc, skip;
+        upsrc.data = U.out32; upsrc.C = U.Cout;
+        skip.data = SK.out32; skip.ss = SK.ss; skip.C = SK.g.Cout;
+        for (size_t i = 0; i < net->dec[k].size(); ++i) {
+            ConvLayer& L = net->dec[k][i];
+            if (i == 0)
+                BOA_TRY(run_conv(L, upsrc, skip));
+            else
+                BOA_TRY(run_conv(L, cur, none));
+            cur.data = L.out32; cur.ss = L.ss; cur.C = L.g.Cout;
+        }
+    }
+    return BOA_OK;
+}
+
+// head of tile i of the current batch (either precision)
+static int net_head(boa_net* net, int i, const int P[3], int plane_skip, float* logits_out, const uint16_t* gauss, uint16_t* acc,
+                    uint16_t* nacc, const int PV[3], const int start[3]) {
+    const boa_net_desc& d = net->d;
+    ConvLayer& last = net->dec.back().back();
+    const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2];
+    const size_t skip = (size_t)plane_skip * d.patch[1] * d.patch[2] * d.features[0];
+    const float* ss = last.ss + (size_t)i * d.features[0] * 2;
+    if (net->precision == 1)
+        return launch_head_f32(net->ctx, last.out32 + (size_t)i * pv * d.features[0] + skip, ss, d.features[0], P, d.num_classes,
+                               net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc, PV, start);
+    return launch_head(net->ctx, last.out + (size_t)i * pv * d.features[0] + skip, ss, d.features[0], P, d.num_classes, net->head_w,
+                       net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc, PV, start);
+}
+
 // run the conv stack for N tiles; leaves the last decoder activation (+ its ss) in net->dec.back().back()
 static int net_forward_stack(boa_net* net, const float* volume, const int V[3], const int vol_off[3],
                              const int* host_origins, int N) {
+    if (net->precision == 1) return net_forward_stack_f32(net, volume, V, vol_off, host_origins, N);
     boa_ctx* c = net->ctx;
     const boa_net_desc& d = net->d;
     BOA_REQUIRE(N >= 1 && N <= net->maxN, "forward: batch %d exceeds max_batch %d", N, net->maxN);
@@ -446,13 +559,9 @@ extern "C" int boa_net_forward(boa_net* net, const float* dev_volume, const int 
     for (int t0 = 0; t0 < n_tiles; t0 += net->maxN) {
         int nb = std::min(net->maxN, n_tiles - t0);
         BOA_TRY(net_forward_stack(net, dev_volume, V, zero, host_origins + (size_t)t0 * 3, nb));
-        ConvLayer& last = net->dec.back().back();
-        for (int i = 0; i < nb; ++i) {
-            BOA_TRY(launch_head(net->ctx, last.out + (size_t)i * pv * d.features[0], last.ss + (size_t)i * d.features[0] * 2,
-                                d.features[0], d.patch, d.num_classes, net->head_w, net->head_b, d.lrelu_slope,
-                                dev_logits_out + (size_t)(t0 + i) * d.num_classes * pv, nullptr, nullptr, nullptr,
-                                nullptr, nullptr));
-        }
+        for (int i = 0; i < nb; ++i)
+            BOA_TRY(net_head(net, i, d.patch, 0, dev_logits_out + (size_t)(t0 + i) * d.num_classes * pv, nullptr, nullptr, nullptr,
+                             nullptr, nullptr));
     }
     return BOA_OK;
 }
@@ -473,12 +582,9 @@ extern "C" int boa_net_predict_sliding_window(boa_net* net, const float* dev_vol
     for (int t0 = 0; t0 < n_tiles; t0 += net->maxN) {
         int nb = std::min(net->maxN, n_tiles - t0);
         BOA_TRY(net_forward_stack(net, dev_volume, V, off, host_origins + (size_t)t0 * 3, nb));
-        ConvLayer& last = net->dec.back().back();
         for (int i = 0; i < nb; ++i) {  // canonical order: one launch per tile, serialised on the stream
             const int* st = host_origins + (size_t)(t0 + i) * 3;
-            BOA_TRY(launch_head(net->ctx, last.out + (size_t)i * pv * d.features[0], last.ss + (size_t)i * d.features[0] * 2,
-                                d.features[0], d.patch, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr,
-                                dev_gauss, dev_acc, dev_n, PV, st));
+            BOA_TRY(net_head(net, i, d.patch, 0, nullptr, dev_gauss, dev_acc, dev_n, PV, st));
         }
     }
     return BOA_OK;
@@ -514,6 +620,7 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
     BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_acc && dev_n && host_defer_planes && stash_out,
                 "boa_net_predict_sliding_window_deferred: NULL argument");
     const boa_net_desc& d = net->d;
+    BOA_REQUIRE(net->precision == 0, "deferred sliding window (tile sharding) is not available in the fp32 exact mode");
     const int zero[3] = {0, 0, 0};
     const int* off = vol_off ? vol_off : zero;
     for (int a = 0; a < 3; ++a)
@@ -651,6 +758,41 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     boa_free(ctx, in16); boa_free(ctx, out16); boa_free(ctx, wpk); boa_free(ctx, bias); boa_free(ctx, gamma);
     boa_free(ctx, beta); boa_free(ctx, partials); boa_free(ctx, ss);
     return rc;
+}
+
+extern "C" int boa_net_debug_activation(boa_net* net, int kind, int stage, int conv, int tile, float* dev_out, int* channels_out,
+                                        int dims_out[3]) {
+    BOA_REQUIRE(net && channels_out && dims_out, "boa_net_debug_activation: NULL argument");
+    BOA_REQUIRE(tile >= 0 && tile < net->maxN, "boa_net_debug_activation: tile %d outside the batch", tile);
+    const float* ss = nullptr;
+    const __half* a16 = nullptr;
+    const float* a32 = nullptr;
+    int Cc = 0, dm[3] = {0, 0, 0};
+    if (kind == 1) {
+        BOA_REQUIRE(stage >= 0 && stage < (int)net->up.size(), "boa_net_debug_activation: no transposed conv %d", stage);
+        const UpLayer& U = net->up[stage];
+        Cc = U.Cout;
+        for (int a = 0; a < 3; ++a) dm[a] = U.din[a] * U.s[a];
+        a16 = U.out;
+        a32 = U.out32;
+    } else {
+        auto& stages = kind == 0 ? net->enc : net->dec;
+        BOA_REQUIRE((kind == 0 || kind == 2) && stage >= 0 && stage < (int)stages.size() && conv >= 0 && conv < (int)stages[stage].size(),
+                    "boa_net_debug_activation: no layer (kind %d, stage %d, conv %d)", kind, stage, conv);
+        const ConvLayer& L = stages[stage][conv];
+        Cc = L.g.Cout;
+        dm[0] = L.g.Do; dm[1] = L.g.Ho; dm[2] = L.g.Wo;
+        a16 = L.out;
+        a32 = L.out32;
+        ss = L.ss + (size_t)tile * Cc * 2;
+    }
+    *channels_out = Cc;
+    for (int a = 0; a < 3; ++a) dims_out[a] = dm[a];
+    if (!dev_out) return BOA_OK;  // size query
+    const size_t vox = (size_t)dm[0] * dm[1] * dm[2];
+    if (net->precision == 1)
+        return launch_ndhwc32_to_nchw_f32(net->ctx, a32 + (size_t)tile * vox * Cc, ss, net->d.lrelu_slope, Cc, vox, dev_out);
+    return launch_ndhwc_to_nchw_f32(net->ctx, a16 + (size_t)tile * vox * Cc, ss, net->d.lrelu_slope, 1, Cc, vox, dev_out);
 }
 
 extern "C" int boa_head_tile(boa_ctx* ctx, const uint16_t* dev_act, const float* dev_ss, int F0, const int P[3], int C,

@@ -149,7 +149,10 @@ typedef struct {
  *   for each decoder stage d (deepest first): Wt[Cin][Cout][s0][s1][s2], bt[Cout], then for conv i: W, b, gamma, beta
  *   head: W[num_classes][features[0]], b[num_classes]
  * (state-dict keys encoder.stages.S.0.convs.I.{conv,norm}.*, decoder.transpconvs.D.*, decoder.stages.D.convs.I.*,
- *  decoder.seg_layers.<last>.*).  precision: 0 = fp16 storage + f16 MFMA / fp32 accumulate. */
+ *  decoder.seg_layers.<last>.*).
+ * precision: 0 = fp16 weights / activations on the f16 matrix cores with fp32 accumulation (production; what the reference's
+ * CUDA path computes under autocast, predict_from_raw_data.py:648); 1 = fp32 "exact" mode: fp32 weights, activations and
+ * accumulation (v_mfma_f32_32x32x2_f32) = what the reference's CPU path computes; a correctness mode, ~30x slower. */
 int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const float* host_weights, size_t n_floats,
                    int max_batch, int precision, boa_net** out);
 void boa_net_destroy(boa_net* net);
@@ -200,6 +203,14 @@ int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int Cin, const
                         const float* host_w, const float* host_b, const float* host_gamma, const float* host_beta,
                         int Cout, const int kernel[3], const int stride[3], int with_norm_act, int impl,
                         float* dev_out); /* impl must be 0 */
+/* Debug seam for the per-layer error report (fp16 production mode against the fp32 exact mode, tools/layer_error.py): the
+ * activation a layer left behind for `tile` of the LAST batch that went through the conv stack, as fp32 [C][D][H][W] with the
+ * layer's InstanceNorm + LeakyReLU applied (i.e. what the next layer consumes; transposed convs have no norm: raw output).
+ * kind 0 = encoder conv (stage, conv), 1 = transposed conv (stage = decoder index, deepest first), 2 = decoder conv.
+ * dev_out == NULL only returns channels / dims. */
+int boa_net_debug_activation(boa_net* net, int kind, int stage, int conv, int tile, float* dev_out, int* channels_out,
+                             int dims_out[3]);
+
 /* Unit-test seam: the fused 1x1x1 head + Gaussian-weighted fp16 accumulation of ONE tile, launched exactly as the tile
  * loop of boa_net_predict_sliding_window launches it (same kernel selection: the MFMA head when F0 == 32, C <= 31,
  * P[2] % 32 == 0 and the z origin / extent are 8-voxel aligned, else the fp32 VALU head; boa_debug_counter tells which).

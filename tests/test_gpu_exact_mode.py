@@ -1,0 +1,147 @@
+"""fp32 "exact" network mode (boa_net_create precision = 1, HipPredictor(precision="fp32")): what the reference's CPU path
+computes (fp32 weights / activations / accumulation; autocast is CUDA-only, predict_from_raw_data.py:648), against the
+torch-CPU fp32 oracle.  SURVEY 8c: "end-to-end label mismatch fraction: target 0 in fp32-MFMA mode on fixtures".
+
+Two fp32 implementations of a 20-layer conv stack cannot agree bit for bit (the summation order inside a convolution
+differs between oneDNN and the MFMA K-loop), so the stated tolerances are: logits within 2e-4 of the logit range (measured
+~2e-5), label flips <= 1e-5 of the voxels (target and normally measured: 0).  The same tests print the flip fraction of the
+fp16 production mode against the exact mode, and bound it.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FP32_LOGIT_TOL = 2e-4      # of the logit range
+FP32_FLIP_TOL = 1e-5       # fraction of voxels
+FP16_FLIP_BOUND = 5e-3     # fp16 production mode vs exact mode, random-weight nets (measured 1-2e-3)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from boa_hip.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _small_net(patch=(32, 32, 32), features=(32, 64, 128), classes=5, seed=0, kernels=None, strides=None):
+    import torch
+    from boa_hip import plans
+    from oracle.network import build_from_arch
+    pj, dj = plans.synthetic_plans(patch=patch, features=features, num_classes=classes, kernels=kernels, strides=strides)
+    cfg = plans.model_config_from_plans(pj, dj)
+    sd = plans.synthetic_state_dict(cfg.geometry, seed)
+    blob = plans.weight_blob_from_state_dict(cfg.geometry, sd)
+    net = build_from_arch(pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"], 1, classes)
+    missing = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not missing.missing_keys, missing
+    return cfg.geometry, blob, net
+
+
+@pytest.mark.parametrize("patch,features,kernels,strides", [
+    ((32, 32, 32), (32, 64, 128), None, None),
+    ((16, 48, 40), (32, 64, 128, 256), [[1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
+     [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2]]),
+])
+def test_fp32_tile_forward_vs_oracle(ctx, patch, features, kernels, strides):
+    from boa_hip.predictor import HipPredictor
+    from oracle.network import network_fn_from_module
+    geom, blob, net = _small_net(patch, features, 5, 0, kernels, strides)
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal((1, patch[0] + 9, patch[1] + 5, patch[2] + 11)).astype(np.float32)
+    origins = np.array([[0, 0, 0], [9, 5, 11], [-3, 2, 7]], dtype=np.int32)     # the last one overhangs: pad_nd_image zeros
+    p32 = HipPredictor(ctx, geom, max_batch=2, precision="fp32")
+    p32.set_parameters([blob])
+    ctx.counters(reset=True)
+    got = p32.network_forward(vol, origins)
+    cnt = ctx.counters()
+    assert cnt["f32"] > 0 and cnt["conv_ws"] == 0 and cnt["head_mfma"] == 0, cnt      # only exact-mode kernels ran
+    p16 = HipPredictor(ctx, geom, max_batch=2, precision="fp16")
+    p16.set_parameters([blob])
+    got16 = p16.network_forward(vol, origins)
+    fn = network_fn_from_module(net, threads=8)
+    padded = np.pad(vol, ((0, 0), (3, 0), (0, 0), (0, 0)))
+    for i, o in enumerate(origins):
+        o = o + np.array([3, 0, 0])
+        ref = fn(padded[:, o[0]:o[0] + patch[0], o[1]:o[1] + patch[1], o[2]:o[2] + patch[2]][None])[0]
+        rng_ = float(ref.max() - ref.min())
+        err = float(np.abs(got[i] - ref).max())
+        flips = int((got[i].argmax(0) != ref.argmax(0)).sum())
+        flips16 = float((got16[i].argmax(0) != got[i].argmax(0)).mean())
+        print(f"tile {i}: fp32 mode max|err| {err:.3g} ({err / rng_:.2g} of the range), label flips {flips} of {ref[0].size}; "
+              f"fp16 mode vs exact mode: max|err| {np.abs(got16[i] - got[i]).max():.3g}, flip fraction {flips16:.2g}")
+        assert err <= FP32_LOGIT_TOL * rng_
+        assert flips <= max(1, FP32_FLIP_TOL * ref[0].size)
+        assert flips16 <= FP16_FLIP_BOUND
+    p32.close()
+    p16.close()
+
+
+def test_fp32_sliding_window_labels_vs_oracle(ctx):
+    """Whole sliding-window prediction in exact mode: fp16 accumulators, normalisation and argmax are bit-exact given the
+    logits, so the labels must match the oracle's (fp32 torch-CPU network through the reference's tile loop)."""
+    from boa_hip.predictor import HipPredictor
+    from oracle import sliding_window as osw
+    from oracle.network import network_fn_from_module
+    geom, blob, net = _small_net((32, 32, 32), (32, 64), 4, 1)
+    rng = np.random.default_rng(6)
+    for shape, step in [((40, 50, 45), 0.5), ((24, 40, 33), 0.8)]:
+        vol = rng.standard_normal((1, *shape)).astype(np.float32)
+        p = HipPredictor(ctx, geom, tile_step_size=step, max_batch=3, precision="fp32")
+        p.set_parameters([blob])
+        got = p.predict_sliding_window_return_logits(vol)
+        seg = p.predict_segmentation(vol)
+        p.close()
+        p16 = HipPredictor(ctx, geom, tile_step_size=step, max_batch=3)
+        p16.set_parameters([blob])
+        seg16 = p16.predict_segmentation(vol)
+        p16.close()
+        ref, nw, _ = osw.predict_sliding_window_return_logits(network_fn_from_module(net, 8), vol, list(geom.patch_size),
+                                                              geom.num_classes, step, return_aux=True)
+        ok = nw.astype(np.float32) >= 1e-3
+        g32, r32 = got.astype(np.float32), ref.astype(np.float32)
+        err = float(np.abs(g32 - r32)[:, ok].max())
+        rng_ = float(r32.max() - r32.min())
+        flips = int((seg != ref.argmax(0)).sum())
+        print(f"{shape} step {step}: exact mode fp16-logit max|err| {err:.3g} (range {rng_:.3g}), label flips {flips} of {seg.size}; "
+              f"fp16 mode flip fraction vs the oracle {float((seg16 != ref.argmax(0)).mean()):.2g}")
+        assert err <= 2e-3 * rng_          # one fp16 ulp of the accumulated logits (|logit| < 16 -> ulp 7.8e-3 .. 1.6e-2)
+        assert flips <= max(1, FP32_FLIP_TOL * seg.size)
+        assert float((seg16 != ref.argmax(0)).mean()) <= FP16_FLIP_BOUND
+        np.testing.assert_array_equal(seg, got.argmax(0).astype(np.uint8))
+
+
+def test_fp32_total_pipeline_labels_vs_oracle(ctx):
+    """Five part models, crop_to_nonzero, CTNormalization, step 0.8, argmax, part merge in exact mode against the oracle
+    pipeline: identical `total` label volume (<= 1e-5 flips)."""
+    import torch
+    from boa_hip import label_maps, plans, totalseg
+    from oracle import pipeline as opipe
+    from oracle.network import build_from_arch, network_fn_from_module
+    rng = np.random.default_rng(11)
+    ct = rng.normal(0, 300, size=(44, 40, 52)).astype(np.int16)
+    ct[ct == 0] = 1
+    ct[:3] = 0
+    ct[:, :, -5:] = 0
+    models, omodels = [], []
+    for tid, nc in zip(label_maps.PART_TASK_IDS, (25, 27, 19, 24, 27)):
+        pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc)
+        cfg = plans.model_config_from_plans(pj, dj)
+        sd = plans.synthetic_state_dict(cfg.geometry, seed=tid)
+        models.append((tid, cfg, [plans.weight_blob_from_state_dict(cfg.geometry, sd)]))
+        net = build_from_arch(pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"], 1, nc)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        omodels.append((network_fn_from_module(net, 8), (32, 32, 32), nc, cfg.intensity_properties["0"],
+                        label_maps.CLASS_MAP_PARTS[tid]))
+    want = opipe.predict_total(ct, omodels, label_maps.CLASS_MAP_TOTAL_INV, 0.8)
+    res = {}
+    for prec in ("fp32", "fp16"):
+        ts = totalseg.TotalSegmentatorHip(ctx, models, step_size=0.8, max_batch=4, precision=prec)
+        res[prec] = ts.predict(ct)
+        ts.close()
+    flips32 = int((res["fp32"] != want).sum())
+    flips16 = float((res["fp16"] != want).mean())
+    print(f"total pipeline: exact mode label flips {flips32} of {want.size}; fp16 mode flip fraction {flips16:.3g}")
+    assert flips32 <= max(1, FP32_FLIP_TOL * want.size)
+    assert flips16 <= FP16_FLIP_BOUND
