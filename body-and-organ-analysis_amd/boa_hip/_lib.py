@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libboa_hip.so")
+# $BOA_HIP_LIB: load another build of the same library (kernel experiments: tools/build_alt.sh)
+LIB_PATH = os.environ.get("BOA_HIP_LIB") or os.path.join(_HERE, "libboa_hip.so")
 
 BOA_OK, BOA_EINVAL, BOA_EHIP, BOA_ENOMEM, BOA_EINF = 0, -1, -2, -3, -4
 K_CONV_MFMA, K_CONV_FIRST, K_CONVT, K_NORM_FINALIZE, K_HEAD_ACCUM, K_ARGMAX, K_OTHER, K_COUNT = range(8)

@@ -51,6 +51,7 @@ extern "C" void boa_destroy(boa_ctx* c) {
     }
     for (auto& r : c->prof_pending) hipEventDestroy(r.ev);
     for (auto e : c->ev_pool) hipEventDestroy(e);
+    for (auto& r : c->ws_runs) hipFree(r.second);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -58,6 +58,9 @@ struct boa_ctx {
     double prof_flops[BOA_K_COUNT] = {};
     double prof_bytes[BOA_K_COUNT] = {};
     long long counters[BOA_CNT_COUNT] = {};  // launches per kernel variant (boa_debug_counter)
+    // k_conv_ws run tables (first tile + length of every virtual workgroup's run), one per distinct layer geometry,
+    // built on first use and kept for the life of the context: (key, device pointer)
+    std::vector<std::pair<std::vector<int>, void*>> ws_runs;
 };
 
 // RAII-less explicit bracket: KernelTimer t(ctx, klass, flops, bytes); <launch>; t.stop();

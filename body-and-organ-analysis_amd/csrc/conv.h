@@ -93,6 +93,8 @@ struct ConvArgs {
     int cy_fast;                // k_conv_ws: cout chunk is the fastest tile index (halo reuse, 2-chunk inputs)
     int nslots;                 // k_conv_ws: statistics slots per (n, cout) in `partials`
     int vw;                     // k_conv_ws: virtual workgroups per sample (<= nslots / 4)
+    int vstep_n, vstep_j;       // k_conv_ws: grid size as (samples, virtual workgroups) = (G / vw, G % vw)
+    const int* runs;            // k_conv_ws: [vw][8] = {count, cy, sp, ox0, oy0, oz0, -, -}: the run of virtual workgroup j
     unsigned long long* trace;  // debug (BOA_WS_TRACE): per-chunk s_memtime stamps of block 0, else nullptr
 };
 

@@ -30,6 +30,9 @@
 #define WS_THREADS 512  // 256 consumer threads (4 waves) + WS_PROD producer threads
 #endif
 #define WS_PROD (WS_THREADS - 256)
+#ifndef WS_DEFER_EPILOGUE
+#define WS_DEFER_EPILOGUE 1
+#endif
 #define WS_WB ((27 * 64 + WS_PROD - 1) / WS_PROD)  // weight items per producer thread (taps * 64 items, <= 27 taps)
 #define WS_TRACE_SLOTS 4096
 // timeline stamps (debug only): slot = event counter of the calling wave; wave 0 (consumer) and wave 4 (producer) of block 0
@@ -119,67 +122,45 @@ __device__ __forceinline__ void next_tile(const ConvArgs& p, TileCoord& c) {
 // virtual workgroups b, b + G, b + 2G, ... one after the other; which physical workgroup runs a virtual one only affects
 // speed.  Workgroup b is observed to run on XCD b % 8 (each XCD has a private 4 MiB L2): a sample's tile list is cut into 8
 // contiguous ranges, one per XCD (j % 8 == b % 8), and the virtual workgroups of an XCD take contiguous runs of that range,
-// so the halos an XCD re-reads are the ones its own L2 just fetched.
-struct TileWalk {
-    int first, count;  // a contiguous run of sample-local tile indices
-};
-
-__device__ __forceinline__ TileWalk tile_walk(int tiles_per_sample, int vw, int j) {
-    TileWalk w;
-    if (vw % 8 != 0) {
-        const int q = tiles_per_sample / vw, r = tiles_per_sample % vw;
-        w.first = j * q + min(j, r);
-        w.count = q + (j < r ? 1 : 0);
-        return w;
-    }
-    const int xcd = j & 7, slot = j >> 3, per = vw >> 3;  // per = virtual workgroups per XCD
-    const int q = tiles_per_sample / 8, rem = tiles_per_sample % 8;
-    const int lo = xcd * q + min(xcd, rem);
-    const int len = q + (xcd < rem ? 1 : 0);
-    // contiguous run per workgroup: consecutive tiles of a workgroup are neighbours along x (x-fastest tile order),
-    // so the x-halo planes a tile re-reads were fetched by the same CU one tile earlier; neighbouring workgroups of
-    // the XCD walk neighbouring lines
-    const int cq = len / per, cr = len % per;
-    w.first = lo + slot * cq + min(slot, cr);
-    w.count = cq + (slot < cr ? 1 : 0);
-    return w;
-}
-
-// virtual workgroup index v (global over the samples of the launch) -> (sample, j).  The rotation by the sample index
-// spreads the runs that are one tile longer over the physical workgroups (j % 8 is kept: XCD affinity).
-__device__ __forceinline__ void virt_decode(int v, int vw, int& n, int& j) {
-    n = v / vw;
-    j = v - n * vw;
-    if (vw % 8 == 0 && vw >= 16) {
-        const int per = vw >> 3;
-        j = (j + 8 * ((n * 5) % per)) % vw;
-    }
-}
-
+// so the halos an XCD re-reads are the ones its own L2 just fetched.  The runs (first tile's coordinates + length) are a
+// host-built table per layer geometry (`ws_run_table`): starting a run costs a few scalar loads, no divisions.
 struct TileSeq {
-    int v;     // current virtual workgroup
+    int n, j;  // current virtual workgroup: sample, index within the sample (statistics slot = 4 j + wave)
     int left;  // tiles left in its run, the current one included
-    int j;     // its index within the sample (statistics slot = 4 j + wave)
     TileCoord tc;
 };
 
-__device__ __forceinline__ void seq_run(const ConvArgs& p, int tiles_per_sample, int v, TileSeq& s) {
-    int n, j;
-    virt_decode(v, p.vw, n, j);
-    const TileWalk w = tile_walk(tiles_per_sample, p.vw, j);
-    s.v = v;
-    s.j = j;
-    s.left = w.count;
-    s.tc = decode_tile(p, n * tiles_per_sample + w.first);
+// position at the first tile of virtual workgroup (n, j): a table lookup (wave-uniform -> scalar loads), no divisions
+__device__ __forceinline__ void seq_run(const ConvArgs& p, TileSeq& s) {
+    const int* r = p.runs + s.j * 8;
+    s.left = r[0];
+    s.tc.n = s.n;
+    s.tc.cy = r[1];
+    s.tc.sp = r[2];
+    s.tc.ox0 = r[3];
+    s.tc.oy0 = r[4];
+    s.tc.oz0 = r[5];
+}
+
+__device__ __forceinline__ void seq_first(const ConvArgs& p, TileSeq& s) {
+    s.n = (int)blockIdx.x / p.vw;
+    s.j = (int)blockIdx.x - s.n * p.vw;
+    seq_run(p, s);
 }
 
 // next tile of this workgroup's sequence; true when it is the first tile of a new virtual workgroup
-__device__ __forceinline__ bool seq_next(const ConvArgs& p, int tiles_per_sample, TileSeq& s) {
+__device__ __forceinline__ bool seq_next(const ConvArgs& p, TileSeq& s) {
     if (--s.left > 0) {
         next_tile(p, s.tc);
         return false;
     }
-    seq_run(p, tiles_per_sample, s.v + (int)gridDim.x, s);
+    s.n += p.vstep_n;  // virtual workgroup v + G
+    s.j += p.vstep_j;
+    if (s.j >= p.vw) {
+        s.j -= p.vw;
+        ++s.n;
+    }
+    seq_run(p, s);
     return true;
 }
 
@@ -195,11 +176,14 @@ struct ProdConst {
     int rel[WS_MAXV];  // input voxel index of halo voxel j relative to the tile's halo origin
     int hc[WS_MAXV];   // packed halo coordinates hx | hy << 10 | hz << 20
     unsigned in_halo;  // bit j: v < HV
+    unsigned face[6];  // bit j: halo voxel j lies on the halo's face x = 0, x = h0 - 1, y = 0, y = h1 - 1, z = 0, z = h2 - 1
 };
 
 __device__ __forceinline__ ProdConst prod_const(const ConvArgs& p, int q, int HV) {
     ProdConst k;
     k.in_halo = 0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) k.face[f] = 0;
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
         const int v = (q >> 1) + (WS_PROD / 2) * j;
@@ -208,7 +192,14 @@ __device__ __forceinline__ ProdConst prod_const(const ConvArgs& p, int q, int HV
         const bool in = v < HV;
         k.rel[j] = in ? (hx * p.Hi + hy) * p.Wi + hz : 0;
         k.hc[j] = in ? (hx | (hy << 10) | (hz << 20)) : 0;
-        k.in_halo |= in ? (1u << j) : 0u;
+        const unsigned bit = in ? (1u << j) : 0u;
+        k.in_halo |= bit;
+        k.face[0] |= hx == 0 ? bit : 0u;
+        k.face[1] |= hx == p.h0 - 1 ? bit : 0u;
+        k.face[2] |= hy == 0 ? bit : 0u;
+        k.face[3] |= hy == p.h1 - 1 ? bit : 0u;
+        k.face[4] |= hz == 0 ? bit : 0u;
+        k.face[5] |= hz == p.h2 - 1 ? bit : 0u;
     }
     return k;
 }
@@ -226,6 +217,21 @@ __device__ __forceinline__ void prod_setup(const ConvArgs& p, const TileCoord& t
         it.ok = k.in_halo;
 #pragma unroll
         for (int j = 0; j < WS_MAXV; ++j) it.gi[j] = base + k.rel[j];
+    } else if (ix0 >= -1 && iy0 >= -1 && iz0 >= -1 && ix0 + p.h0 <= p.Di + 1 && iy0 + p.h1 <= p.Hi + 1 && iz0 + p.h2 <= p.Wi + 1) {
+        // wave-uniform: the halo sticks out of the tensor by exactly one voxel layer on some sides (the conv padding of a
+        // tile at the tensor's border -- with 4 x 4 x 32 tiles on 128^3 more than half of all tiles): the voxels outside are
+        // whole faces of the halo, whose per-lane item masks are kernel constants.  ~35 instructions instead of ~165.
+        unsigned out = 0;
+        out |= ix0 < 0 ? k.face[0] : 0u;
+        out |= ix0 + p.h0 > p.Di ? k.face[1] : 0u;
+        out |= iy0 < 0 ? k.face[2] : 0u;
+        out |= iy0 + p.h1 > p.Hi ? k.face[3] : 0u;
+        out |= iz0 < 0 ? k.face[4] : 0u;
+        out |= iz0 + p.h2 > p.Wi ? k.face[5] : 0u;
+        const unsigned okm = k.in_halo & ~out;
+        it.ok = okm;
+#pragma unroll
+        for (int j = 0; j < WS_MAXV; ++j) it.gi[j] = ((okm >> j) & 1u) ? base + k.rel[j] : 0;
     } else {
         // straight-line (no short-circuit branches): unsigned compares fold the two-sided range checks
         unsigned okm = 0;
@@ -552,14 +558,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     const int buf_bytes = resident_w ? 2 * plane : 2 * plane + taps * 1024;
     unsigned char* bufs = smem + wres_bytes;
 
-    // this workgroup's tiles: the runs of the virtual workgroups b, b + G, ... (total_tiles = tiles per sample here)
-    const int tiles_per_sample = total_tiles;
+    // this workgroup's tiles: the runs of the virtual workgroups b, b + G, ...
     int my_tiles = 0;
-    for (int v = (int)blockIdx.x; v < p.N * p.vw; v += (int)gridDim.x) {
-        int n_, j_;
-        virt_decode(v, p.vw, n_, j_);
-        my_tiles += tile_walk(tiles_per_sample, p.vw, j_).count;
-    }
+    for (int v = (int)blockIdx.x; v < p.N * p.vw; v += (int)gridDim.x) my_tiles += p.runs[(v % p.vw) * 8];
     const int my_chunks = my_tiles * ncc;
 
     if (resident_w) {
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         if (dbg & 512) __builtin_amdgcn_s_setprio(3);
         const ProdConst pc = prod_const(p, q, HV);
         TileSeq pseq;
-        pseq.v = pseq.left = pseq.j = 0;
+        pseq.n = pseq.left = pseq.j = 0;
         TileCoord& ptc = pseq.tc;
         ptc.n = ptc.cy = ptc.ox0 = ptc.oy0 = ptc.oz0 = ptc.sp = 0;
         ProdItems items;
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         int w_cc = 0, w_cy = 0;  // (chunk, cout chunk) of the chunk issued last = the one committed next (its weights go by DMA)
         const bool live = !(dbg & 2);
         if (live && my_chunks > 0) {
-            seq_run(p, tiles_per_sample, (int)blockIdx.x, pseq);
+            seq_first(p, pseq);
             prod_setup(p, ptc, pc, items);
             prod_issue(p, ptc, items, pc.in_halo, 0, false, q, dbg, rg);
             w_cy = ptc.cy;
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 WS_STAMP(2);
                 if (g + 2 < my_chunks) {
                     if (pcc == 0) {
-                        const bool new_run = seq_next(p, tiles_per_sample, pseq);
+                        const bool new_run = seq_next(p, pseq);
                         reuse = p.cy_fast && ptc.cy != 0 && !new_run;  // same spatial tile as the previous tile of this run
                         if (!reuse) prod_setup(p, ptc, pc, items);
                         WS_STAMP(8);
@@ -691,22 +692,32 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     for (int i = 0; i < 16; ++i) stA.s[i] = stA.q[i] = stB.s[i] = stB.q[i] = 0.f;
     int st_n = -1, st_cy = 0;
     auto flush_set = [&](StatSet& st, int cy) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-#pragma unroll
-            for (int mm = 1; mm < 32; mm <<= 1) {  // the 32 lanes that share kh
-                st.s[i] += __shfl_xor(st.s[i], mm);
-                st.q[i] += __shfl_xor(st.q[i], mm);
-            }
-        }
-        if (l31 == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = cy * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
-                float* pp = p.partials + (((size_t)st_n * p.Cout + row) * 2) * nslots + slot;
-                pp[0] = st.s[i];
-                pp[nslots] = st.q[i];
-            }
+        // recursive halving over the 32 lanes that share kh: after step m a lane keeps half of its entries, summed with
+        // its partner's copy (8 + 4 + 2 + 1 shuffles per quantity instead of 5 x 16); entry index = bits 0..3 of the lane
+        // in reversed significance, the last step folds lanes 16-31 onto 0-15.  The order of the additions is fixed.
+#define WS_HALVE(M, HALF)                                                                                \
+    {                                                                                                    \
+        const bool up = (l31 & (M)) != 0;                                                                \
+        _Pragma("unroll") for (int i = 0; i < (HALF); ++i) {                                             \
+            const float ks = up ? st.s[i + (HALF)] : st.s[i], gs = up ? st.s[i] : st.s[i + (HALF)];      \
+            const float kq = up ? st.q[i + (HALF)] : st.q[i], gq = up ? st.q[i] : st.q[i + (HALF)];      \
+            st.s[i] = ks + __shfl_xor(gs, (M));                                                          \
+            st.q[i] = kq + __shfl_xor(gq, (M));                                                          \
+        }                                                                                                \
+    }
+        WS_HALVE(1, 8)
+        WS_HALVE(2, 4)
+        WS_HALVE(4, 2)
+        WS_HALVE(8, 1)
+#undef WS_HALVE
+        st.s[0] += __shfl_xor(st.s[0], 16);
+        st.q[0] += __shfl_xor(st.q[0], 16);
+        if (l31 < 16) {
+            const int i = ((l31 & 1) << 3) | ((l31 & 2) << 1) | ((l31 & 4) >> 1) | ((l31 & 8) >> 3);  // entry this lane ended up with
+            const int row = cy * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
+            float* pp = p.partials + (((size_t)st_n * p.Cout + row) * 2) * nslots + slot;
+            pp[0] = st.s[0];
+            pp[nslots] = st.q[0];
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) st.s[i] = st.q[i] = 0.f;
@@ -722,7 +733,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     };
 
     TileSeq cseq;
-    cseq.v = cseq.left = cseq.j = 0;
+    cseq.n = cseq.left = cseq.j = 0;
     TileCoord& tc = cseq.tc;
     tc.n = tc.cy = tc.ox0 = tc.oy0 = tc.oz0 = tc.sp = 0;
     if (p.trace && blockIdx.x == 0 && tid == 0) {
@@ -730,18 +741,122 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         p.trace[WS_TRACE_SLOTS - 3] = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();  // chunk 0 staged (pairs with the producers' g = -1 barrier)
-    for (int k = 0; k < my_tiles; ++k) {
+    // The epilogue of a tile (bias, statistics, transpose, stores: registers and global memory only, no LDS) is DEFERRED past
+    // the chunk barrier into the next tile's first interval (WS_DEFER_EPILOGUE): that interval is the producers' long one (they
+    // issue the HBM-cold loads of the tile after next), the interval of a tile's last chunk their short one, so the roles'
+    // long and short intervals now coincide instead of alternating in opposite phase.
+    f32x16 acc[R];
+    auto epilogue = [&](const TileCoord& tc) {
+        // ---- epilogue: + bias, InstanceNorm partial sums (fp32), register transpose (v_permlane32_swap), fp16
+        // convert, two 16-byte stores per lane (32 contiguous bytes of the voxel's record)
+        const bool two = TWO_SETS && p.cy_fast;
+        if (tc.n != st_n || (!two && tc.cy != st_cy)) {
+            flush_stats();
+            st_n = tc.n;
+            st_cy = tc.cy;
+        }
+        const int cout0 = tc.cy * 32;
+        const bool full = tc.ox0 + p.b0 * p.w0 <= p.Do && tc.oy0 + p.b1 * p.w1 <= p.Ho && tc.oz0 + p.b2 * p.w2 <= p.Wo;
+        // wave-uniform base + 32-bit lane offset (scalar-base global_store / global_load forms, see prod_issue)
+        const size_t obase = ((size_t)tc.n * out_vox + ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * p.Cout + cout0;
+        const unsigned olane = ((unsigned)srel0 * (unsigned)p.Cout + (unsigned)kh * 16u) * 2u;
+        // the tile's 16 bias values of this lane (4 independent loads, one wait)
+        float4 bq[4];
+        const WS_GLOBAL unsigned char* bbase = sgpr_ptr(p.bias + cout0);
+        unsigned bl = (unsigned)kh * 16u;
+        asm volatile("" : "+v"(bl));
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4_t bv = *(const WS_GLOBAL f32x4_t*)(bbase + bl + 32 * gq);
+            bq[gq] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int m = cw * R + r;  // wave-uniform M-tile origin within the block tile
+            const int mx = (m >> (p.lb2 + p.lb1)) * p.w0, my = ((m >> p.lb2) & (p.b1 - 1)) * p.w1, mz = (m & (p.b2 - 1)) * p.w2;
+            const int mrel = (mx * p.Ho + my) * p.Wo + mz;
+            bool ok = true;
+            if (!full) {  // wave-uniform: only tiles that stick out of the tensor mask statistics and stores
+                int x, y, z;
+                vox_rel(l31, x, y, z);
+                ok = tc.ox0 + mx + x < p.Do && tc.oy0 + my + y < p.Ho && tc.oz0 + mz + z < p.Wo;
+            }
+            const float dm = ok ? 1.f : 0.f;
+            float v[16];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                v[gq * 4 + 0] = acc[r][gq * 4 + 0] + bq[gq].x;
+                v[gq * 4 + 1] = acc[r][gq * 4 + 1] + bq[gq].y;
+                v[gq * 4 + 2] = acc[r][gq * 4 + 2] + bq[gq].z;
+                v[gq * 4 + 3] = acc[r][gq * 4 + 3] + bq[gq].w;
+            }
+            if (TWO_SETS && two && tc.cy != 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float vm = full ? v[i] : v[i] * dm;
+                    stB.s[i] += vm;
+                    stB.q[i] = __builtin_fmaf(vm, vm, stB.q[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float vm = full ? v[i] : v[i] * dm;
+                    stA.s[i] += vm;
+                    stA.q[i] = __builtin_fmaf(vm, vm, stA.q[i]);
+                }
+            }
+            // D fragment -> voxel records without LDS: v_permlane32_swap exchanges the upper half of one register
+            // with the lower half of another.  Lane (kh, voxel) holds couts 8 gq + 4 kh + e; swapping group gq with
+            // group gq + 2 leaves the kh = 0 lane with couts [0, 16) and the kh = 1 lane with couts [16, 32) of its
+            // voxel: 32 contiguous bytes each.
+            unsigned w[8];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {  // pr 0: groups (0, 2) -> couts 0-7 | 16-23; pr 1: groups (1, 3) -> 8-15 | 24-31
+                float lo4[4], hi4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[pr * 4 + e]), __float_as_uint(v[(pr + 2) * 4 + e]), false, false);
+                    lo4[e] = __uint_as_float(sw[0]);  // kh 0: cout 8 pr + e      | kh 1: cout 16 + 8 pr + e
+                    hi4[e] = __uint_as_float(sw[1]);  // kh 0: cout 8 pr + 4 + e  | kh 1: cout 16 + 8 pr + 4 + e
+                }
+                union {
+                    unsigned u;
+                    __half h[2];
+                } c;
+                c.h[0] = __float2half_rn(lo4[0]); c.h[1] = __float2half_rn(lo4[1]); w[pr * 4 + 0] = c.u;
+                c.h[0] = __float2half_rn(lo4[2]); c.h[1] = __float2half_rn(lo4[3]); w[pr * 4 + 1] = c.u;
+                c.h[0] = __float2half_rn(hi4[0]); c.h[1] = __float2half_rn(hi4[1]); w[pr * 4 + 2] = c.u;
+                c.h[0] = __float2half_rn(hi4[2]); c.h[1] = __float2half_rn(hi4[3]); w[pr * 4 + 3] = c.u;
+            }
+            if (ok && !(dbg & 4)) {
+                WS_GLOBAL unsigned char* dst = sgpr_ptr(p.out + (obase + (size_t)mrel * p.Cout));
+                unsigned ol = olane;
+                asm volatile("" : "+v"(ol));  // keep the 32 -> 64 bit extension in this block (instruction selection is per block)
+                *(WS_GLOBAL u32x4_t*)(dst + ol) = u32x4_t{w[0], w[1], w[2], w[3]};
+                *(WS_GLOBAL u32x4_t*)(dst + ol + 16) = u32x4_t{w[4], w[5], w[6], w[7]};
+            }
+        }
+    };
+    TileCoord done_tc;
+    done_tc.n = done_tc.cy = done_tc.ox0 = done_tc.oy0 = done_tc.oz0 = done_tc.sp = 0;
+    // (one extra iteration for the last tile's deferred epilogue: a single call site -- two inlined copies of the epilogue
+    //  made hipcc's backend fail with "illegal VGPR to SGPR copy")
+    for (int k = 0; k < my_tiles + WS_DEFER_EPILOGUE; ++k) {
         bool new_run = true;
+        const bool more = k < my_tiles;
         if (k == 0)
-            seq_run(p, tiles_per_sample, (int)blockIdx.x, cseq);
-        else
-            new_run = seq_next(p, tiles_per_sample, cseq);
+            seq_first(p, cseq);
+        else if (more)
+            new_run = seq_next(p, cseq);
+#if WS_DEFER_EPILOGUE
+        if (k > 0 && !(dbg & 8)) epilogue(done_tc);  // the previous tile's (its statistics belong to the previous run: before the flush)
+        if (!more) break;
+#endif
         if (new_run) {  // the partial sums of a virtual workgroup go to its own slot
             flush_stats();
             st_n = -1;
             slot = cseq.j * 4 + cw;
         }
-        f32x16 acc[R];
         for (int cc = 0; cc < ncc; ++cc) {
             const int g = k * ncc + cc;
             const unsigned char* cur = bufs + (g & 1) * buf_bytes;
@@ -765,100 +880,19 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             else
                 consume_chunk<R, K0, K1, K2, false>(bp, ap, p.h1, p.h2, acc);
             WS_STAMP(5);
-            if (cc == ncc - 1 && !(dbg & 8)) {
-                // ---- epilogue: + bias, InstanceNorm partial sums (fp32), register transpose (v_permlane32_swap), fp16
-                // convert, two 16-byte stores per lane (32 contiguous bytes of the voxel's record)
-                const bool two = TWO_SETS && p.cy_fast;
-                if (tc.n != st_n || (!two && tc.cy != st_cy)) {
-                    flush_stats();
-                    st_n = tc.n;
-                    st_cy = tc.cy;
-                }
-                const int cout0 = tc.cy * 32;
-                const bool full = tc.ox0 + p.b0 * p.w0 <= p.Do && tc.oy0 + p.b1 * p.w1 <= p.Ho && tc.oz0 + p.b2 * p.w2 <= p.Wo;
-                // wave-uniform base + 32-bit lane offset (scalar-base global_store / global_load forms, see prod_issue)
-                const size_t obase = ((size_t)tc.n * out_vox + ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * p.Cout + cout0;
-                const unsigned olane = ((unsigned)srel0 * (unsigned)p.Cout + (unsigned)kh * 16u) * 2u;
-                // the tile's 16 bias values of this lane (4 independent loads, one wait)
-                float4 bq[4];
-                const WS_GLOBAL unsigned char* bbase = sgpr_ptr(p.bias + cout0);
-                unsigned bl = (unsigned)kh * 16u;
-                asm volatile("" : "+v"(bl));
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4_t bv = *(const WS_GLOBAL f32x4_t*)(bbase + bl + 32 * gq);
-                    bq[gq] = make_float4(bv[0], bv[1], bv[2], bv[3]);
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int m = cw * R + r;  // wave-uniform M-tile origin within the block tile
-                    const int mx = (m >> (p.lb2 + p.lb1)) * p.w0, my = ((m >> p.lb2) & (p.b1 - 1)) * p.w1, mz = (m & (p.b2 - 1)) * p.w2;
-                    const int mrel = (mx * p.Ho + my) * p.Wo + mz;
-                    bool ok = true;
-                    if (!full) {  // wave-uniform: only tiles that stick out of the tensor mask statistics and stores
-                        int x, y, z;
-                        vox_rel(l31, x, y, z);
-                        ok = tc.ox0 + mx + x < p.Do && tc.oy0 + my + y < p.Ho && tc.oz0 + mz + z < p.Wo;
-                    }
-                    const float dm = ok ? 1.f : 0.f;
-                    float v[16];
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        v[gq * 4 + 0] = acc[r][gq * 4 + 0] + bq[gq].x;
-                        v[gq * 4 + 1] = acc[r][gq * 4 + 1] + bq[gq].y;
-                        v[gq * 4 + 2] = acc[r][gq * 4 + 2] + bq[gq].z;
-                        v[gq * 4 + 3] = acc[r][gq * 4 + 3] + bq[gq].w;
-                    }
-                    if (TWO_SETS && two && tc.cy != 0) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float vm = full ? v[i] : v[i] * dm;
-                            stB.s[i] += vm;
-                            stB.q[i] = __builtin_fmaf(vm, vm, stB.q[i]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float vm = full ? v[i] : v[i] * dm;
-                            stA.s[i] += vm;
-                            stA.q[i] = __builtin_fmaf(vm, vm, stA.q[i]);
-                        }
-                    }
-                    // D fragment -> voxel records without LDS: v_permlane32_swap exchanges the upper half of one register
-                    // with the lower half of another.  Lane (kh, voxel) holds couts 8 gq + 4 kh + e; swapping group gq with
-                    // group gq + 2 leaves the kh = 0 lane with couts [0, 16) and the kh = 1 lane with couts [16, 32) of its
-                    // voxel: 32 contiguous bytes each.
-                    unsigned w[8];
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {  // pr 0: groups (0, 2) -> couts 0-7 | 16-23; pr 1: groups (1, 3) -> 8-15 | 24-31
-                        float lo4[4], hi4[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[pr * 4 + e]), __float_as_uint(v[(pr + 2) * 4 + e]), false, false);
-                            lo4[e] = __uint_as_float(sw[0]);  // kh 0: cout 8 pr + e      | kh 1: cout 16 + 8 pr + e
-                            hi4[e] = __uint_as_float(sw[1]);  // kh 0: cout 8 pr + 4 + e  | kh 1: cout 16 + 8 pr + 4 + e
-                        }
-                        union {
-                            unsigned u;
-                            __half h[2];
-                        } c;
-                        c.h[0] = __float2half_rn(lo4[0]); c.h[1] = __float2half_rn(lo4[1]); w[pr * 4 + 0] = c.u;
-                        c.h[0] = __float2half_rn(lo4[2]); c.h[1] = __float2half_rn(lo4[3]); w[pr * 4 + 1] = c.u;
-                        c.h[0] = __float2half_rn(hi4[0]); c.h[1] = __float2half_rn(hi4[1]); w[pr * 4 + 2] = c.u;
-                        c.h[0] = __float2half_rn(hi4[2]); c.h[1] = __float2half_rn(hi4[3]); w[pr * 4 + 3] = c.u;
-                    }
-                    if (ok && !(dbg & 4)) {
-                        WS_GLOBAL unsigned char* dst = sgpr_ptr(p.out + (obase + (size_t)mrel * p.Cout));
-                        unsigned ol = olane;
-                        asm volatile("" : "+v"(ol));  // keep the 32 -> 64 bit extension in this block (instruction selection is per block)
-                        *(WS_GLOBAL u32x4_t*)(dst + ol) = u32x4_t{w[0], w[1], w[2], w[3]};
-                        *(WS_GLOBAL u32x4_t*)(dst + ol + 16) = u32x4_t{w[4], w[5], w[6], w[7]};
-                    }
-                }
-            }
+#if !WS_DEFER_EPILOGUE
+            if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc);
+#endif
             WS_STAMP(6);
             __syncthreads();
         }
+        // (wave-uniform values: pinned to SGPRs, the epilogue's scalar-base stores need them there)
+        done_tc.n = __builtin_amdgcn_readfirstlane(tc.n);
+        done_tc.cy = __builtin_amdgcn_readfirstlane(tc.cy);
+        done_tc.sp = __builtin_amdgcn_readfirstlane(tc.sp);
+        done_tc.ox0 = __builtin_amdgcn_readfirstlane(tc.ox0);
+        done_tc.oy0 = __builtin_amdgcn_readfirstlane(tc.oy0);
+        done_tc.oz0 = __builtin_amdgcn_readfirstlane(tc.oz0);
     }
     if (p.trace && blockIdx.x == 0 && tid == 0) {
         p.trace[WS_TRACE_SLOTS - 2] = __builtin_readcyclecounter();
@@ -921,11 +955,60 @@ static int launch_ws_r(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int t
     return BOA_OK;
 }
 
+// Run table of a layer: the tiles of ONE sample (decode_tile's order) cut into vw contiguous runs, 8 XCD ranges first
+// (virtual workgroup j <-> XCD j % 8) and then the virtual workgroups of an XCD; entry j = {count, cy, sp, ox0, oy0, oz0}
+// of the run's first tile.  A function of the layer geometry only (never of the batch size).
+static const int* ws_run_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, int vw) {
+    std::vector<int> key = {a.t0, a.t1, a.t2, a.b0, a.b1, a.b2, a.w0, a.w1, a.w2, a.Cout, a.cy_fast, vw};
+    for (auto& e : ctx->ws_runs)
+        if (e.first == key) return (const int*)e.second;
+    std::vector<int> tab((size_t)vw * 8, 0);
+    const int nsp = a.t0 * a.t1 * a.t2, ncy = a.Cout / 32;
+    for (int j = 0; j < vw; ++j) {
+        int first, count;
+        if (vw % 8 != 0) {
+            const int q = tiles_per_sample / vw, r = tiles_per_sample % vw;
+            first = j * q + std::min(j, r);
+            count = q + (j < r ? 1 : 0);
+        } else {
+            const int xcd = j & 7, slot = j >> 3, per = vw >> 3;
+            const int q = tiles_per_sample / 8, rem = tiles_per_sample % 8;
+            const int lo = xcd * q + std::min(xcd, rem), len = q + (xcd < rem ? 1 : 0);
+            const int cq = len / per, cr = len % per;
+            first = lo + slot * cq + std::min(slot, cr);
+            count = cq + (slot < cr ? 1 : 0);
+        }
+        int cy, sp;
+        if (a.cy_fast) {
+            cy = first % ncy;
+            sp = first / ncy;
+        } else {
+            sp = first % nsp;
+            cy = first / nsp;
+        }
+        int bt = sp;
+        const int tx = bt % a.t0;
+        bt /= a.t0;
+        const int tz = bt % a.t2, ty = bt / a.t2;
+        int* e = &tab[(size_t)j * 8];
+        e[0] = count; e[1] = cy; e[2] = sp; e[3] = tx * a.b0 * a.w0; e[4] = ty * a.b1 * a.w1; e[5] = tz * a.b2 * a.w2;
+    }
+    void* dev = nullptr;
+    if (hipMalloc(&dev, tab.size() * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        hipFree(dev);
+        return nullptr;
+    }
+    ctx->ws_runs.emplace_back(std::move(key), dev);
+    return (const int*)dev;
+}
+
 int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes) {
     const ConvArgs& a0 = a_in;
     // tiles of one sample; its virtual workgroups (batch-invariant statistics, see tile_walk); physical grid
     const int total = t.tiles[0] * t.tiles[1] * t.tiles[2] * (a0.Cout / 32);
-    const int vw = std::min(total, ctx->cu_count);
+    static const int vw_cap = getenv("BOA_WS_VW") ? atoi(getenv("BOA_WS_VW")) : 0;  // experiment hook (changes the statistics grouping)
+    const int vw = std::min(total, vw_cap > 0 ? std::min(vw_cap, ctx->cu_count) : ctx->cu_count);
     const int grid = (int)std::min<long long>((long long)vw * a0.N, ctx->cu_count);
     const int taps = a0.k0 * a0.k1 * a0.k2;
     const int HV = t.h[0] * t.h[1] * t.h[2];
@@ -940,7 +1023,11 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     // statistics slots: one per (workgroup, consumer wave); waves that never touch an (n, cout chunk) leave zeros
     a.nslots = conv_ws_nslots(ctx->cu_count);
     a.vw = vw;
+    a.vstep_n = grid / vw;
+    a.vstep_j = grid % vw;
     a.cy_fast = ((a.C0 + a.C1) == 32 && a.Cout == 64 && t.R == 1 && !getenv("BOA_WS_NO_CYFAST")) ? 1 : 0;
+    a.runs = ws_run_table(ctx, a, total, vw);
+    BOA_REQUIRE(a.runs != nullptr, "conv_ws: could not allocate the run table");
     // a.partials must be all zero on entry: the callers zero it once (allocation / test seam) and k_norm_finalize
     // clears what it has read, so no per-launch memset is needed
     if (want_trace) {

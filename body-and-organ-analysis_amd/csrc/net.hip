@@ -146,7 +146,12 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
     } else {
         BOA_REQUIRE((cin0 % 16) == 0 && (cin1 % 16) == 0 && (cout % 32) == 0,
                     "conv %d+%d -> %d: channel counts must be multiples of 16 (in) / 32 (out)", cin0, cin1, cout);
-        BOA_REQUIRE(choose_conv_tile(L.g, net->ctx->cu_count, &L.t), "no tile configuration fits conv %dx%dx%d", din[0],
+        // the tile shape fixes the fp32 summation order inside the conv and the grouping of the InstanceNorm partial sums:
+        // it is chosen for a nominal batch (8 tiles, what the task drivers use), never for the actual max_batch, so that a
+        // tile's result does not depend on the batch size the network was created with
+        ConvGeom gref = L.g;
+        gref.N = 8;
+        BOA_REQUIRE(choose_conv_tile(gref, net->ctx->cu_count, &L.t), "no tile configuration fits conv %dx%dx%d", din[0],
                     din[1], din[2]);
         L.nblk = conv_nblk(L.t, net->ctx->cu_count);
     }
@@ -724,7 +729,9 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     }
     g.Do = dout[0]; g.Ho = dout[1]; g.Wo = dout[2];
     ConvTile t;
-    BOA_REQUIRE(choose_conv_tile(g, ctx->cu_count, &t), "conv test: no tile configuration");
+    ConvGeom gref = g;
+    gref.N = 8;  // as the network does: the tile shape must not depend on the batch size
+    BOA_REQUIRE(choose_conv_tile(gref, ctx->cu_count, &t), "conv test: no tile configuration");
     size_t vin = (size_t)dims[0] * dims[1] * dims[2], vout = (size_t)dout[0] * dout[1] * dout[2];
     __half *in16 = nullptr, *out16 = nullptr, *wpk = nullptr;
     float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *partials = nullptr, *ss = nullptr;
