@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- CT volumes/sec of the BOA hot path on MI355X (BASELINE.json metric).
+"""bench.py -- CT volumes/sec of the BOA hot path on MI355X (BASELINE.json metric: 512^3 @1.5 mm, `total+bca`).
 
-Workload (configs[1] of BASELINE.json): one 512x512x512 @1.5 mm synthetic CT per GPU, `total` task = the five
-part models Dataset291-295 (PlainConvUNet 3d_fullres, patch 128^3, step 0.8 -> 125 tiles each = 625 tile
-forwards), Gaussian-weighted fp16 accumulation, normalise + argmax + part->global merge; the int16 CT is
-resident in HBM when the timed region starts and the uint8 label volume stays in HBM (PCIe-inclusive rate: see
-DESIGN.md).  One "step" = one whole volume.  Multi-GPU: one process per GPU, every rank segments its own volume
-(volume-level sharding, no data-path collective) -> weak scaling; value = all volumes / max-over-ranks time.
-`--shard tiles` instead lets the N GPUs share every volume (tile rows split across ranks, overlap slabs of the fp16
-accumulators over RCCL, boa_hip/tile_shard.py): strong scaling, the latency mode; not the default because whole volumes
-are the cheaper way to fill a node.
+One "step" = one whole CT through the hot path of `body_organ_analysis --models total+bca`:
+    total   : canonicalise -> CTNormalization -> 5 part models (PlainConvUNet 3d_fullres, patch 128^3, step 0.8 = 125 tiles
+              each) -> Gaussian-weighted fp16 accumulation -> normalise + argmax + part merge -> `total` labels
+    measure : per-label HU statistics of the 117 `total` labels (one histogram pass + eroded / fat-window masks)
+    bca     : body_parts + body_regions nets (5 folds each, 5 mm slices), CC / contour-fill post-processing, tissue map,
+              per-slice tables, bca-measurements JSON
+on a synthetic 512x512x512 @1.5 mm CT with seeded random weights of the documented architectures (no weights offline).
+`value` = volumes / (max-over-ranks wall time of the K timed steps), with the int16 CT resident in HBM when the timed
+region starts and the label volumes left in HBM (the tables come back to the host); `host_to_host` in the same line is the
+PCIe-inclusive rate (CT uploaded, three label volumes + `total` labels downloaded inside the timed region) -- never `value`.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--batch 4] [--no-cpu]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+Multi-GPU: one process per GPU over RCCL.  `python bench.py --gpus N` launches the N ranks itself (torch.distributed.run on
+127.0.0.1) when it is not already running under a launcher, and refuses to print a line when WORLD_SIZE != N.
+Default sharding: whole volumes (every rank segments its own CT, no data-path collective) -> weak scaling.
+`--shard tiles|models` lets the N GPUs share every volume (strong scaling; tile rows split with an RCCL exchange of the
+overlap slabs of the fp16 accumulators, or the part models dealt out to the ranks).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--models total+bca|total] [--batch 8] [--no-cpu]
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,15 +38,65 @@ for p in (ROOT, os.path.join(ROOT, "body-and-organ-analysis_amd")):
 import numpy as np  # noqa: E402
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+HBM_PEAK_GBPS = 8000.0               # same guide: 8 TB/s spec (6.3 TB/s measured for a float4 copy)
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_512.json")
 
 
-def cpu_baseline(geom_tuple, n_tiles_sample, tiles_per_volume, log):
-    """Oracle (torch-CPU fp32 PlainConvUNet + numpy fp16 accumulation = the reference's CPU path restated) timed
-    on the host on a bounded sample: `n_tiles_sample` tile forwards of part model 291, extrapolated by tile count."""
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, nargs="+", default=[512])
+    ap.add_argument("--batch", type=int, default=8, help="tiles per conv-stack launch")
+    ap.add_argument("--models", choices=["total+bca", "total"], default="total+bca",
+                    help="total+bca = BASELINE.json's metric (default); total = the five part models only (configs[1])")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host (PCIe-inclusive) extra")
+    ap.add_argument("--no-parity", action="store_true", help="skip the fp16-vs-exact-mode label flip sample")
+    ap.add_argument("--cpu-tiles", type=int, default=8)
+    ap.add_argument("--no-prof", action="store_true", help="no per-launch events (measures their overhead; roofline fields become 0)")
+    ap.add_argument("--shard", choices=["volumes", "tiles", "models"], default="volumes",
+                    help="N>1: 'volumes' = one volume per GPU, no data-path collective (weak scaling, default); 'tiles' = all "
+                         "GPUs share each volume: tile rows split, overlap slabs over RCCL (strong scaling, latency mode); "
+                         "'models' = the part models of `total` dealt out to the ranks, label volumes all-reduced")
+    ap.add_argument("--shard-mode", choices=["exact", "allreduce"], default="exact",
+                    help="--shard tiles: ordered send/recv hand-over (bit-exact) or pairwise fp16 all-reduce of the slabs")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo lets several ranks share one GPU for validation)")
+    ap.add_argument("--dump", type=str, default=None, help="write per-kernel-class timings to this JSON file")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks (one per GPU) and relay their exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(part_model, n_tiles_sample, work, log):
+    """The oracle (= the reference's CPU path restated: torch-CPU fp32 PlainConvUNet, numpy fp16 accumulation, numpy argmax /
+    merge, numpy tissue + HU statistics) timed on the host on a BOUNDED sample and extrapolated by unit counts:
+      network + accumulate : `n_tiles_sample` 128^3 tile forwards              x tile forwards per volume
+      normalise + argmax   : one 25-class 128^3 block                           x (sum of classes x voxels) per volume
+      part merge           : the reference's 117 compare-and-assign passes on 128^3   x voxels
+      aggregation          : tissue map + per-slice tables + per-label HU statistics on 128^3 x voxels"""
     import torch
+    from oracle import bca as obca
+    from oracle import labels as olab
+    from oracle import measurements as omeas
     from oracle import sliding_window as osw
     from oracle.network import build_from_arch
-    pj, dj, sd = geom_tuple
+    pj, dj, sd = part_model
     threads = min(8, os.cpu_count() or 1)  # the reference caps torch at min(8, n) (predict_from_raw_data.py:479-480)
     torch.set_num_threads(threads)
     arch = pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"]
@@ -57,112 +114,175 @@ def cpu_baseline(geom_tuple, n_tiles_sample, tiles_per_volume, log):
         for _ in range(n_tiles_sample):
             y = net(x)[0].numpy()
             osw.accumulate_tile(acc, n, y, g, (0, 0, 0))
-        dt = (time.perf_counter() - t0) / n_tiles_sample
-    log(f"cpu_baseline: {dt:.3f} s per tile forward+accumulate on {threads} threads")
-    return {"value": 1.0 / (dt * tiles_per_volume), "unit": "volumes/s", "cores": threads, "kind": "port",
-            "sample": f"{n_tiles_sample} x 128^3 tile forward (torch-CPU fp32 PlainConvUNet, 31M params) + fp16 Gaussian "
-                      f"accumulation, extrapolated to {tiles_per_volume} tile forwards per volume; argmax/merge not included",
-            "s_per_tile": dt, "host_cpus": os.cpu_count()}
+        t_tile = (time.perf_counter() - t0) / n_tiles_sample
+    pv = int(np.prod(patch))
+    t0 = time.perf_counter()
+    logits = osw.finalize_logits(acc, n)
+    seg = olab.argmax_labels(logits)
+    t_argmax = (time.perf_counter() - t0) / (nc * pv)          # per (class, voxel)
+    from boa_hip import label_maps
+    t0 = time.perf_counter()
+    olab.merge_parts([seg] * 5, [label_maps.CLASS_MAP_PARTS[t] for t in label_maps.PART_TASK_IDS], label_maps.CLASS_MAP_TOTAL_INV)
+    t_merge = (time.perf_counter() - t0) / pv                  # per voxel (all five parts)
+    rng = np.random.default_rng(0)
+    ct = rng.integers(-1000, 1500, size=patch).astype(np.int16)
+    regions = rng.integers(0, 12, size=patch).astype(np.uint8)
+    parts = rng.integers(0, 7, size=patch).astype(np.uint8)
+    total = rng.integers(0, 118, size=patch).astype(np.uint8)
+    t0 = time.perf_counter()
+    tis = obca.subclassify_tissues(ct, regions)
+    obca.slicewise_measurements(tis, parts, (1.5, 1.5, 1.5))
+    omeas.metrics_for_each_region(ct, total, {f"l{i}": i for i in range(1, 118)}, None, None, (1.5, 1.5, 1.5))
+    t_agg = (time.perf_counter() - t0) / pv                    # per voxel
+    s_net = t_tile * work["tile_forwards"]
+    s_arg = t_argmax * work["class_voxels"]
+    s_merge = t_merge * work["voxels"]
+    s_agg = t_agg * work["voxels"] * (1.0 if work["with_bca"] else 0.5)
+    total_s = s_net + s_arg + s_merge + s_agg
+    log(f"cpu_baseline: {t_tile:.3f} s per tile forward+accumulate on {threads} threads; per volume: nets {s_net:.0f} s, normalise+argmax "
+        f"{s_arg:.0f} s, merge {s_merge:.0f} s, aggregation {s_agg:.0f} s")
+    return {"value": 1.0 / total_s, "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"{n_tiles_sample} x 128^3 tile forward (torch-CPU fp32 PlainConvUNet, 31M params, {threads} threads) + fp16 Gaussian "
+                      f"accumulation; normalise + argmax, the reference's 117-pass part merge, tissue map + slice tables + per-label HU "
+                      f"statistics on one 128^3 block each (numpy, 1 thread); extrapolated by unit counts to {work['tile_forwards']} tile "
+                      f"forwards, {work['class_voxels']:.3g} class-voxels, {work['voxels']:.3g} voxels per volume",
+            "s_per_tile": t_tile, "s_per_volume": {"nets": s_net, "argmax": s_arg, "merge": s_merge, "aggregation": s_agg},
+            "host_cpus": os.cpu_count()}
 
 
+def parity_sample(ctx, part_model_cfg, blob, batch, log):
+    """fp16 production mode against the fp32 exact mode (= the reference's CPU arithmetic, tests/test_gpu_exact_mode.py) on a
+    bounded sample: label flip fraction of part model 291 on a 160x160x192 crop of the phantom (8 tiles, step 0.8)."""
+    from boa_hip import synthetic
+    from boa_hip.predictor import HipPredictor
+    ct = synthetic.ct_phantom([160, 160, 192], seed=7).astype(np.float32)
+    ip = part_model_cfg.intensity_properties["0"]
+    x = ((np.clip(ct, ip["percentile_00_5"], ip["percentile_99_5"]) - ip["mean"]) / max(ip["std"], 1e-8)).astype(np.float32)[None]
+    labs = {}
+    for prec in ("fp16", "fp32"):
+        p = HipPredictor(ctx, part_model_cfg.geometry, tile_step_size=0.8, max_batch=min(batch, 4), precision=prec)
+        p.set_parameters([blob])
+        labs[prec] = p.predict_segmentation(x)
+        p.close()
+    flips = float((labs["fp16"] != labs["fp32"]).mean())
+    log(f"parity sample: fp16 vs exact-mode label flip fraction {flips:.3g} on {labs['fp16'].size} voxels")
+    return {"fp16_vs_exact_mode_label_flip_fraction": flips, "voxels": int(labs["fp16"].size),
+            "sample": "part model 291 (synthetic weights) on a 160x160x192 phantom crop, 8 tiles, step 0.8; exact mode = fp32 "
+                      "weights/activations/accumulation, 0 flips against the torch-CPU oracle on the test fixtures"}
+
+
+# ------------------------------------------------------------------------------------------------- main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, nargs="+", default=[512])
-    ap.add_argument("--batch", type=int, default=8, help="tiles per conv-stack launch")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=4)
-    ap.add_argument("--no-prof", action="store_true", help="no per-launch events (measures their overhead; roofline fields become 0)")
-    ap.add_argument("--shard", choices=["volumes", "tiles", "models"], default="volumes",
-                    help="N>1: 'volumes' = one volume per GPU, no data-path collective (weak scaling, default); 'tiles' = all "
-                         "GPUs share each volume: tile rows split, overlap slabs over RCCL (strong scaling, latency mode); "
-                         "'models' = all GPUs share each volume: the five part models dealt out to the ranks, label volumes "
-                         "all-reduced and merged in part order (strong scaling, bit-identical at any tile batch)")
-    ap.add_argument("--shard-mode", choices=["exact", "allreduce"], default="exact",
-                    help="--shard tiles: ordered send/recv hand-over (bit-exact) or pairwise fp16 all-reduce of the slabs")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo lets several ranks share one GPU for validation)")
-    ap.add_argument("--with-bca", dest="with_bca", action="store_true", default=True,
-                    help="N=1: also time the BCA half of `total+bca` on the same volume (extra field total_plus_bca; default on)")
-    ap.add_argument("--no-bca", dest="with_bca", action="store_false")
-    ap.add_argument("--dump", type=str, default=None, help="write per-kernel-class timings to this JSON file")
-    args = ap.parse_args()
-
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    n_gpus = args.gpus
-    dist = None
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for GPUs that are not running",
+              file=sys.stderr)
+        sys.exit(2)
     import torch
+    dist = None
     if world > 1:
         from boa_hip import distributed as D
+        if args.backend == "nccl" and torch.cuda.device_count() < world:
+            print(f"bench.py: {world} RCCL ranks need {world} GPUs, {torch.cuda.device_count()} visible", file=sys.stderr)
+            sys.exit(2)
         if args.backend == "gloo":
             local_rank %= max(torch.cuda.device_count(), 1)
         dist = D.init(args.backend, rank, world, local_rank)  # backend "nccl" is RCCL on ROCm
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
 
-    from boa_hip import label_maps, synthetic
-    from boa_hip._lib import check
+    from boa_hip import label_maps, plans, synthetic
+    from boa_hip import measurements as M
+    from boa_hip import sliding_window as sw
+    from boa_hip.devarray import DevArray
     from boa_hip.device import Context
-    from boa_hip.predictor import HipPredictor
+    from boa_hip.pipeline import BcaPipelineHip
+    from boa_hip.task import SegmentationTask
 
+    with_bca = args.models == "total+bca"
     shape = args.size * 3 if len(args.size) == 1 else args.size
     ctx = Context(local_rank)
     log("device:", ctx.info())
     t0 = time.perf_counter()
-    models = synthetic.total_part_models()
-    predictors = []
-    for tid, cfg, blob, _ in models:
-        p = HipPredictor(ctx, cfg.geometry, tile_step_size=0.8, max_batch=args.batch)  # TS/nnunet.py:507-514
-        p.set_parameters([blob])
-        p._ensure_net(0)
-        predictors.append((tid, cfg, p))
-    tile_shard = None
-    if dist is not None and args.shard == "tiles":
+    part_models = synthetic.total_part_models()                         # [(task id, ModelConfig, blob, (plans, dataset, state dict))]
+    total_task = SegmentationTask(ctx, "total", [(tid, cfg, [blob]) for tid, cfg, blob, _ in part_models], resample=1.5,
+                                  multimodel=True, max_batch=args.batch)
+    tasks = [total_task]
+    pipe = None
+    if with_bca:
+        bm = {}
+        for name, nc, seed in (("body_parts", 7, 543), ("body_regions", 12, 542)):
+            pj, dj = plans.synthetic_plans(num_classes=nc, spacing=(5.0, 1.5, 1.5))
+            cfg = plans.model_config_from_plans(pj, dj)
+            bm[name] = (cfg, [plans.weight_blob_from_state_dict(cfg.geometry, plans.synthetic_state_dict(cfg.geometry, seed + f))
+                              for f in range(5)])
+        pipe = BcaPipelineHip(ctx, bm["body_parts"], bm["body_regions"], fast_bca=False, max_batch=args.batch)
+        tasks += list(pipe.tasks.values())
+    comm = None
+    if dist is not None and args.shard != "volumes":
         from boa_hip import tile_shard as ts
-        tile_shard = ts.TileShard(ts.ShardComm(dist, rank, world, f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"), args.shard_mode)
-    model_comm = None
-    if dist is not None and args.shard == "models":
-        from boa_hip import tile_shard as ts
-        model_comm = ts.ShardComm(dist, rank, world, f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
-    shared = tile_shard is not None or model_comm is not None          # all ranks work on the same volume
-    ct = synthetic.ct_phantom(shape, seed=20260928 + (0 if shared else rank))
+        comm = ts.ShardComm(dist, rank, world, f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+        for t in tasks:
+            if args.shard == "tiles":
+                t.shard = ts.TileShard(comm, args.shard_mode)
+            else:
+                t.model_shard = comm
+    shared = comm is not None                                            # all ranks work on the same volume
+    ct = synthetic.ct_phantom(shape, seed=20260928 + (0 if shared else rank))   # file array (x, y, z), int16 HU
+    affine = np.diag([-1.5, -1.5, 1.5, 1.0])                             # an LPS file @1.5 mm: exercises the canonicalisation
+    label_map = label_maps.measurement_label_map("total")
     log(f"setup (synthetic weights + phantom {shape}) {time.perf_counter() - t0:.1f}s")
     nvox = int(np.prod(shape))
-    d_ct = ctx.from_numpy(ct)
-    d_vol = ctx.alloc(nvox * 4)
-    d_lab = ctx.alloc(nvox)
-    d_part = ctx.alloc(nvox) if args.shard == "models" else None
-    work = {}
-    ip = models[0][1].intensity_properties["0"]
-    tiles_per_volume = 0
-    flops_per_volume = 0.0
-    from boa_hip import sliding_window as sw
-    for tid, cfg, p in predictors:
+
+    # work per volume (for the roofline / CPU extrapolation): tile forwards and FLOPs of every network
+    tile_forwards, flops_per_volume, class_voxels = 0, 0.0, 0.0
+    for tid, cfg, _, _ in part_models:
         PV, _ = sw.pad_amounts(shape, cfg.geometry.patch_size)
         nt = len(sw.get_sliding_window_origins(PV, cfg.geometry.patch_size, 0.8))
-        tiles_per_volume += nt
+        tile_forwards += nt
         flops_per_volume += nt * cfg.geometry.flops_per_tile()
+        class_voxels += (cfg.geometry.num_classes + 1.0) * nvox
+    if with_bca:
+        zb = int(round(shape[2] * 1.5 / 5.0))                            # slices at 5 mm (TS/resampling.py:165-181)
+        for name in ("body_parts", "body_regions"):
+            cfg = bm[name][0]
+            vs = [zb, shape[1], shape[0]]                                # nnU-Net array order (z, y, x)
+            PV, _ = sw.pad_amounts(vs, cfg.geometry.patch_size)
+            nt = len(sw.get_sliding_window_origins(PV, cfg.geometry.patch_size, 0.5)) * 5
+            tile_forwards += nt
+            flops_per_volume += nt * cfg.geometry.flops_per_tile()
+            class_voxels += 5 * (cfg.geometry.num_classes + 1.0) * float(np.prod(vs))
 
-    def step():
-        # CTNormalization -> 5 part models (sliding window, fp16 accumulate) -> argmax + merge into `total` labels
-        check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, 0, d_vol.vp, nvox, ip["mean"], ip["std"], ip["percentile_00_5"],
-                                       ip["percentile_99_5"]))
-        d_lab.zero()
-        if model_comm is not None:
-            from boa_hip import tile_shard as ts
-            for k, (tid, cfg, p) in enumerate(predictors):
-                check(ctx.lib.boa_memset(ctx.h, d_part.vp, 0, nvox))
-                if k % world == rank:
-                    p.predict_segmentation_device(d_vol, shape, d_part, lut=label_maps.part_lut(tid), merge=False, work=work)
-                ts.all_reduce_labels(ctx, model_comm, d_part, nvox)
-                check(ctx.lib.boa_label_overlay(ctx.h, d_part.vp, nvox, d_lab.vp))
-            return
-        for tid, cfg, p in predictors:
-            p.predict_segmentation_device(d_vol, shape, d_lab, lut=label_maps.part_lut(tid), merge=True, work=work,
-                                          shard=tile_shard)
+    d_ct = DevArray.from_numpy(ctx, ct)                                  # resident int16 CT, file axis order
+
+    def step(d_in, download=False):
+        """One CT through total -> total measurements -> bca.  `download`: also bring the label volumes to the host."""
+        outs = []
+        d_total = total_task.predict_image(d_in, affine, return_device=True)
+        outs.append(d_total)
+        # compute_measurements' view: SimpleITK (z,y,x) arrays of the file (BOA/compute/measurements.py:257-258)
+        c_zyx = d_in.transpose((2, 1, 0)).contiguous(np.int16, force_copy=True)
+        s_zyx = d_total.transpose((2, 1, 0)).contiguous(force_copy=True)
+        meas, d_mask = M.total_measurements(ctx, None, None, label_map, (1.5, 1.5, 1.5), cnr_adjustment=True, d_ct=c_zyx.buf,
+                                            d_lab=s_zyx.buf, shape=c_zyx.shape, mask_on_device=True)
+        d_mask.free()
+        c_zyx.free()
+        s_zyx.free()
+        res = None
+        if pipe is not None:
+            res = pipe.run_resident(d_in, affine, d_total)
+            outs += [res["body_parts"], res["body_regions"], res["tissues"]]
+        host = [a.download() for a in outs] if download else None
+        chk = None
+        if download:
+            chk = int(host[0].astype(np.int64).sum())
+        for a in outs:
+            a.free()
+        return meas, res["bca_measurements"] if res else None, chk
 
     def barrier():
         ctx.sync()
@@ -171,24 +291,45 @@ def main():
         torch.cuda.synchronize() if torch.cuda.is_available() else None
 
     for _ in range(args.warmup):
-        step()
+        step(d_ct)
     ctx.sync()
+    ctx.counters(reset=True)
     ctx.prof_reset()
     ctx.prof_enable(not args.no_prof)
     barrier()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        meas, bca_js, _ = step(d_ct)
     barrier()
     elapsed = time.perf_counter() - t_start
     ctx.prof_enable(False)
     prof = ctx.prof_get()
+    counters = ctx.counters()
+    ranks_seen = world
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+        dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)                                             # ranks that actually took part, counted over RCCL
+        ranks_seen = int(one.item())
+        if ranks_seen != args.gpus:
+            print(f"bench.py: {ranks_seen} ranks answered the all-reduce, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
 
-    labels_sum = int(d_lab.download((nvox,), np.uint8).astype(np.int64).sum()) if rank == 0 else 0
+    h2h = None
+    if rank == 0 and not args.no_h2h and args.gpus == 1:
+        # PCIe-inclusive: upload the CT, download `total` + the three BCA label volumes (tables are host dicts already)
+        ctx.sync()
+        tb = time.perf_counter()
+        d_up = DevArray.from_numpy(ctx, ct)
+        _, _, chk = step(d_up, download=True)
+        d_up.free()
+        ctx.sync()
+        h2h = {"s_per_volume": time.perf_counter() - tb, "label_checksum": chk}
+        h2h["value"] = 1.0 / h2h["s_per_volume"]
+
     if rank == 0:
         conv = prof["conv_mfma"]
         conv_ms = conv["ms"]
@@ -198,88 +339,75 @@ def main():
             if v["launches"]:
                 log(f"  {k:16s} {v['ms']:10.1f} ms  {v['launches']:8d} launches  "
                     f"{v['flops'] / max(v['ms'], 1e-9) / 1e9:9.1f} TFLOP/s  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:9.1f} GB/s")
-        log(f"  sum of kernel times {total_ms:.1f} ms of {elapsed * 1e3:.1f} ms wall; label checksum {labels_sum}")
+        log(f"  sum of event-timed kernel classes {total_ms:.1f} ms of {elapsed * 1e3:.1f} ms wall; kernel variants {counters}")
+        n_vol = (1 if shared else args.gpus) * args.steps
         res = {
-            "metric": "CT volumes/sec (512^3 @1.5 mm, total) on MI355X",
-            "value": (1 if shared else n_gpus) * args.steps / elapsed, "unit": "volumes/s", "n_gpus": n_gpus, "steps": args.steps,
+            "metric": "CT volumes/sec (512^3 @1.5 mm, total+bca) on MI355X" if with_bca else "CT volumes/sec (512^3 @1.5 mm, total) on MI355X",
+            "value": n_vol / elapsed, "unit": "volumes/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "strong" if shared else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: single {shape[0]}x{shape[1]}x{shape[2]} @1.5 mm volume, `total` "
-                                   f"(5 part models, {tiles_per_volume} tile forwards of 128^3, step 0.8), " +
-                                   (f"each volume tile-sharded over {n_gpus} GPUs ({args.shard_mode} slab exchange)" if tile_shard
-                                    else f"the part models of each volume dealt out to {n_gpus} GPUs" if model_comm
+            "config": {"workload": f"configs[1] volume ({shape[0]}x{shape[1]}x{shape[2]} @1.5 mm, LPS file), `{args.models}`: 5 part models "
+                                   f"(patch 128^3, step 0.8)" + (" + total measurements + body_parts / body_regions nets (5 folds each at 5 mm "
+                                   "slices, step 0.5) + CC / contour-fill post-processing + tissues + tables" if with_bca else
+                                   " + total measurements") + f", {tile_forwards} tile forwards per volume; " +
+                                   (f"each volume shared by {args.gpus} GPUs (--shard {args.shard}" +
+                                    (f", {args.shard_mode} slab exchange)" if args.shard == "tiles" else ")") if shared
                                     else "1 volume per GPU"),
-                       "tiles_per_volume": tiles_per_volume, "tile_batch": args.batch,
-                       "tflop_per_volume": flops_per_volume / 1e12,
-                       "precision": "fp16 activations/weights, fp32 MFMA accumulate, fp16 logit accumulators (reference semantics)"},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_ws<R,3,3,3> (all MFMA 3x3x3 conv launches: wave-specialised implicit GEMM, v_mfma_f32_32x32x16_f16)",
+                       "tile_forwards_per_volume": tile_forwards, "tile_batch": args.batch,
+                       "tflop_per_volume": flops_per_volume / 1e12, "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
+                       "precision": "fp16 activations/weights, fp32 MFMA accumulate, fp16 logit accumulators (reference semantics)",
+                       "input": "int16 CT resident in HBM at the start of the timed region; label volumes stay in HBM, tables on the host"},
+            "roofline": {"bound": "mfma", "kernel": "k_conv_ws<R,K> (all MFMA 3x3x3 / 1x3x3 conv launches of the step: wave-specialised "
+                                                    "implicit GEMM, v_mfma_f32_32x32x16_f16)",
                          "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
                          "launches": conv["launches"], "avg_launch_ms": conv_ms / max(conv["launches"], 1),
                          "flops_per_launch": conv["flops"] / max(conv["launches"], 1),
+                         "bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
                          "share_of_kernel_time": conv_ms / max(total_ms, 1e-9)},
-            "end_to_end_tflops": flops_per_volume * args.steps / elapsed / 1e12,
-            # the HBM-bound stages of the same run (algorithmic bytes / event time, peak 8 TB/s): BASELINE.json's "% HBM roofline"
+            "end_to_end_tflops": flops_per_volume * n_vol / elapsed / 1e12,
+            # the HBM-bound stages of the same run (algorithmic bytes / event time against 8 TB/s): BASELINE.json's "% HBM roofline"
             "hbm_stages": {k: {"achieved_GBps": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6,
-                               "frac": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6 / 8000.0, "ms": prof[k]["ms"],
+                               "frac": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6 / HBM_PEAK_GBPS, "ms": prof[k]["ms"],
                                "launches": prof[k]["launches"]}
                            for k in ("head_accum", "finalize_argmax", "convT_mfma", "conv_first") if prof[k]["launches"]},
+            "kernel_variants": counters,
+            "host_to_host": h2h,
+            "tables": {"total_labels_present": int(sum(1 for v in meas["segmentations"]["total"].values() if v.get("present"))) if meas else None,
+                       "bca_aggregated_groups": len(bca_js.get("aggregated", {})) if bca_js else None},
         }
-        # HBM traffic of the dominant kernel: FETCH_SIZE / WRITE_SIZE from the committed rocprofv3 --pmc passes
-        # (tools/profile_round.sh: separate passes, gfx950 FETCH correction; they cannot run inside this process), averaged over
-        # the k_conv_ws launches; per launch like `achieved` (bytes; compare with bytes_per_launch = algorithmic)
+        # HBM traffic of the dominant kernel: FETCH_SIZE / WRITE_SIZE from the committed rocprofv3 --pmc passes of THIS workload
+        # (tools/profile_round.sh: separate passes at 512^3, gfx950 FETCH correction; counters cannot be collected inside this
+        # process), launch-weighted mean over the k_conv_ws launches; per launch like `achieved`
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_256.json")))["kernels"]
-            rows = [v for k, v in pmc.items() if "k_conv_ws" in k]
+            pj_ = json.load(open(PMC_PROFILE))
+            rows = [v for k, v in pj_["kernels"].items() if "k_conv_ws" in k]
             nd = sum(v["dispatches"] for v in rows)
             res["roofline"]["traffic"] = 1e6 * 1.048576 * sum(
                 v["dispatches"] * (v["fetch_MB_corrected_per_dispatch"] + v["write_MB_per_dispatch"]) for v in rows) / nd
-            res["roofline"]["traffic_unit"] = "HBM bytes per launch (PMC, profiles/r01_pmc_fetch_write_256.json)"
-            res["roofline"]["bytes_per_launch"] = conv["bytes"] / max(conv["launches"], 1)
-        except Exception:
-            pass
-        if not args.no_cpu and n_gpus == 1:
-            res["cpu_baseline"] = cpu_baseline(models[0][3], args.cpu_tiles, tiles_per_volume, log)
+            res["roofline"]["traffic_source"] = {"file": os.path.relpath(PMC_PROFILE, ROOT), "command": pj_.get("command"),
+                                                 "git": pj_.get("git")}
+        except Exception as e:  # noqa: BLE001
+            res["roofline"]["traffic_source"] = f"unavailable ({type(e).__name__})"
+        if not args.no_parity and args.gpus == 1:
+            try:
+                res["parity"] = parity_sample(ctx, part_models[0][1], part_models[0][2], args.batch, log)
+            except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
+                res["parity"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.no_cpu and args.gpus == 1:
+            res["cpu_baseline"] = cpu_baseline(part_models[0][3], args.cpu_tiles,
+                                               {"tile_forwards": tile_forwards, "class_voxels": class_voxels, "voxels": float(nvox),
+                                                "with_bca": with_bca}, log)
         else:
             res["cpu_baseline"] = None
-        if args.with_bca and n_gpus == 1:
-            # BASELINE.json's metric names `total+bca`: the BCA half (body_parts + body_regions nets, 5 folds each at 5 mm
-            # slices, CC / contour-fill post-processing, tissues, per-slice tables, JSON) on the same volume, host to host
-            # (uploads the CT, downloads three label volumes), timed once after one warm-up; not part of `value`.
-            try:
-                from boa_hip import plans
-                from boa_hip.pipeline import BcaPipelineHip
-                bm = {}
-                for name, nc, seed in (("body_parts", 7, 543), ("body_regions", 12, 542)):
-                    pj, dj = plans.synthetic_plans(num_classes=nc, spacing=(5.0, 1.5, 1.5))
-                    cfg = plans.model_config_from_plans(pj, dj)
-                    bm[name] = (cfg, [plans.weight_blob_from_state_dict(cfg.geometry, plans.synthetic_state_dict(cfg.geometry, seed + f))
-                                      for f in range(5)])
-                pipe = BcaPipelineHip(ctx, bm["body_parts"], bm["body_regions"], fast_bca=False)
-                total_lab = d_lab.download(tuple(shape), np.uint8)
-                aff = np.diag([-1.5, -1.5, 1.5, 1.0])
-                pipe.run(ct, aff, total_seg=total_lab)
-                ctx.sync()
-                tb = time.perf_counter()
-                out = pipe.run(ct, aff, total_seg=total_lab)
-                ctx.sync()
-                t_bca = time.perf_counter() - tb
-                pipe.close()
-                t_total = elapsed / args.steps
-                res["total_plus_bca"] = {"bca_s": t_bca, "total_s": t_total, "value": 1.0 / (t_total + t_bca), "unit": "volumes/s",
-                                         "note": "bca = 2 nets x 5 folds at 5 mm slices + post-processing + tissues + tables, host to "
-                                                 "host, one run after one warm-up; synthetic weights",
-                                         "tissue_voxels": int((out["tissues"] > 0).sum())}
-                log(f"total+bca: total {t_total:.3f} s + bca {t_bca:.3f} s -> {1.0 / (t_total + t_bca):.3f} volumes/s")
-            except Exception as e:  # noqa: BLE001  (the extra must never cost the headline line)
-                res["total_plus_bca"] = {"error": f"{type(e).__name__}: {e}"}
         if args.dump:
             os.makedirs(os.path.dirname(os.path.abspath(args.dump)), exist_ok=True)
             with open(args.dump, "w") as f:
                 json.dump({"prof": prof, "elapsed_s": elapsed, "result": res}, f, indent=1)
         print(json.dumps(res), flush=True)
-    for _, _, p in predictors:
-        p.close()
+    d_ct.free()
+    for t in tasks:
+        t.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

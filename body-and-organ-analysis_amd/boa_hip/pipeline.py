@@ -151,20 +151,40 @@ class BcaPipelineHip:
         """-> {"body_parts", "body_regions", "tissues" (file axis order, uint8), "bca_measurements" (dict),
         "vertebrae" (dict)}.  `total_seg`: the `total` label volume on the same grid (vertebra groups), optional.
         The CT is uploaded once; every stage (nets, post-processing, LPS reload, tissues, tables) works on resident
-        buffers, the three label volumes are downloaded at the end."""
-        ctx = self.ctx
-        affine = np.asarray(affine, dtype=np.float64)
+        buffers (`run_resident`), the three label volumes are downloaded at the end."""
         if np.asarray(ct).dtype != np.int16:
             from .compute.util import require_int16_exact
             require_int16_exact(ct, "bca: CT")    # tissue rules / HU sums run on int16 HU: never truncate or wrap silently
-        d_ct = DevArray.from_numpy(ctx, SegmentationTask._supported(ct))
-        live = [d_ct]
+        d_ct = DevArray.from_numpy(self.ctx, SegmentationTask._supported(ct))
+        d_tot = None if total_seg is None else DevArray.from_numpy(self.ctx, np.ascontiguousarray(total_seg, dtype=np.uint8))
+        res = None
+        try:
+            res = self.run_resident(d_ct, affine, d_tot, median_filtering, examined_body_region, crop_body, force_split, raw_parts,
+                                    raw_regions, done_parts, done_regions)
+            return {"body_parts": res["body_parts"].download(), "body_regions": res["body_regions"].download(),
+                    "tissues": res["tissues"].download(), "bca_measurements": res["bca_measurements"],
+                    "vertebrae": res["vertebrae"], "examined_body_part": res["examined_body_part"]}
+        finally:
+            for a in [d_ct, d_tot] + ([res[k] for k in ("body_parts", "body_regions", "tissues")] if res else []):
+                if a is not None:
+                    a.free()
+
+    def run_resident(self, d_ct: DevArray, affine: np.ndarray, d_total: Optional[DevArray] = None,
+                     median_filtering: bool = False, examined_body_region: Optional[str] = None, crop_body: bool = False,
+                     force_split: bool = False, raw_parts: Optional[np.ndarray] = None, raw_regions: Optional[np.ndarray] = None,
+                     done_parts: Optional[np.ndarray] = None, done_regions: Optional[np.ndarray] = None) -> dict:
+        """`run` on device-resident inputs (CT and `total` labels in the file's axis order; neither is freed here): the three
+        label volumes come back as contiguous DevArrays in file axis order (the caller frees them), the tables as dicts."""
+        ctx = self.ctx
+        affine = np.asarray(affine, dtype=np.float64)
+        live = []
+        keep = []
         try:
             d_parts = self._inference_device("body_parts", d_ct, affine, force_split, None, raw_parts, done_parts)
-            live.append(d_parts)
+            keep.append(d_parts)
             crop = d_parts.download() if crop_body else None
             d_regions = self._inference_device("body_regions", d_ct, affine, force_split, crop, raw_regions, done_regions)
-            live.append(d_regions)
+            keep.append(d_regions)
             with _Stage(ctx, "LPS reload, body-part flags, vertebrae, tissues + tables, JSON"):
                 _, laff = orientation.with_axcodes(np.empty(d_ct.shape, dtype=np.uint8), affine, "LPS")
                 sp = np.sqrt(np.sum(np.asarray(laff, dtype=np.float64)[:3, :3] ** 2, axis=0))
@@ -184,10 +204,8 @@ class BcaPipelineHip:
                 else:
                     flags = bca.examined_body_part(present, spacing)
                 vertebrae = {}
-                if total_seg is not None:
-                    d_tot = DevArray.from_numpy(ctx, np.ascontiguousarray(total_seg, dtype=np.uint8))
-                    live.append(d_tot)
-                    tot_l = self._lps_zyx(d_tot, affine)
+                if d_total is not None:
+                    tot_l = self._lps_zyx(d_total, affine)
                     live.append(tot_l)
                     vertebrae = bca.create_vertebrae_info(ctx, None, label_maps.CLASS_MAP_TOTAL, flags, d_total=tot_l.buf,
                                                           shape=tot_l.shape)
@@ -197,12 +215,15 @@ class BcaPipelineHip:
                 live.append(tis_l)
                 # back to the file's axis order: (z,y,x) LPS -> (x,y,z) LPS -> file orientation
                 back = orientation.ornt_transform(orientation.axcodes2ornt("LPS"), orientation.io_orientation(affine))
-                tissues = tis_l.transpose((2, 1, 0)).apply_orientation(back).download()
-            return {"body_parts": d_parts.download(), "body_regions": d_regions.download(), "tissues": tissues,
-                    "bca_measurements": js, "vertebrae": vertebrae, "examined_body_part": flags}
+                tissues = tis_l.transpose((2, 1, 0)).apply_orientation(back).contiguous(force_copy=True)
+                keep.append(tissues)
+            out = {"body_parts": d_parts, "body_regions": d_regions, "tissues": tissues, "bca_measurements": js,
+                   "vertebrae": vertebrae, "examined_body_part": flags}
+            keep = []
+            return out
         finally:
             seen = set()
-            for a in live:
+            for a in live + keep:
                 if id(a.buf) not in seen:
                     seen.add(id(a.buf))
                     a.free()

@@ -9,6 +9,8 @@ import json
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
+command = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --size 256 --steps 1 --warmup 0 --no-cpu"
+git = sys.argv[4] if len(sys.argv) > 4 else None
 res = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(f"{root}/pmc_{c}/**/*counter_collection.csv", recursive=True)
@@ -28,7 +30,7 @@ for k, d in res.items():
         d["fetch_MB_corrected_per_dispatch"] = 2 * d["FETCH_SIZE_KB_per_dispatch"] * 1024 / 2 ** 20
     if "WRITE_SIZE_KB_per_dispatch" in d:
         d["write_MB_per_dispatch"] = d["WRITE_SIZE_KB_per_dispatch"] * 1024 / 2 ** 20
-json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --size 256 --steps 1 --warmup 0 --no-cpu",
+json.dump({"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- " + command, "git": git,
            "note": __doc__, "kernels": dict(sorted(res.items(), key=lambda kv: -kv[1].get("FETCH_SIZE_KB_per_dispatch", 0) * kv[1].get("dispatches", 0)))},
           open(out, "w"), indent=1)
 print(open(out).read()[:1500])
