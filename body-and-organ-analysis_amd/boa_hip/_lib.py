@@ -10,8 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOA_HIP_LIB") or os.path.join(_HERE, "libboa_hip.so")
 
 BOA_OK, BOA_EINVAL, BOA_EHIP, BOA_ENOMEM, BOA_EINF = 0, -1, -2, -3, -4
-K_CONV_MFMA, K_CONV_FIRST, K_CONVT, K_NORM_FINALIZE, K_HEAD_ACCUM, K_ARGMAX, K_OTHER, K_COUNT = range(8)
-K_NAMES = ["conv_mfma", "conv_first", "convT_mfma", "norm_finalize", "head_accum", "finalize_argmax", "other"]
+K_CONV_MFMA, K_CONV_FIRST, K_CONVT, K_NORM_FINALIZE, K_HEAD_ACCUM, K_ARGMAX, K_OTHER, K_AGG, K_MORPH, K_RESAMPLE, K_COPY, K_COUNT = range(12)
+K_NAMES = ["conv_mfma", "conv_first", "convT_mfma", "norm_finalize", "head_accum", "finalize_argmax", "other", "aggregation",
+           "morphology", "resample", "copy_remap"]
 CNT_NAMES = ["head_mfma", "head_valu", "conv_ws", "conv_simple", "first_mfma", "first_valu", "f32"]
 MAX_STAGES = 8
 
@@ -89,6 +90,8 @@ _PROTOS = {
     "boa_nonzero_bbox": (i32, [vp, vp, i32, ip, ip]),
     "boa_resample_cubic": (i32, [vp, vp, i32, ip, vp, i32, ip]),
     "boa_resample_nearest_u8": (i32, [vp, vp, ip, vp, ip]),
+    "boa_resize_skimage_f32": (i32, [vp, vp, ip, vp, ip, i32, i32]),
+    "boa_resize_logits_argmax": (i32, [vp, vp, i32, ip, ip, ip, ip, i32, vp, i32, vp]),
 }
 
 EXPORTS = sorted(_PROTOS)

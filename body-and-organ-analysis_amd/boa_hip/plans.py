@@ -186,7 +186,8 @@ def model_config_from_plans(plans: dict, dataset_json: dict, configuration: str 
                        transpose_backward=list(plans.get("transpose_backward", [0, 1, 2])),
                        normalization_schemes=list(cfg.get("normalization_schemes", ["CTNormalization"])),
                        intensity_properties={str(k): v for k, v in ip.items()}, labels=dict(labels),
-                       configuration_name=configuration)
+                       configuration_name=configuration,
+                       extra={k: cfg[k] for k in cfg if k.startswith("resampling_fn_")})
 
 
 def load_model_folder(model_folder: str, configuration: Optional[str] = None):

@@ -175,12 +175,17 @@ class HipPredictor:
         return pred
 
     def predict_segmentation_device(self, dvol: DeviceBuffer, V, labels_out: DeviceBuffer, lut: Optional[np.ndarray] = None,
-                                    merge: bool = False, work: Optional[dict] = None, shard=None):
+                                    merge: bool = False, work: Optional[dict] = None, shard=None, resample_to=None):
         """All folds -> labels on device.  dvol: fp32 [Cin,*V] resident; labels_out: uint8 [*V] resident (updated in
         place when merge=True).  `work` may carry preallocated acc / n / fold buffers to reuse across models.
         `shard` (tile_shard.TileShard): this volume is shared by the ranks of shard.comm -- every rank holds the volume,
-        runs its block of tile rows, exchanges the overlap slabs and ends with the same labels_out."""
+        runs its block of tile rows, exchanges the overlap slabs and ends with the same labels_out.
+        `resample_to` = (out_dims, slice_axis): the volume is at the plans' spacing and the labels are wanted on another
+        grid (nnU-Net's own resampling, export_prediction.py:25-33): the fold-mean logits are resampled with order 1 to
+        `out_dims` and reduced to labels there (`boa_resize_logits_argmax`); labels_out is then uint8 [*out_dims]."""
         if shard is not None and shard.comm.world > 1:
+            if resample_to is not None:
+                raise NotImplementedError("tile sharding together with nnU-Net's plan-spacing resampling")
             return self._predict_segmentation_sharded(dvol, V, labels_out, lut, merge, work, shard)
         PV, below = sw.pad_amounts(V, self.geom.patch_size)
         origins = sw.get_sliding_window_origins(PV, self.geom.patch_size, self.tile_step_size)
@@ -208,17 +213,26 @@ class HipPredictor:
         if lut is not None:
             lut_arr = np.zeros(256, dtype=np.uint8)
             lut_arr[:len(lut)] = lut
+        lut_p = lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None
         crop = any(b != 0 for b in below) or list(PV) != list(V)
+        direct = resample_to is None
         for f in range(nf):
             self._run_fold(dvol, V, PV, below, origins, acc, nacc, f)
             last = f == nf - 1
+            # resampled path: keep the normalised (fold-mean) logits -- in `acc` for one fold, in `fold` otherwise -- and
+            # take the argmax after the resampling
             check(self.lib.boa_finalize_labels(
                 self.ctx.h, acc.vp, nacc.vp, C_, int3(PV), fold.vp if fold else None, 0 if f == 0 else 1,
-                nf if (last and fold) else 0, 0, lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None,
-                1 if merge else 0, labels_out.vp if last else None, int3(below) if crop else None,
+                nf if (last and fold) else 0, 0 if (direct or fold) else 1, lut_p,
+                1 if merge else 0, labels_out.vp if (last and direct) else None, int3(below) if crop else None,
                 int3(V) if crop else None, flag.vp), "boa_finalize_labels")
         if int(flag.download((1,), np.int32)[0]):
             raise RuntimeError("Encountered inf in predicted array. Aborting...")
+        if not direct:
+            out_dims, slice_axis = resample_to
+            check(self.lib.boa_resize_logits_argmax(self.ctx.h, (fold if fold else acc).vp, C_, int3(PV), int3(below), int3(V),
+                                                    int3(out_dims), int(slice_axis), lut_p, 1 if merge else 0, labels_out.vp),
+                  "boa_resize_logits_argmax")
         if own:
             for b in work.values():
                 b.free()

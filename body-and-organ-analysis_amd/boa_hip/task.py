@@ -10,10 +10,11 @@ TS/nnunet.py:nnUNet_predict_image (:326-829) + nnUNetPredictor.predict_from_file
     -> recombine the thirds (:580-587) -> change_spacing order 0 back to the input grid (:685-687, device)
     -> undo_canonical (:691) -> undo_crop (:695) -> uint8 labels on the input grid.
 
-Axis permutes / flips / crops are index remaps done with numpy views; every per-voxel computation runs in
-libboa_hip.so.  nnU-Net's own resampling to the plans' spacing (default_preprocessor.py:82-96) must be the identity
-(true for every BASELINE.json config: `total` is resampled to 1.5 mm = plans spacing, the BCA nets get (sx, sy, 5.0));
-a plan with a different spacing raises NotImplementedError instead of silently skipping that step.
+Axis permutes / flips / crops are index remaps done with device views; every per-voxel computation runs in
+libboa_hip.so.  nnU-Net's own resampling to the plans' spacing (default_preprocessor.py:82-93) and of the logits back
+(export_prediction.py:25-33) happens per model inside `predict_zyx_device` whenever the array's spacing differs from the
+model's plans (`boa_hip/nnunet_resample.py`); it is the identity at every BASELINE.json config (`total` is resampled to
+1.5 mm = plans spacing) and active for real-world BCA / cascade inputs whose in-plane spacing differs from the plans'.
 """
 from __future__ import annotations
 
@@ -22,8 +23,9 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import label_maps, orientation
+from . import nnunet_resample as nr
 from . import resample as rs
-from ._lib import check
+from ._lib import check, int3
 from .devarray import DevArray
 from .device import Context
 from .plans import ModelConfig
@@ -110,8 +112,11 @@ class SegmentationTask:
         self._work = {}
 
     # ---- device core: resident CT [z,y,x] -> resident uint8 labels -----------------------------------------
-    def predict_zyx_device(self, d_ct, shape, d_labels, in_dtype: int = 0):
-        """in_dtype 0 int16 / 1 float32 / 2 int32.  Labels are zeroed here, then every model writes (merges) into them."""
+    def predict_zyx_device(self, d_ct, shape, d_labels, in_dtype: int = 0, spacing_zyx=None):
+        """in_dtype 0 int16 / 1 float32 / 2 int32.  Labels are zeroed here, then every model writes (merges) into them.
+        `spacing_zyx`: voxel spacing of the array (nnU-Net axis order); when it differs from a model's plans spacing the
+        normalised volume is resampled to the plans' grid and the logits back (nnU-Net's own resampling,
+        default_preprocessor.py:82-93 / export_prediction.py:25-33) -- None = the array is at the plans' spacing."""
         ctx = self.ctx
         n = int(np.prod(shape))
         vol = self._work.get("vol")
@@ -121,14 +126,30 @@ class SegmentationTask:
             vol = self._work["vol"] = ctx.alloc(n * 4)
         d_labels.zero()
         if self.model_shard is not None and self.model_shard.world > 1 and self.multimodel:
+            if spacing_zyx is not None and any(nr.compute_new_shape(shape, spacing_zyx, cfg.spacing) != list(shape) for _, cfg, _, _ in self.parts):
+                raise NotImplementedError("model sharding together with nnU-Net's plan-spacing resampling")
             return self._predict_zyx_model_sharded(d_ct, shape, d_labels, in_dtype, vol, n)
         for task_id, cfg, p, lut in self.parts:
             ip = cfg.intensity_properties["0"]
             # every model normalises with its own plans' intensity properties (default_preprocessor.py:336-348)
             check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, in_dtype, vol.vp, n, ip["mean"], ip["std"],
                                            ip["percentile_00_5"], ip["percentile_99_5"]), "boa_ct_normalize")
-            p.predict_segmentation_device(vol, list(shape), d_labels, lut=lut, merge=self.multimodel, work=self._work,
-                                          shard=self.shard)
+            new_shape = list(shape) if spacing_zyx is None else nr.compute_new_shape(shape, spacing_zyx, cfg.spacing)
+            if new_shape == list(shape):      # resample_data_or_seg returns its input unchanged (default_resampling.py:194-196)
+                p.predict_segmentation_device(vol, list(shape), d_labels, lut=lut, merge=self.multimodel, work=self._work,
+                                              shard=self.shard)
+                continue
+            # normalise BEFORE resampling (default_preprocessor.py:82-84), order 3 in; order 1 back, then argmax
+            ax_in = nr.slice_axis_for(nr.checked_kwargs(cfg.extra, "data"), spacing_zyx, cfg.spacing)
+            ax_out = nr.slice_axis_for(nr.checked_kwargs(cfg.extra, "probabilities"), cfg.spacing, spacing_zyx)
+            vol_r = ctx.alloc(int(np.prod(new_shape)) * 4)
+            try:
+                check(ctx.lib.boa_resize_skimage_f32(ctx.h, vol.vp, int3(shape), vol_r.vp, int3(new_shape), 3, ax_in),
+                      "boa_resize_skimage_f32")
+                p.predict_segmentation_device(vol_r, new_shape, d_labels, lut=lut, merge=self.multimodel, work=self._work,
+                                              shard=self.shard, resample_to=(list(shape), ax_out))
+            finally:
+                vol_r.free()
 
     def _predict_zyx_model_sharded(self, d_ct, shape, d_labels, in_dtype, vol, n):
         from . import tile_shard as ts
@@ -150,16 +171,8 @@ class SegmentationTask:
             ts.all_reduce_labels(ctx, comm, part, n)
             check(ctx.lib.boa_label_overlay(ctx.h, part.vp, n, d_labels.vp), "boa_label_overlay")
 
-    def _check_plan_spacing(self, spacing_xyz):
-        sp_zyx = [float(s) for s in spacing_xyz[::-1]]
-        for _, cfg, _, _ in self.parts:
-            if not np.allclose(sp_zyx, cfg.spacing, rtol=0, atol=1e-3):
-                raise NotImplementedError(
-                    f"{self.task_name}: image spacing (z,y,x) {sp_zyx} differs from the plans' spacing {list(cfg.spacing)}; "
-                    "nnU-Net's internal resampling (default_preprocessor.py:82-96) is not implemented on the device")
-
     # ---- one (sub-)volume, device resident ----------------------------------------------------------------------
-    def _predict_part_device(self, part_xyz: DevArray, dst_xyz: DevArray, src_lo: int, src_hi: int):
+    def _predict_part_device(self, part_xyz: DevArray, dst_xyz: DevArray, src_lo: int, src_hi: int, spacing_zyx=None):
         """`part_xyz`: (x,y,z) view of the (resampled) CT that TS would write to s0k_0000.nii.gz.  Its labels for the
         part-local z range [src_lo, src_hi) are written into `dst_xyz` (a zero-initialised (x,y,z) view of the same
         x/y extent and src_hi - src_lo slices).  nibabel reader view change, crop_to_nonzero and insert_crop_into_image
@@ -173,7 +186,7 @@ class SegmentationTask:
         crop = zyx if full else zyx.box(bbox).contiguous()
         d_lab = DevArray.empty(self.ctx, crop.shape, np.uint8)
         try:
-            self.predict_zyx_device(crop.buf, crop.shape, d_lab.buf, in_dtype=code)
+            self.predict_zyx_device(crop.buf, crop.shape, d_lab.buf, in_dtype=code, spacing_zyx=spacing_zyx)
             k0, k1 = max(bbox[0][0], src_lo), min(bbox[0][1], src_hi)
             if k0 < k1:
                 src = d_lab.slice(0, k0 - bbox[0][0], k1 - bbox[0][0]).transpose((2, 1, 0))
@@ -278,17 +291,18 @@ class SegmentationTask:
             else:
                 img_rsp = view if cast is None else own(view.contiguous(cast))
                 sp_rsp = zooms
-            self._check_plan_spacing(sp_rsp)
             ss = img_rsp.shape
+            # nnU-Net reads the spacing from the header of the file TS wrote (float32 pixdim), in array axis order (z, y, x)
+            sp_zyx = [float(np.float32(v)) for v in sp_rsp[::-1]]
             seg = own(DevArray.zeros(ctx, ss, np.uint8))
             do_split = (np.prod(ss) > NR_VOXELS_THR and ss[2] > 200 and self.multimodel) or force_split
             if do_split:
                 parts, comb = split_bounds(ss[2])
                 for (lo, hi), (dst, srcsl) in zip(parts, comb):
                     a, b, _ = srcsl.indices(hi - lo)
-                    self._predict_part_device(img_rsp.slice(2, lo, hi), seg.slice(2, dst.start, dst.stop), a, b)
+                    self._predict_part_device(img_rsp.slice(2, lo, hi), seg.slice(2, dst.start, dst.stop), a, b, sp_zyx)
             else:
-                self._predict_part_device(img_rsp, seg, 0, ss[2])
+                self._predict_part_device(img_rsp, seg, 0, ss[2], sp_zyx)
             if zoom is not None:                                         # back to the input grid (TS/nnunet.py:685-687)
                 if tuple(in_shape) != tuple(ss):
                     buf = rs.resample_nearest_device(ctx, seg.buf, ss, in_shape)

@@ -143,7 +143,7 @@ extern "C" int boa_resample_cubic(boa_ctx* c, const void* dev_in, int in_dtype, 
     double* coef = nullptr;
     BOA_TRY(boa_malloc(c, pn * sizeof(double), (void**)&coef));
     const unsigned gp = (unsigned)((pn + 255) / 256);
-    KernelTimer t(c, BOA_K_OTHER, 0, (double)pn * 8.0 * 8);
+    KernelTimer t(c, BOA_K_RESAMPLE, 0, (double)pn * 8.0 * 8);
     switch (in_dtype) {
         case 0: hipLaunchKernelGGL(k_pad_edge_f64<short>, dim3(gp), dim3(256), 0, c->stream, (const short*)dev_in, X, Y, Z, coef); break;
         case 1: hipLaunchKernelGGL(k_pad_edge_f64<float>, dim3(gp), dim3(256), 0, c->stream, (const float*)dev_in, X, Y, Z, coef); break;
@@ -173,10 +173,289 @@ extern "C" int boa_resample_nearest_u8(boa_ctx* c, const uint8_t* dev_in, const 
     BOA_REQUIRE(c && dev_in && dev_out && in_dims && out_dims, "boa_resample_nearest_u8: NULL argument");
     for (int a = 0; a < 3; ++a) BOA_REQUIRE(in_dims[a] >= 1 && out_dims[a] >= 1, "boa_resample_nearest_u8: bad dims");
     const size_t on = (size_t)out_dims[0] * out_dims[1] * out_dims[2];
-    KernelTimer t(c, BOA_K_OTHER, 0, (double)on * 2.0);
+    KernelTimer t(c, BOA_K_RESAMPLE, 0, (double)on * 2.0);
     hipLaunchKernelGGL(k_zoom_nearest_u8, dim3((unsigned)((on + 255) / 256)), dim3(256), 0, c->stream, dev_in, in_dims[0],
                        in_dims[1], in_dims[2], out_dims[0], out_dims[1], out_dims[2], zoom_factor(in_dims[0], out_dims[0]),
                        zoom_factor(in_dims[1], out_dims[1]), zoom_factor(in_dims[2], out_dims[2]), dev_out);
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+
+// ======================================================================================================
+// nnU-Net's own resampling between the image grid and the plans' spacing (NN/preprocessing/resampling/
+// default_resampling.py:113-196): skimage.transform.resize(mode="edge", anti_aliasing=False, clip=True) -- published
+// algorithm: scipy.ndimage.zoom(grid_mode=True, mode="nearest") + clip to the input's range -- either on the whole 3-D array
+// or, for anisotropic spacings ("separate z"), slice by slice in 2-D with nearest sampling along the slice axis.
+// Same fp64 operation order as the kernels above; grid_mode coordinates cc = (k + 0.5) * (n_in / n_out) - 0.5.
+
+__device__ __forceinline__ unsigned f2ord(float f) {  // order-preserving float -> uint (atomicMin / atomicMax on floats)
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+// min / max per group: group = index along `gaxis` (separate z: one slice each) or the whole volume (gaxis < 0)
+__global__ __launch_bounds__(256) void k_minmax_groups(const float* __restrict__ in, int X, int Y, int Z, int gaxis,
+                                                       unsigned* __restrict__ mm /*[groups][2], pre-set to {~0, 0}*/) {
+    const size_t n = (size_t)X * Y * Z;
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= n) return;
+    // 8 consecutive voxels along the contiguous axis; a group change inside the run can only happen when gaxis == 2
+    int cur = -1;
+    float lo = 0.f, hi = 0.f;
+    for (int k = 0; k < 8 && i0 + k < n; ++k) {
+        const size_t i = i0 + k;
+        const int z = (int)(i % Z), y = (int)((i / Z) % Y), x = (int)(i / ((size_t)Z * Y));
+        const int g = gaxis < 0 ? 0 : (gaxis == 0 ? x : (gaxis == 1 ? y : z));
+        const float v = in[i];
+        if (g != cur) {
+            if (cur >= 0) {
+                atomicMin(&mm[2 * cur], f2ord(lo));
+                atomicMax(&mm[2 * cur + 1], f2ord(hi));
+            }
+            cur = g;
+            lo = hi = v;
+        } else {
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    }
+    if (cur >= 0) {
+        atomicMin(&mm[2 * cur], f2ord(lo));
+        atomicMax(&mm[2 * cur + 1], f2ord(hi));
+    }
+}
+
+// edge padding by NPAD on the resized axes only
+__global__ __launch_bounds__(256) void k_pad_edge_axes_f64(const float* __restrict__ in, int X, int Y, int Z, int px, int py, int pz,
+                                                           double* __restrict__ out) {
+    const int PX = X + 2 * px, PY = Y + 2 * py, PZ = Z + 2 * pz;
+    const size_t n = (size_t)PX * PY * PZ;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int z = (int)(i % PZ) - pz, y = (int)((i / PZ) % PY) - py, x = (int)(i / ((size_t)PZ * PY)) - px;
+    x = min(max(x, 0), X - 1);
+    y = min(max(y, 0), Y - 1);
+    z = min(max(z, 0), Z - 1);
+    out[i] = (double)in[((size_t)x * Y + y) * Z + z];
+}
+
+struct ResizeArgs {
+    int I[3], P[3], O[3];  // input dims, padded dims, output dims
+    int act[3];            // axis is resized (spline) / is the slice axis (nearest)
+    double zf[3];          // n_in / n_out
+    int gaxis;             // clip group axis (-1: whole volume)
+};
+
+// nearest source index along the slice axis: scipy map_coordinates(order=0, mode="nearest") at scale * (o + 0.5) - 0.5
+__device__ __forceinline__ int nearest_src(int o, double scale, int n_in) {
+    const double cc = scale * ((double)o + 0.5) - 0.5;
+    return min(max((int)floor(cc + 0.5), 0), n_in - 1);
+}
+
+__global__ __launch_bounds__(256) void k_resize_cubic_f32(const double* __restrict__ coef, ResizeArgs a, const unsigned* __restrict__ mm,
+                                                          float* __restrict__ out) {
+    const size_t n = (size_t)a.O[0] * a.O[1] * a.O[2];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int o[3] = {(int)(i / ((size_t)a.O[2] * a.O[1])), (int)((i / a.O[2]) % a.O[1]), (int)(i % a.O[2])};
+    double w[3][4];
+    int st[3], nt[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (a.act[d]) {
+            cubic_weights(((double)o[d] + 0.5) * a.zf[d] - 0.5 + NPAD, &st[d], w[d]);
+            nt[d] = 4;
+        } else {
+            st[d] = a.I[d] == a.O[d] ? o[d] : nearest_src(o[d], a.zf[d], a.I[d]);
+            nt[d] = 1;
+        }
+    }
+    double t = 0.0;
+    for (int p = 0; p < nt[0]; ++p)
+        for (int q = 0; q < nt[1]; ++q) {
+            const double* row = coef + ((size_t)(st[0] + p) * a.P[1] + (st[1] + q)) * a.P[2] + st[2];
+            for (int r = 0; r < nt[2]; ++r) {
+                double cf = row[r];
+                if (a.act[0]) cf *= w[0][p];
+                if (a.act[1]) cf *= w[1][q];
+                if (a.act[2]) cf *= w[2][r];
+                t += cf;
+            }
+        }
+    // clip to the range of the input (of the source slice in separate-z mode), then `reshaped_final[c] = ...` (float64 -> float32)
+    const int g = a.gaxis < 0 ? 0 : st[a.gaxis];
+    const double lo = (double)ord2f(mm[2 * g]), hi = (double)ord2f(mm[2 * g + 1]);
+    t = t < lo ? lo : (t > hi ? hi : t);
+    out[i] = (float)t;
+}
+
+// double -> half with ONE rounding (numpy's npy_double_to_half): to float with round-to-odd, then RTNE to half
+__device__ __forceinline__ unsigned short d2h_rn(double d) {
+    float f = __double2float_rz(d);
+    if ((double)f != d) f = __uint_as_float(__float_as_uint(f) | 1u);
+    return f2us(f);
+}
+
+struct LogitsResizeArgs {
+    const unsigned short* logits;  // fp16 [C][L0][L1][L2]
+    int C, L[3], off[3], I[3], O[3];  // full grid, crop origin, crop dims (= resampled shape), output dims
+    int act[3];
+    double zf[3];
+    int merge;
+    unsigned char lut[256];
+};
+
+// resampling_fn_probabilities (order 1) of every class at one output voxel + fp16 rounding + numpy argmax + lut / merge
+__global__ __launch_bounds__(256) void k_resize_logits_argmax(LogitsResizeArgs a, unsigned char* __restrict__ labels) {
+    const size_t n = (size_t)a.O[0] * a.O[1] * a.O[2];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int o[3] = {(int)(i / ((size_t)a.O[2] * a.O[1])), (int)((i / a.O[2]) % a.O[1]), (int)(i % a.O[2])};
+    double w[3][2];
+    int i0[3], i1[3], nt[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (a.act[d]) {
+            const double cc = ((double)o[d] + 0.5) * a.zf[d] - 0.5;  // not clamped: the tap INDICES are (mode "nearest")
+            const double fl = floor(cc);
+            const double x = cc - fl;
+            w[d][0] = 1.0 - x;
+            w[d][1] = x;
+            i0[d] = min(max((int)fl, 0), a.I[d] - 1);
+            i1[d] = min(max((int)fl + 1, 0), a.I[d] - 1);
+            nt[d] = 2;
+        } else {
+            i0[d] = i1[d] = a.I[d] == a.O[d] ? o[d] : nearest_src(o[d], a.zf[d], a.I[d]);
+            nt[d] = 1;
+        }
+    }
+    const size_t lv = (size_t)a.L[0] * a.L[1] * a.L[2];
+    float best = 0.f;
+    int bidx = 0;
+    bool bnan = false;
+    for (int c = 0; c < a.C; ++c) {
+        const unsigned short* base = a.logits + (size_t)c * lv;
+        double t = 0.0;
+        for (int p = 0; p < nt[0]; ++p)
+            for (int q = 0; q < nt[1]; ++q)
+                for (int r = 0; r < nt[2]; ++r) {
+                    const int x = (p ? i1[0] : i0[0]) + a.off[0], y = (q ? i1[1] : i0[1]) + a.off[1], z = (r ? i1[2] : i0[2]) + a.off[2];
+                    double cf = (double)us2f(base[((size_t)x * a.L[1] + y) * a.L[2] + z]);
+                    if (a.act[0]) cf *= w[0][p];
+                    if (a.act[1]) cf *= w[1][q];
+                    if (a.act[2]) cf *= w[2][r];
+                    t += cf;
+                }
+        const float f = us2f(d2h_rn(t));  // `reshaped_final` has the logits' dtype: float16
+        const bool isn = f != f;
+        if (c == 0) {
+            best = f;
+            bnan = isn;
+        } else if (!bnan && (isn || f > best)) {
+            best = f;
+            bidx = c;
+            bnan = isn;
+        }
+    }
+    if (a.merge) {
+        if (bidx != 0) labels[i] = a.lut[bidx];
+    } else {
+        labels[i] = a.lut[bidx];
+    }
+}
+
+static int resize_axes(const int in_dims[3], const int out_dims[3], int slice_axis, ResizeArgs* a) {
+    for (int d = 0; d < 3; ++d) {
+        a->I[d] = in_dims[d];
+        a->O[d] = out_dims[d];
+        a->act[d] = d != slice_axis;
+        a->P[d] = in_dims[d] + (a->act[d] ? 2 * NPAD : 0);
+        a->zf[d] = (double)in_dims[d] / (double)out_dims[d];
+    }
+    a->gaxis = slice_axis;
+    return BOA_OK;
+}
+
+extern "C" int boa_resize_skimage_f32(boa_ctx* c, const float* dev_in, const int in_dims[3], float* dev_out, const int out_dims[3],
+                                      int order, int slice_axis) {
+    BOA_REQUIRE(c && dev_in && dev_out && in_dims && out_dims, "boa_resize_skimage_f32: NULL argument");
+    BOA_REQUIRE(order == 3, "boa_resize_skimage_f32: order %d (image data is resampled with order 3)", order);
+    BOA_REQUIRE(slice_axis >= -1 && slice_axis <= 2, "boa_resize_skimage_f32: slice_axis %d", slice_axis);
+    for (int a = 0; a < 3; ++a) BOA_REQUIRE(in_dims[a] >= 1 && out_dims[a] >= 1, "boa_resize_skimage_f32: bad dims");
+    for (int a = 0; a < 3; ++a) BOA_REQUIRE(a == slice_axis || in_dims[a] >= 2, "boa_resize_skimage_f32: a resized axis needs >= 2 samples");
+    ResizeArgs ra;
+    resize_axes(in_dims, out_dims, slice_axis, &ra);
+    const size_t pn = (size_t)ra.P[0] * ra.P[1] * ra.P[2];
+    const size_t in_n = (size_t)in_dims[0] * in_dims[1] * in_dims[2];
+    const int groups = slice_axis < 0 ? 1 : in_dims[slice_axis];
+    double* coef = nullptr;
+    unsigned* mm = nullptr;
+    BOA_TRY(boa_malloc(c, pn * sizeof(double), (void**)&coef));
+    int rc = boa_malloc(c, (size_t)groups * 2 * sizeof(unsigned), (void**)&mm);
+    if (rc) {
+        boa_free(c, coef);
+        return rc;
+    }
+    std::vector<unsigned> init((size_t)groups * 2);
+    for (int g = 0; g < groups; ++g) {
+        init[2 * g] = 0xffffffffu;
+        init[2 * g + 1] = 0u;
+    }
+    hipMemcpyAsync(mm, init.data(), init.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream);
+    hipStreamSynchronize(c->stream);  // `init` is a host temporary
+    c->prof_break = true;
+    KernelTimer t(c, BOA_K_RESAMPLE, 0, (double)pn * 8.0 * 6 + (double)in_n * 8.0);
+    hipLaunchKernelGGL(k_minmax_groups, dim3((unsigned)((in_n / 8 + 256) / 256)), dim3(256), 0, c->stream, dev_in, in_dims[0], in_dims[1],
+                       in_dims[2], slice_axis, mm);
+    hipLaunchKernelGGL(k_pad_edge_axes_f64, dim3((unsigned)((pn + 255) / 256)), dim3(256), 0, c->stream, dev_in, in_dims[0], in_dims[1],
+                       in_dims[2], (ra.P[0] - ra.I[0]) / 2, (ra.P[1] - ra.I[1]) / 2, (ra.P[2] - ra.I[2]) / 2, coef);
+    // scipy filters the axes in ascending order; the slice axis of the separate-z mode is not filtered
+    const size_t s0 = (size_t)ra.P[1] * ra.P[2], s1 = (size_t)ra.P[2], s2 = 1;
+    if (ra.act[0])
+        hipLaunchKernelGGL(k_spline_filter_axis, dim3((unsigned)(((size_t)ra.P[1] * ra.P[2] + 63) / 64)), dim3(64), 0, c->stream, coef, ra.P[0],
+                           s0, ra.P[1], s1, ra.P[2], s2, spline_consts(ra.P[0]));
+    if (ra.act[1])
+        hipLaunchKernelGGL(k_spline_filter_axis, dim3((unsigned)(((size_t)ra.P[0] * ra.P[2] + 63) / 64)), dim3(64), 0, c->stream, coef, ra.P[1],
+                           s1, ra.P[0], s0, ra.P[2], s2, spline_consts(ra.P[1]));
+    if (ra.act[2])
+        hipLaunchKernelGGL(k_spline_filter_axis, dim3((unsigned)(((size_t)ra.P[0] * ra.P[1] + 63) / 64)), dim3(64), 0, c->stream, coef, ra.P[2],
+                           s2, ra.P[0], s0, ra.P[1], s1, spline_consts(ra.P[2]));
+    const size_t on = (size_t)out_dims[0] * out_dims[1] * out_dims[2];
+    hipLaunchKernelGGL(k_resize_cubic_f32, dim3((unsigned)((on + 255) / 256)), dim3(256), 0, c->stream, coef, ra, mm, dev_out);
+    t.stop();
+    hipError_t e = hipGetLastError();
+    rc = boa_free(c, coef);  // synchronises the stream
+    boa_free(c, mm);
+    BOA_HIP_TRY(e);
+    return rc;
+}
+
+extern "C" int boa_resize_logits_argmax(boa_ctx* c, const uint16_t* dev_logits, int C, const int grid_dims[3], const int* crop_off,
+                                        const int* crop_dims, const int out_dims[3], int slice_axis, const uint8_t* host_lut,
+                                        int merge, uint8_t* dev_labels_out) {
+    BOA_REQUIRE(c && dev_logits && grid_dims && out_dims && dev_labels_out, "boa_resize_logits_argmax: NULL argument");
+    BOA_REQUIRE(C >= 1 && C <= 255, "boa_resize_logits_argmax: C=%d out of range", C);
+    BOA_REQUIRE(slice_axis >= -1 && slice_axis <= 2, "boa_resize_logits_argmax: slice_axis %d", slice_axis);
+    LogitsResizeArgs a;
+    a.logits = dev_logits;
+    a.C = C;
+    a.merge = merge;
+    for (int d = 0; d < 3; ++d) {
+        a.L[d] = grid_dims[d];
+        a.off[d] = crop_off ? crop_off[d] : 0;
+        a.I[d] = crop_dims ? crop_dims[d] : grid_dims[d];
+        a.O[d] = out_dims[d];
+        BOA_REQUIRE(a.off[d] >= 0 && a.I[d] >= 1 && a.off[d] + a.I[d] <= a.L[d] && a.O[d] >= 1, "boa_resize_logits_argmax: bad geometry on axis %d", d);
+        a.act[d] = d != slice_axis;
+        a.zf[d] = (double)a.I[d] / (double)a.O[d];
+    }
+    for (int i = 0; i < 256; ++i) a.lut[i] = host_lut ? host_lut[i] : (unsigned char)i;
+    const size_t on = (size_t)out_dims[0] * out_dims[1] * out_dims[2];
+    KernelTimer t(c, BOA_K_ARGMAX, 0, (double)on * (2.0 * C + 1.0));
+    hipLaunchKernelGGL(k_resize_logits_argmax, dim3((unsigned)((on + 255) / 256)), dim3(256), 0, c->stream, a, dev_labels_out);
     t.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

@@ -64,8 +64,12 @@ int boa_timer_stop(boa_ctx* ctx, int slot, float* ms_out);
 #define BOA_K_NORM_FINALIZE 3
 #define BOA_K_HEAD_ACCUM 4
 #define BOA_K_ARGMAX 5
-#define BOA_K_OTHER 6
-#define BOA_K_COUNT 7
+#define BOA_K_OTHER 6      /* memset, CTNormalization */
+#define BOA_K_AGG 7        /* tissue map / slice tables / label histograms / masks / erosion (agg.hip) */
+#define BOA_K_MORPH 8      /* connected components, contour fill, median (morph.hip) */
+#define BOA_K_RESAMPLE 9   /* cubic / nearest resampling (resample.hip) */
+#define BOA_K_COPY 10      /* boa_copy3 index remaps (reorientation, transposes, crops) */
+#define BOA_K_COUNT 11
 int boa_prof_enable(boa_ctx* ctx, int on);
 int boa_prof_reset(boa_ctx* ctx);
 int boa_prof_get(boa_ctx* ctx, int kclass, double* total_ms, long long* launches, double* flops, double* bytes);
@@ -336,6 +340,26 @@ int boa_resample_cubic(boa_ctx* ctx, const void* dev_in, int in_dtype, const int
 /* order 0 (labels back to the original grid, TS/nnunet.py:685-687): index floor(out * (n_in-1)/(n_out-1) + 0.5). */
 int boa_resample_nearest_u8(boa_ctx* ctx, const uint8_t* dev_in, const int in_dims[3], uint8_t* dev_out,
                             const int out_dims[3]);
+
+
+/* ------------------------------------------------------------------ nnU-Net's own resampling to / from the plans' spacing --- */
+/* resampling_fn_data (NN/preprocessing/preprocessors/default_preprocessor.py:82-93 -> NN/preprocessing/resampling/
+ * default_resampling.py:113-196, is_seg False, order 3, order_z 0): skimage.transform.resize(mode="edge",
+ * anti_aliasing=False, clip=True) restated from its published algorithm (scipy.ndimage.zoom(grid_mode=True,
+ * mode="nearest") + clip to the input's range; skimage itself is absent from the build image: unpinned) in fp64, result
+ * cast to float32.  slice_axis = -1: one 3-D resize; 0..2 ("separate z", anisotropic spacing): every slice along that axis
+ * is resized in 2-D (clip range per slice) and the axis itself is sampled nearest (map_coordinates order 0) when its
+ * extent changes.  in / out: dev fp32 [d0][d1][d2].  Synchronous (frees its fp64 scratch). */
+int boa_resize_skimage_f32(boa_ctx* ctx, const float* dev_in, const int in_dims[3], float* dev_out, const int out_dims[3],
+                           int order, int slice_axis);
+/* resampling_fn_probabilities + argmax (NN/inference/export_prediction.py:25-47): the (fold-mean) fp16 logits
+ * [C][grid_dims], of which the box crop_off / crop_dims is the network's output for the resampled image (pad_nd_image
+ * reverted), are resampled with order 1 to out_dims (slice_axis as above), rounded to fp16 (the reference's result array
+ * has the logits' dtype) and reduced with numpy's argmax semantics; lut / merge as boa_finalize_labels.  The [C][out_dims]
+ * tensor is never materialised.  (skimage's clip is a no-op for order 1 up to one fp64 rounding and is not applied.) */
+int boa_resize_logits_argmax(boa_ctx* ctx, const uint16_t* dev_logits, int C, const int grid_dims[3], const int* crop_off,
+                             const int* crop_dims, const int out_dims[3], int slice_axis, const uint8_t* host_lut, int merge,
+                             uint8_t* dev_labels_out);
 
 #ifdef __cplusplus
 }

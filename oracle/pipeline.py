@@ -29,18 +29,31 @@ def predict_total(ct_xyz, part_models, class_map_inv, step_size=0.8):
     return np.ascontiguousarray(comb.transpose(2, 1, 0))
 
 
-def predict_part(data_xyz, models, class_map_inv, step_size, multimodel):
-    """One s0k_0000 sub-volume through every model (TS/nnunet.py:536-559 or :566-573)."""
+def predict_part(data_xyz, models, class_map_inv, step_size, multimodel, spacing_xyz=None):
+    """One s0k_0000 sub-volume through every model (TS/nnunet.py:536-559 or :566-573).  A model entry may carry a sixth
+    element, its plans' spacing (z, y, x): when it differs from the image's, nnU-Net resamples the normalised crop to the
+    plans' grid (order 3) and the fold-mean logits back (order 1) before the argmax (default_preprocessor.py:82-93,
+    export_prediction.py:25-33; oracle/nnunet_resample.py)."""
+    from . import nnunet_resample as nnr
     data = np.ascontiguousarray(data_xyz.transpose(2, 1, 0))[None].astype(np.float32)
     bbox = labels.nonzero_bbox(data)
     sl = tuple(slice(a, b) for a, b in bbox)
     crop = data[(slice(None),) + sl]
     segs, maps = [], []
-    for fns, patch, heads, ip, pmap in models:
+    for entry in models:
+        fns, patch, heads, ip, pmap = entry[:5]
+        plan_sp = entry[5] if len(entry) > 5 else None
         fns = fns if isinstance(fns, (list, tuple)) else [fns]
         x = labels.ct_normalize(crop[0], ip["mean"], ip["std"], ip["percentile_00_5"], ip["percentile_99_5"])[None]
+        shape = x.shape[1:]
+        sp_zyx = None if spacing_xyz is None else [float(v) for v in list(spacing_xyz)[::-1]]
+        new_shape = shape if (plan_sp is None or sp_zyx is None) else tuple(nnr.compute_new_shape(shape, sp_zyx, plan_sp))
+        if tuple(new_shape) != tuple(shape):
+            x = nnr.resample_to_shape(x, new_shape, sp_zyx, plan_sp, order=3).astype(np.float32)
         lg = sw.ensemble_folds([sw.predict_sliding_window_return_logits(fn, x, list(patch), heads, step_size)
                                 for fn in fns])
+        if tuple(new_shape) != tuple(shape):
+            lg = nnr.resample_to_shape(lg, shape, plan_sp, sp_zyx, order=1)
         seg = np.zeros(data.shape[1:], dtype=np.uint8)
         seg[sl] = labels.argmax_labels(lg)
         segs.append(seg)
@@ -64,17 +77,18 @@ def predict_image(ct_xyz, spacing_xyz, models, class_map_inv=None, task_name="to
         img, zoom = ct_xyz, None
     step = 0.8 if (task_name == "total" and rsp is not None and rsp[0] < 3.0) else 0.5
     ss = img.shape
+    sp_now = [float(v) for v in (rsp if rsp is not None else spacing)]
     if (np.prod(ss) > 512 * 512 * 900 and ss[2] > 200 and multimodel) or force_split:
         third, margin = ss[2] // 3, 20
-        p1 = predict_part(img[:, :, :third + margin], models, class_map_inv, step, multimodel)
-        p2 = predict_part(img[:, :, third + 1 - margin:third * 2 + margin], models, class_map_inv, step, multimodel)
-        p3 = predict_part(img[:, :, third * 2 + 1 - margin:], models, class_map_inv, step, multimodel)
+        p1 = predict_part(img[:, :, :third + margin], models, class_map_inv, step, multimodel, sp_now)
+        p2 = predict_part(img[:, :, third + 1 - margin:third * 2 + margin], models, class_map_inv, step, multimodel, sp_now)
+        p3 = predict_part(img[:, :, third * 2 + 1 - margin:], models, class_map_inv, step, multimodel, sp_now)
         seg = np.zeros(ss, dtype=np.uint8)
         seg[:, :, :third] = p1[:, :, :-margin]
         seg[:, :, third:third * 2] = p2[:, :, margin - 1:-margin]
         seg[:, :, third * 2:] = p3[:, :, margin - 1:]
     else:
-        seg = predict_part(img, models, class_map_inv, step, multimodel)
+        seg = predict_part(img, models, class_map_inv, step, multimodel, sp_now)
     if rsp is not None and zoom is not None:
         seg, _ = orsp.change_spacing_array(seg, rsp, rsp, target_shape=ct_xyz.shape, order=0, dtype=np.uint8)
     return seg

@@ -440,13 +440,61 @@ def g12_cropping():
     save_npz("g12_cropping.npz", **out)
 
 
+# ---------------------------------------------------------------------------------------------- G13
+def g13_nnunet_resampling():
+    """The reference's own resample_data_or_seg_to_shape (NN/preprocessing/resampling/default_resampling.py:83-196) and its
+    helpers, executed with `skimage.transform.resize` (absent here) replaced by the oracle's restatement of its published
+    algorithm (oracle/nnunet_resample.py:skimage_resize = scipy.ndimage.zoom(grid_mode=True, mode="nearest") + clip).  Pins
+    the axis choice, the per-slice loop, the nearest sampling along the anisotropic axis and the dtypes -- NOT skimage."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.nnunet_resample import skimage_resize
+    import nnunetv2.preprocessing.resampling.default_resampling as dr
+
+    def resize(image, output_shape, order=None, mode="reflect", anti_aliasing=None, **kw):
+        assert mode == "edge" and anti_aliasing is False and not kw, (mode, anti_aliasing, kw)
+        return skimage_resize(image, output_shape, order)
+    dr.resize = resize
+    rng = np.random.default_rng(13)
+    out = {}
+    cases = [  # (name, data shape, dtype, current spacing, new spacing, order)
+        ("iso3d", (1, 14, 18, 16), np.float32, (1.5, 1.5, 1.5), (1.2, 1.0, 1.4), 3),
+        ("sepz_same_z", (1, 6, 20, 22), np.float32, (5.0, 0.8, 0.8), (5.0, 1.0, 0.9), 3),
+        ("sepz_new_z", (1, 7, 20, 18), np.float32, (5.0, 0.8, 0.8), (3.0, 1.0, 1.0), 3),
+        ("logits_back", (3, 9, 16, 17), np.float16, (5.0, 1.0, 0.9), (5.0, 0.8, 0.8), 1),
+        ("logits_iso", (4, 12, 10, 11), np.float16, (1.0, 1.0, 1.0), (1.5, 1.5, 1.5), 1),
+        ("new_aniso", (1, 20, 16, 16), np.float32, (1.0, 1.0, 1.0), (4.0, 1.0, 1.0), 3),
+        ("identity", (1, 8, 9, 10), np.float32, (1.5, 1.5, 1.5), (1.5, 1.5, 1.5), 3),
+    ]
+    names = []
+    for name, shp, dt, cur, new, order in cases:
+        d = (rng.standard_normal(shp) * 3).astype(dt)
+        new_shape = dr.compute_new_shape(shp[1:], cur, new)
+        sep, axis = dr.determine_do_sep_z_and_axis(None, cur, new)
+        res = dr.resample_data_or_seg_to_shape(d, new_shape, cur, new, is_seg=False, order=order, order_z=0, force_separate_z=None)
+        assert res.dtype == dt
+        out[f"{name}_in"] = d.view(np.uint16) if dt == np.float16 else d
+        out[f"{name}_out"] = res.view(np.uint16) if dt == np.float16 else res
+        out[f"{name}_meta"] = np.array([*cur, *new, order, int(sep), -1 if axis is None else int(axis), *new_shape], dtype=np.float64)
+        names.append(name)
+    out["names"] = np.array(names)
+    # decision table of determine_do_sep_z_and_axis / compute_new_shape on awkward spacings
+    tab = []
+    for cur, new in [((5.0, 0.78, 0.78), (5.0, 0.8, 0.8)), ((0.24, 1.25, 1.25), (1.0, 1.0, 1.0)), ((3.0, 1.0, 1.0), (1.0, 1.0, 1.0)),
+                     ((3.01, 1.0, 1.0), (1.0, 1.0, 1.0)), ((1.0, 1.0, 1.0), (1.0, 1.0, 6.0)), ((2.0, 2.0, 2.0), (2.0, 2.0, 2.0)),
+                     ((1.5, 0.5, 1.5), (1.0, 1.0, 1.0)), ((0.7, 0.7, 5.0), (0.7, 0.7, 5.0))]:
+        sep, axis = dr.determine_do_sep_z_and_axis(None, cur, new)
+        tab.append([*cur, *new, int(sep), -1 if axis is None else int(axis), *dr.compute_new_shape((37, 201, 199), cur, new)])
+    out["decisions"] = np.array(tab, dtype=np.float64)
+    save_npz("g13_nnunet_resampling.npz", **out)
+
+
 if __name__ == "__main__":
     ct = load_example_ct()
     print("example ct", ct.shape, ct.dtype, ct.min(), ct.max())
     only = sys.argv[1:]
     fns = dict(g1=g1_steps, g2=g2_gaussian, g3=g3_sliding_window, g3b=g3b_fold_ensemble, g4=lambda: g4_ctnorm(ct),
                g5=lambda: g5_resample(ct), g67=g67_argmax_merge, g10=g10_config, g9=g9_measurements, g8=g8_bca,
-               g11=g11_measurement_label_maps, g12=g12_cropping)
+               g11=g11_measurement_label_maps, g12=g12_cropping, g13=g13_nnunet_resampling)
     for k, f in fns.items():
         if not only or k in only:
             f()

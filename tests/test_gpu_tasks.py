@@ -107,15 +107,6 @@ def test_bca_nets_thickness_resampling_5_folds(ctx):
     assert agree >= 0.97
 
 
-def test_plan_spacing_mismatch_raises(ctx):
-    from boa_hip.task import SegmentationTask
-    m, _ = _model(542, 4, 1, (5.0, 1.0, 1.0))
-    t = SegmentationTask(ctx, "body_regions", [m], resample=5.0, resample_only_thickness=True)
-    with pytest.raises(NotImplementedError):
-        t.predict_image(_ct((34, 34, 40), 4), np.diag([0.8, 0.8, 2.0, 1.0]))
-    t.close()
-
-
 def test_bca_pipeline_vs_oracle_composition(ctx):
     """run_pipeline numerics: nets (fast_bca: 1 fold) -> CC / contour-fill post-processing -> tissues -> LPS reload ->
     body-part detection, vertebra ranges, bca-measurements JSON.  The raw network labels are shared with the oracle

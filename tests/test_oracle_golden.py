@@ -196,3 +196,43 @@ def test_g12_cropping_helpers():
             want.append([0, mask.shape[ax]] if nz.size == 0 else [int(nz[0]), int(nz[-1]) + 1])
         assert labels.nonzero_bbox(d) == want, j
         assert task.nonzero_bbox(d[0]) == want, j        # binary_fill_holes cannot change the bounding box
+
+
+def test_g13_nnunet_resampling():
+    """The reference's resample_data_or_seg_to_shape / determine_do_sep_z_and_axis / compute_new_shape (executed with the
+    restated skimage resize, see make_golden.g13) against the oracle and the product's host logic."""
+    from boa_hip import nnunet_resample as hnr
+    from oracle import nnunet_resample as nnr
+    z = _npz("g13_nnunet_resampling.npz")
+    for name in z["names"]:
+        meta = z[f"{name}_meta"]
+        cur, new, order, sep, axis, new_shape = meta[:3], meta[3:6], int(meta[6]), bool(meta[7]), int(meta[8]), [int(v) for v in meta[9:12]]
+        f16 = z[f"{name}_in"].dtype == np.uint16
+        d = z[f"{name}_in"].view(np.float16) if f16 else z[f"{name}_in"]
+        want = z[f"{name}_out"]
+        assert list(nnr.compute_new_shape(d.shape[1:], cur, new)) == new_shape == hnr.compute_new_shape(d.shape[1:], cur, new)
+        for mod in (nnr, hnr):
+            s, a = mod.determine_do_sep_z_and_axis(None, cur, new)
+            assert (bool(s), -1 if a is None else a) == (sep, axis), (name, mod.__name__)
+        for fn in (nnr.skimage_resize, nnr.skimage_resize_explicit):
+            got = nnr.resample_to_shape(d, new_shape, cur, new, order=order, resize_fn=fn)
+            assert got.dtype == d.dtype
+            np.testing.assert_array_equal(got.view(np.uint16) if f16 else got, want, err_msg=f"{name} {fn.__name__}")
+    for row in z["decisions"]:
+        cur, new = row[:3], row[3:6]
+        for mod in (nnr, hnr):
+            s, a = mod.determine_do_sep_z_and_axis(None, cur, new)
+            assert [int(s), -1 if a is None else a] == [int(row[6]), int(row[7])]
+            assert [int(v) for v in mod.compute_new_shape((37, 201, 199), cur, new)] == [int(v) for v in row[8:11]]
+
+
+def test_skimage_resize_restatement_matches_scipy_grid_mode():
+    """`skimage_resize_explicit` (blueprint of csrc/resample.hip k_resize_*) == scipy.ndimage.zoom(grid_mode=True,
+    mode="nearest") + clip, bit for bit, 2-D and 3-D, order 1 and 3, up- and down-sampling."""
+    from oracle import nnunet_resample as nnr
+    rng = np.random.default_rng(3)
+    for shp, osh in [((20, 17, 23), (25, 17, 30)), ((20, 17, 23), (13, 11, 9)), ((16, 31), (40, 20)), ((33, 18), (12, 27)),
+                     ((9, 9, 9), (9, 14, 9)), ((5, 7), (50, 3))]:
+        d = rng.standard_normal(shp) * 50
+        for order in (1, 3):
+            np.testing.assert_array_equal(nnr.skimage_resize_explicit(d, osh, order), nnr.skimage_resize(d, osh, order))
