@@ -1,0 +1,148 @@
+"""BASELINE.json `configs` as -m gpu tests (synthetic weights of the documented geometries):
+  configs[0]  128^3 CT, `--models total --fast-total` (Dataset297 at 3 mm) through the file-level drop-in surface, against
+              the oracle pipeline (torch-CPU fp32 net) -- includes the pad_nd_image path (resampled volume thinner than the patch)
+  configs[2]  512x512x768 `total+bca` on one GPU: runs, is reproducible bit for bit, tables are consistent
+  configs[4]  512x512x1024 `total`: the reference's triple z-split at full size -- the middle third of the result equals
+              the middle part predicted on its own
+  configs[3]  (8 volumes on 8 GPUs) is the bench's volume-sharded mode: covered by tests/test_distributed_cpu.py and the
+              RCCL tests of test_gpu_tile_shard.py, which skip on a one-GPU box.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from boa_hip.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def test_config0_total_fast_128_dropin_vs_oracle(tmp_path, monkeypatch):
+    """`compute_all_models(ct, folder, "total", {"fast": True})`: one model (Dataset297), resample 3.0, step 0.5
+    (TS/nnunet.py:507-514: only `total` below 3 mm uses 0.8), single-model task (no part merge, labels = argmax)."""
+    import torch
+    from boa_hip import label_maps, model_store, nifti, plans
+    from boa_hip.compute.inference import compute_all_models
+    from boa_hip.synthetic import ct_phantom
+    from oracle import pipeline as opipe
+    from oracle.network import build_from_arch, network_fn_from_module
+    root = tmp_path / "results"
+    pj, dj = plans.synthetic_plans(patch=(64, 96, 64), features=(32, 64, 128), num_classes=118, spacing=(3.0, 3.0, 3.0))
+    cfg = plans.model_config_from_plans(pj, dj)
+    sd = plans.synthetic_state_dict(cfg.geometry, seed=297)
+    model_store.write_model_folder(str(root), 297, "TotalSegmentator_3mm", "nnUNetTrainer_4000epochs_NoMirroring", pj, dj, [sd])
+    monkeypatch.setenv("nnUNet_results", str(root))
+    ct = ct_phantom((128, 128, 128), seed=1)
+    aff = np.diag([1.5, 1.5, 1.5, 1.0])
+    ct_path = tmp_path / "ct.nii.gz"
+    nifti.save(ct_path, ct, aff)
+    out = tmp_path / "seg"
+    params = {"preview": False, "fast": True, "ml": True, "nr_thr_resamp": 1, "nr_thr_saving": 1, "quiet": True, "verbose": False,
+              "device": "gpu", "license_number": None}
+    stats = compute_all_models(ct_path, out, "total", params)
+    assert stats == {"num_voxels": 128 ** 3, "num_slices": 128, "num_slices_resampled": 128}
+    got, gaff, hdr = nifti.load(out / "total.nii.gz")
+    assert got.shape == ct.shape and got.dtype == np.uint8 and np.allclose(gaff, aff)
+    assert nifti.parse_label_xml(hdr.extensions[0][1]) == label_maps.CLASS_MAP_TOTAL
+    assert (out / "total-measurements.json").is_file()
+    net = build_from_arch(pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"], 1, 118)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    omodel = (network_fn_from_module(net, 8), (64, 96, 64), 118, cfg.intensity_properties["0"], None)
+    want = opipe.predict_image(ct, (1.5, 1.5, 1.5), [omodel], None, "total", 3.0, multimodel=False)
+    agree = float((got == want).mean())
+    print("configs[0] total_fast 128^3 label agreement with the oracle pipeline", agree, "labels", len(np.unique(got)))
+    assert agree >= 0.99            # 118 classes of a random-weight fp16 net; every other step is exact
+
+
+def _bca_models(folds):
+    from boa_hip import plans
+    out = {}
+    for name, nc, seed in (("body_parts", 7, 543), ("body_regions", 12, 542)):
+        pj, dj = plans.synthetic_plans(num_classes=nc, spacing=(5.0, 1.5, 1.5))
+        cfg = plans.model_config_from_plans(pj, dj)
+        out[name] = (cfg, [plans.weight_blob_from_state_dict(cfg.geometry, plans.synthetic_state_dict(cfg.geometry, seed + f))
+                           for f in range(folds)])
+    return out
+
+
+def test_config2_total_bca_512x512x768(ctx):
+    """configs[2]: whole-body 512x512x768 @1.5 mm, `total` (1 000 tile forwards) + `bca` (fast_bca: one fold per net at 5 mm
+    slices -- the 5-fold arithmetic is covered at small size) + total measurements on one GPU.  Properties: two runs agree
+    bit for bit (labels and tables), every table is consistent with the label volumes it summarises."""
+    from boa_hip import label_maps, synthetic
+    from boa_hip import measurements as M
+    from boa_hip.devarray import DevArray
+    from boa_hip.pipeline import BcaPipelineHip
+    from boa_hip.totalseg import TotalSegmentatorHip
+    shape = (512, 512, 768)
+    ct = synthetic.ct_phantom(shape, seed=3)
+    aff = np.diag([-1.5, -1.5, 1.5, 1.0])
+    ts = TotalSegmentatorHip(ctx, [(tid, cfg, [blob]) for tid, cfg, blob, _ in synthetic.total_part_models()])
+    bm = _bca_models(1)
+    pipe = BcaPipelineHip(ctx, bm["body_parts"], bm["body_regions"], fast_bca=True)
+    runs = []
+    for _ in range(2):
+        total = ts.predict(ct, affine=aff)
+        out = pipe.run(ct, aff, total_seg=total)
+        runs.append((total, out))
+    ts.close()
+    pipe.close()
+    (t0, o0), (t1, o1) = runs
+    assert t0.shape == shape and t0.dtype == np.uint8 and len(np.unique(t0)) > 20
+    np.testing.assert_array_equal(t0, t1)
+    for k in ("body_parts", "body_regions", "tissues"):
+        np.testing.assert_array_equal(o0[k], o1[k])
+    assert o0["bca_measurements"] == o1["bca_measurements"]
+    # tables vs volumes: per-slice tissue volumes sum to the voxel counts of the tissue map
+    js = o0["bca_measurements"]
+    ml = 1.5 ** 3 / 1000.0
+    tis = o0["tissues"]
+    slices = js["slices"]
+    assert len(slices) == shape[2]
+    for name, val in (("muscle", 1), ("bone", 2)):
+        tot = sum(s[name] for s in slices) if name in slices[0] else None
+        if tot is not None:
+            assert abs(tot - float((tis == val).sum()) * ml) <= 1e-6 * max(tot, 1.0)
+    # per-label HU statistics: the voxel counts of `total-measurements` equal numpy's
+    lm = label_maps.measurement_label_map("total")
+    d_f = DevArray.from_numpy(ctx, ct)
+    d_ct = d_f.transpose((2, 1, 0)).contiguous(np.int16, force_copy=True)
+    d_s = DevArray.from_numpy(ctx, t0)
+    d_lab = d_s.transpose((2, 1, 0)).contiguous(force_copy=True)
+    meas, _ = M.total_measurements(ctx, None, None, lm, (1.5, 1.5, 1.5), d_ct=d_ct.buf, d_lab=d_lab.buf, shape=d_ct.shape)
+    for a in (d_f, d_ct, d_s, d_lab):
+        a.free()
+    counts = np.bincount(t0.ravel(), minlength=256)
+    seg = meas["segmentations"]["total"]
+    for name, lab in list(lm.items())[:40]:
+        if counts[lab]:
+            assert seg[name]["present"] and abs(seg[name]["volume_ml"] - counts[lab] * ml) <= 1e-9 * counts[lab] * ml
+        else:
+            assert not seg[name]["present"]
+
+
+def test_config4_triple_split_512x512x1024(ctx):
+    """configs[4] shape: 268 M voxels > 512*512*900 and z > 200 trigger the reference's triple z-split for the multi-model
+    `total` task (TS/nnunet.py:489-505, recombination :583-586): 3 x 100 tiles per model = 1 500 tile forwards.  The
+    middle third of the result must equal the middle part predicted on its own (split bookkeeping at full size)."""
+    from boa_hip import synthetic
+    from boa_hip.task import split_bounds
+    from boa_hip.totalseg import TotalSegmentatorHip
+    shape = (512, 512, 1024)
+    ct = synthetic.ct_phantom(shape, seed=4)
+    ct[:, :, 0] = 7                       # nothing to crop: the border planes are non-zero
+    aff = np.diag([1.5, 1.5, 1.5, 1.0])
+    ts = TotalSegmentatorHip(ctx, [(tid, cfg, [blob]) for tid, cfg, blob, _ in synthetic.total_part_models()])
+    seg = ts.predict(ct, affine=aff)
+    assert seg.shape == shape and len(np.unique(seg)) > 20
+    parts, comb = split_bounds(shape[2])
+    assert parts == [(0, 361), (322, 702), (663, 1024)]
+    lo, hi = parts[1]
+    mid = ts.predict(np.ascontiguousarray(ct[:, :, lo:hi]), affine=aff)
+    ts.close()
+    dst, src = comb[1]
+    np.testing.assert_array_equal(seg[:, :, dst], mid[:, :, src])
