@@ -231,6 +231,9 @@ def main():
                 t.shard = ts.TileShard(comm, args.shard_mode)
             else:
                 t.model_shard = comm
+        if pipe is not None:      # the aggregation half of a shared volume runs per z-slab (boa_hip/agg_shard.py)
+            from boa_hip import agg_shard as ag
+            pipe.agg = (ag.AggComm(dist, rank, world), comm)
     shared = comm is not None                                            # all ranks work on the same volume
     ct = synthetic.ct_phantom(shape, seed=20260928 + (0 if shared else rank))   # file array (x, y, z), int16 HU
     affine = np.diag([-1.5, -1.5, 1.5, 1.0])                             # an LPS file @1.5 mm: exercises the canonicalisation

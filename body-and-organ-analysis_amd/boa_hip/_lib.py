@@ -81,6 +81,9 @@ _PROTOS = {
     "boa_ccl26": (i32, [vp, vp, i32, i32, i32, vp, vp, ip]),
     "boa_ccl_filter_largest": (i32, [vp, vp, vp, u64, vp, i32]),
     "boa_ccl_remove_small": (i32, [vp, vp, vp, u64, C.c_uint32, vp]),
+    "boa_ccl_list_components": (i32, [vp, vp, u64, i32, vp, vp, ip]),
+    "boa_scatter_u32": (i32, [vp, vp, vp, vp, i32]),
+    "boa_ccl_fill_unmarked": (i32, [vp, vp, vp, u64, C.c_uint32, vp, i32]),
     "boa_label_select": (i32, [vp, vp, u64, i32, ip, vp]),
     "boa_fill_holes_2d": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "boa_mask_assign": (i32, [vp, vp, u64, i32, i32, vp]),

@@ -321,6 +321,70 @@ def postprocess_region_segmentation_device(ctx: Context, d_seg: DeviceBuffer, sh
             b.free()
 
 
+def postprocess_region_segmentation_device_sharded(ctx: Context, agg, d_seg: DeviceBuffer, shape) -> None:
+    """The same CC filters with the (z,y,x) label volume cut into z-slabs, one per rank (SURVEY 8e aggregation stages;
+    boa_hip/agg_shard.py): `agg` = (agg_shard.AggComm, tile_shard.ShardComm).  Every rank passes the same full volume and
+    ends with the same cleaned volume (the slabs are exchanged as a sum over disjoint supports)."""
+    from . import agg_shard as ag
+    from . import tile_shard as ts
+    from .device import BufferView
+    comm, label_comm = agg
+    Z, Y, X = (int(v) for v in shape)
+    n = Z * Y * X
+    z0, z1 = ag.slab_bounds(Z, comm.world)[comm.rank]
+    n_slab = (z1 - z0) * Y * X
+    slab = BufferView(d_seg, z0 * Y * X, n_slab)
+    d_mask = ctx.alloc(max(n_slab, 1))
+    eng = ag.HipAggEngine(ctx, (z1 - z0, Y, X))
+
+    def select(seg, mode, vals):
+        if n_slab:
+            check(ctx.lib.boa_label_select(ctx.h, seg.vp, n_slab, mode, (C.c_int * 3)(*vals), d_mask.vp))
+        return d_mask
+
+    try:
+        ag.postprocess_region_segmentation_sharded(comm, eng, select, slab, z0, REGION)
+        BufferView(d_seg, 0, z0 * Y * X).zero()
+        BufferView(d_seg, z1 * Y * X, n - z1 * Y * X).zero()
+        ts.all_reduce_labels(ctx, label_comm, d_seg, n)
+    finally:
+        eng.close()
+        d_mask.free()
+
+
+def bca_measurements_device_sharded(ctx: Context, agg, d_ct: DeviceBuffer, d_rg: DeviceBuffer, d_pt: DeviceBuffer, shape, spacing_xyz,
+                                    vertebrae=None, orientation="LPS", body_parts_override=None):
+    """`bca_measurements_device(return_tissues=True)` with the tissue pass and the presence table computed per z-slab and the
+    per-slice tables gathered (agg_shard.gather_slice_tables); returns (dict, full tissues buffer), identical on all ranks."""
+    from . import agg_shard as ag
+    from . import tile_shard as ts
+    from .device import BufferView
+    comm, label_comm = agg
+    Z, Y, X = (int(v) for v in shape)
+    n = Z * Y * X
+    z0, z1 = ag.slab_bounds(Z, comm.world)[comm.rank]
+    Zl, pl = z1 - z0, Y * X
+    tis = ctx.zeros(n)
+    try:
+        if Zl:
+            cnt, sums = ctx.alloc(Zl * 16 * 4), ctx.alloc(Zl * 16 * 8)
+            check(ctx.lib.boa_tissue_aggregate(ctx.h, BufferView(d_ct, z0 * pl * 2, Zl * pl * 2).vp, None, BufferView(d_rg, z0 * pl, Zl * pl).vp,
+                                               BufferView(d_pt, z0 * pl, Zl * pl).vp, BufferView(tis, z0 * pl, Zl * pl).vp, Zl, Y, X,
+                                               cnt.vp, sums.vp), "boa_tissue_aggregate")
+            counts, hu_sums = cnt.download((Zl, 2, 8), np.uint32), sums.download((Zl, 2, 8), np.int64)
+            cnt.free()
+            sums.free()
+            present = slice_label_presence(ctx, BufferView(d_rg, z0 * pl, Zl * pl), (Zl, Y, X))
+        else:
+            counts, hu_sums, present = np.zeros((0, 2, 8), np.uint32), np.zeros((0, 2, 8), np.int64), np.zeros((0, 256), bool)
+        counts, hu_sums, present = ag.gather_slice_tables(comm, counts, hu_sums, present)
+        ts.all_reduce_labels(ctx, label_comm, tis, n)
+        return bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae, body_parts_override), tis
+    except Exception:
+        tis.free()
+        raise
+
+
 def postprocess_part_segmentation(ctx: Context, seg: np.ndarray, threshold: int = 3000) -> np.ndarray:
     """BCA/body_parts/postprocess.py:7-60 (`remove_small_labeled_objects`) on the device.  Per label (ascending):
     slice-wise external-contour fill (boa_fill_holes_2d), remove 26-connected objects with <= threshold-1 voxels,

@@ -64,6 +64,36 @@ class DeviceBuffer:
         return C.c_void_p(self.ptr)
 
 
+class BufferView:
+    """Non-owning window [byte_offset, byte_offset + nbytes) of a DeviceBuffer (z-slabs of a (z, y, x) volume are
+    contiguous ranges of its buffer)."""
+
+    def __init__(self, buf, byte_offset: int, nbytes: int):
+        assert 0 <= byte_offset and byte_offset + nbytes <= buf.nbytes, (byte_offset, nbytes, buf.nbytes)
+        self._keep = buf
+        self.ctx = buf.ctx
+        self.ptr = buf.ptr + int(byte_offset)
+        self.nbytes = int(nbytes)
+
+    @property
+    def vp(self):
+        return C.c_void_p(self.ptr)
+
+    def free(self):
+        pass
+
+    def zero(self):
+        if self.nbytes:
+            check(self.ctx.lib.boa_memset(self.ctx.h, self.vp, 0, self.nbytes))
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes, (out.nbytes, self.nbytes)
+        if out.nbytes:
+            check(self.ctx.lib.boa_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.vp, out.nbytes))
+        return out
+
+
 class Context:
     """One per GPU / process (`boa_init`)."""
 

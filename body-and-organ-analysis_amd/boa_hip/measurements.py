@@ -91,14 +91,17 @@ def _metrics(st: Optional[dict], ml_per_voxel: float, auto_mean, auto_std, cnr_n
 
 
 # ---- device passes --------------------------------------------------------------------------------------
-def label_hu_histogram(ctx: Context, d_ct: DeviceBuffer, d_labels: DeviceBuffer, n: int,
-                       d_mask: Optional[DeviceBuffer] = None) -> np.ndarray:
+def _label_hu_histogram_local(ctx: Context, d_ct: DeviceBuffer, d_labels: DeviceBuffer, n: int,
+                              d_mask: Optional[DeviceBuffer] = None) -> np.ndarray:
     d_hist = ctx.alloc(256 * NBINS * 4)
     check(ctx.lib.boa_label_hu_histogram(ctx.h, d_ct.vp, d_labels.vp, d_mask.vp if d_mask else None, n, HU_MIN, NBINS,
                                          d_hist.vp), "boa_label_hu_histogram")
     h = d_hist.download((256, NBINS), np.uint32)
     d_hist.free()
     return h
+
+
+label_hu_histogram = _label_hu_histogram_local
 
 
 def _lut(labels: Iterable[int]) -> np.ndarray:
@@ -133,10 +136,13 @@ def erode_region(ctx: Context, mask: np.ndarray, kernel_value: int = 6) -> np.nd
             b.free()
 
 
-def _masked_stats(ctx, d_ct, d_mask, n):
+def _masked_stats_local(ctx, d_ct, d_mask, n):
     """stats of ct[mask != 0]: histogram with the mask itself as the (0/1) label volume."""
-    h = label_hu_histogram(ctx, d_ct, d_mask, n)
+    h = _label_hu_histogram_local(ctx, d_ct, d_mask, n)
     return stats_from_hist(h[1])
+
+
+_masked_stats = _masked_stats_local
 
 
 def metrics_for_each_region(ctx: Context, ct: np.ndarray, region_data: np.ndarray, label_map: Dict[str, int],
@@ -166,10 +172,16 @@ def _metrics_from_hist(hist, label_map, am, asd, spacing):
 
 def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Optional[np.ndarray], label_map: Dict[str, int],
                        spacing, cnr_adjustment: bool = True, model_name: str = "total", d_ct: Optional[DeviceBuffer] = None,
-                       d_lab: Optional[DeviceBuffer] = None, shape=None, mask_on_device: bool = False):
+                       d_lab: Optional[DeviceBuffer] = None, shape=None, mask_on_device: bool = False, shard=None):
     """compute_measurements (:244-343) for models == ["total"] on (z,y,x) arrays.  Returns (measurements dict, ct_pfav
     mask).  Resident inputs: pass `d_ct` (int16) / `d_lab` (uint8) + `shape` instead of the host arrays (not freed here);
-    `mask_on_device=True` returns the mask as a DeviceBuffer (caller frees)."""
+    `mask_on_device=True` returns the mask as a DeviceBuffer (caller frees).
+
+    `shard` = (agg_shard.AggComm, (a, b)): the arrays are this rank's z-slab of the volume INCLUDING a halo of
+    agg_shard.ERODE_REACH planes towards its neighbours, and planes [a, b) of them are the ones the rank owns.  Masks and
+    erosions run on the whole slab (the halo supplies the neighbours' voxels; its own planes are discarded), histograms only
+    over the owned planes and are summed over the ranks -- every rank returns the volume's measurements; the returned
+    ct_pfav mask covers the slab."""
     own = d_ct is None
     if own:
         if ct.shape != total_seg.shape:
@@ -181,8 +193,27 @@ def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Option
     n = int(np.prod(shape))
     ml = np.prod(spacing) / 1000.0
     meas: Dict[str, Any] = {"segmentations": {}, "info": {}}
-    d_m, d_e, d_t = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    d_m, d_e, d_t = ctx.alloc(max(n, 1)), ctx.alloc(max(n, 1)), ctx.alloc(max(n, 1))
     keep_mask = None
+    if shard is not None:
+        from .device import BufferView
+        comm, (own_a, own_b) = shard
+        plane = shape[1] * shape[2]
+        n_own = (own_b - own_a) * plane
+
+        def owned(buf, itemsize):
+            return BufferView(buf, own_a * plane * itemsize, n_own * itemsize)
+
+        def label_hu_histogram(ctx_, dc, dl, n_, d_mask=None):          # noqa: F811  (slab version: owned planes, all-reduced)
+            h = _label_hu_histogram_local(ctx_, owned(dc, 2), owned(dl, 1), n_own, owned(d_mask, 1) if d_mask is not None else None) \
+                if n_own else np.zeros((256, NBINS), np.uint32)
+            return comm.all_reduce_sum(h)
+
+        def _masked_stats(ctx_, dc, d_mask, n_):                       # noqa: F811
+            return stats_from_hist(label_hu_histogram(ctx_, dc, d_mask, n_)[1])
+    else:
+        label_hu_histogram = _label_hu_histogram_local
+        _masked_stats = _masked_stats_local
     try:
         hist = label_hu_histogram(ctx, d_ct, d_lab, n)
         # autochthon reference: (left | right) minus fat, eroded (:42-58)

@@ -94,6 +94,10 @@ class BcaPipelineHip:
             self.tasks[name] = SegmentationTask(ctx, name, [(info["task_id"], cfg, blobs)], resample=info["resample"],
                                                 resample_only_thickness=True, multimodel=False, max_batch=max_batch)
 
+        # (agg_shard.AggComm, tile_shard.ShardComm): several ranks share every volume also in the aggregation half -- CC
+        # filters of body_regions, tissue pass and per-slice tables run per z-slab; None = whole volumes here
+        self.agg = None
+
     def close(self):
         for t in self.tasks.values():
             t.close()
@@ -117,7 +121,10 @@ class BcaPipelineHip:
                 zyx.free()
                 zyx = DevArray(self.ctx, buf, zyx.shape, np.uint8)
             elif task_name == "body_regions":
-                bca.postprocess_region_segmentation_device(self.ctx, zyx.buf, zyx.shape)
+                if self.agg is not None and self.agg[0].world > 1:
+                    bca.postprocess_region_segmentation_device_sharded(self.ctx, self.agg, zyx.buf, zyx.shape)
+                else:
+                    bca.postprocess_region_segmentation_device(self.ctx, zyx.buf, zyx.shape)
             else:
                 zyx.free()
                 raise ValueError(task_name)
@@ -209,8 +216,12 @@ class BcaPipelineHip:
                     live.append(tot_l)
                     vertebrae = bca.create_vertebrae_info(ctx, None, label_maps.CLASS_MAP_TOTAL, flags, d_total=tot_l.buf,
                                                           shape=tot_l.shape)
-                js, d_tis = bca.bca_measurements_device(ctx, ct_l.buf, rg_l.buf, pt_l.buf, ct_l.shape, spacing, vertebrae or None,
-                                                        True, median_filtering, "LPS", flags if examined_body_region else None)
+                if self.agg is not None and self.agg[0].world > 1 and not median_filtering:
+                    js, d_tis = bca.bca_measurements_device_sharded(ctx, self.agg, ct_l.buf, rg_l.buf, pt_l.buf, ct_l.shape, spacing,
+                                                                    vertebrae or None, "LPS", flags if examined_body_region else None)
+                else:
+                    js, d_tis = bca.bca_measurements_device(ctx, ct_l.buf, rg_l.buf, pt_l.buf, ct_l.shape, spacing, vertebrae or None,
+                                                            True, median_filtering, "LPS", flags if examined_body_region else None)
                 tis_l = DevArray(ctx, d_tis, ct_l.shape, np.uint8)
                 live.append(tis_l)
                 # back to the file's axis order: (z,y,x) LPS -> (x,y,z) LPS -> file orientation

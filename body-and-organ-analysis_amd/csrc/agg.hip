@@ -251,8 +251,16 @@ extern "C" int boa_tissue_projections(boa_ctx* c, const uint8_t* dev_tissues, co
 // organ at constant HU) issues ONE atomic -- or none when that key is "not measured".  A volume of a few constant regions
 // used to serialise ~10^8 atomics on a handful of addresses (57 ms per pass at 512^3; now memory bound).
 __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
-                                                    const unsigned char* __restrict__ mask, size_t n, int hu_min,
+                                                    const unsigned char* __restrict__ mask, size_t n_all, size_t head, int hu_min,
                                                     int nbins, unsigned int* __restrict__ hist) {
+    // voxels [0, head) and the last (n - head) % 16 are handled one by one (unaligned views: z-slabs of a volume)
+    const unsigned char* labels0 = labels;
+    const short* ct0 = ct;
+    const unsigned char* mask0 = mask;
+    labels += head;
+    ct += head;
+    if (mask) mask += head;
+    const size_t n = n_all - head;
     const size_t n16 = n / 16;
     const size_t stride = (size_t)gridDim.x * 256;
     auto key_of = [&](int l, int hu, int m) {
@@ -309,11 +317,30 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
         }
         if (run_key >= 0) atomicAdd(&hist[run_key], run);
     }
-    // tail (n % 16 voxels)
+    // tail (n % 16 voxels) and head
     if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n16 * 16)) {
         const size_t i = n16 * 16 + threadIdx.x;
         const int k = key_of(labels[i], ct[i], mask ? mask[i] : 1);
         if (k >= 0) atomicAdd(&hist[k], 1u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)head) {
+        const size_t i = threadIdx.x;
+        const int k = key_of(labels0[i], ct0[i], mask0 ? mask0[i] : 1);
+        if (k >= 0) atomicAdd(&hist[k], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_label_hist_scalar(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
+                                                           const unsigned char* __restrict__ mask, size_t n, int hu_min, int nbins,
+                                                           unsigned int* __restrict__ hist) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const int l = labels[i];
+        if (l == 0 || (mask && !mask[i])) continue;
+        int b = (int)ct[i] - hu_min;
+        b = b < 0 ? 0 : (b >= nbins ? nbins - 1 : b);
+        atomicAdd(&hist[(size_t)l * nbins + b], 1u);
     }
 }
 
@@ -322,12 +349,19 @@ extern "C" int boa_label_hu_histogram(boa_ctx* c, const int16_t* dev_ct, const u
     BOA_REQUIRE(c && dev_ct && dev_labels && dev_hist && nbins > 0, "boa_label_hu_histogram: bad argument");
     BOA_HIP_TRY(hipMemsetAsync(dev_hist, 0, (size_t)256 * nbins * sizeof(uint32_t), c->stream));
     if (n == 0) return BOA_OK;
-    BOA_REQUIRE(((uintptr_t)dev_ct) % 16 == 0 && ((uintptr_t)dev_labels) % 16 == 0 && (!dev_mask || ((uintptr_t)dev_mask) % 16 == 0),
-                "boa_label_hu_histogram: buffers must be 16-byte aligned");
+    // 16-byte vector loads need the three arrays aligned at the same voxel: skip `head` voxels (views into a volume start
+    // anywhere); arrays that cannot be aligned together are processed one voxel at a time
+    size_t head = (size_t)((16 - ((uintptr_t)dev_labels & 15)) & 15);
+    if (head > n) head = n;
+    const bool together = (((uintptr_t)dev_ct + 2 * head) & 15) == 0 && (!dev_mask || (((uintptr_t)dev_mask + head) & 15) == 0);
     int grid = (int)std::min<size_t>((n / 16 + 255) / 256 + 1, (size_t)c->cu_count * 16);
     KernelTimer t(c, BOA_K_AGG, 0, (double)n * (3.0 + (dev_mask ? 1 : 0)));
-    hipLaunchKernelGGL(k_label_hist, dim3(grid), dim3(256), 0, c->stream, dev_ct, dev_labels, dev_mask, n, hu_min,
-                       nbins, dev_hist);
+    if (together) {
+        hipLaunchKernelGGL(k_label_hist, dim3(grid), dim3(256), 0, c->stream, dev_ct, dev_labels, dev_mask, n, head, hu_min, nbins, dev_hist);
+    } else {
+        hipLaunchKernelGGL(k_label_hist_scalar, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 32)), dim3(256), 0,
+                           c->stream, dev_ct, dev_labels, dev_mask, n, hu_min, nbins, dev_hist);
+    }
     t.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
@@ -670,6 +704,104 @@ extern "C" int boa_ccl_remove_small(boa_ctx* c, const int32_t* dev_roots, const 
     unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_ccl_remove_small, dim3(grid), dim3(256), 0, c->stream, dev_roots, dev_sizes, n, max_size,
                        dev_mask_inout);
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// z-slab sharded connected components (SURVEY 8e "aggregation stages"): each rank labels its slab with boa_ccl26; the
+// components that touch a slab interface are merged on the host over the exchanged boundary planes (boa_hip/agg_shard.py).
+// These helpers move the small per-component tables between the device and the host.
+__global__ __launch_bounds__(256) void k_ccl_list(const unsigned int* __restrict__ sizes, size_t n, int max_out, int* __restrict__ roots_out,
+                                                  unsigned int* __restrict__ sizes_out, int* __restrict__ count) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned s = sizes[i];
+    if (s == 0) return;
+    const int k = atomicAdd(count, 1);
+    if (k < max_out) {
+        roots_out[k] = (int)i;
+        sizes_out[k] = s;
+    }
+}
+
+extern "C" int boa_ccl_list_components(boa_ctx* c, const uint32_t* dev_sizes, size_t n, int max_out, int32_t* host_roots,
+                                       uint32_t* host_sizes, int* host_count) {
+    BOA_REQUIRE(c && dev_sizes && host_roots && host_sizes && host_count && max_out >= 0, "boa_ccl_list_components: bad argument");
+    int* d_cnt = nullptr;
+    int* d_roots = nullptr;
+    unsigned* d_sz = nullptr;
+    BOA_TRY(boa_malloc(c, sizeof(int), (void**)&d_cnt));
+    int rc = boa_malloc(c, (size_t)std::max(max_out, 1) * 4, (void**)&d_roots);
+    if (!rc) rc = boa_malloc(c, (size_t)std::max(max_out, 1) * 4, (void**)&d_sz);
+    if (!rc) {
+        hipMemsetAsync(d_cnt, 0, sizeof(int), c->stream);
+        if (n) hipLaunchKernelGGL(k_ccl_list, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_sizes, n, max_out, d_roots, d_sz, d_cnt);
+        c->prof_break = true;
+        hipError_t e = hipMemcpyAsync(host_count, d_cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        const int m = std::min(*host_count, max_out);
+        if (e == hipSuccess && m > 0) e = hipMemcpy(host_roots, d_roots, (size_t)m * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && m > 0) e = hipMemcpy(host_sizes, d_sz, (size_t)m * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            boa_set_error("boa_ccl_list_components: %s", hipGetErrorString(e));
+            rc = BOA_EHIP;
+        }
+    }
+    boa_free(c, d_cnt);
+    if (d_roots) boa_free(c, d_roots);
+    if (d_sz) boa_free(c, d_sz);
+    return rc;
+}
+
+__global__ __launch_bounds__(256) void k_scatter_u32(const int* __restrict__ idx, const unsigned int* __restrict__ val, int m,
+                                                     unsigned int* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) dst[idx[i]] = val[i];
+}
+
+extern "C" int boa_scatter_u32(boa_ctx* c, uint32_t* dev_dst, const int32_t* host_idx, const uint32_t* host_val, int m) {
+    BOA_REQUIRE(c && dev_dst && (m == 0 || (host_idx && host_val)) && m >= 0, "boa_scatter_u32: bad argument");
+    if (m == 0) return BOA_OK;
+    int* d_i = nullptr;
+    unsigned* d_v = nullptr;
+    BOA_TRY(boa_malloc(c, (size_t)m * 4, (void**)&d_i));
+    int rc = boa_malloc(c, (size_t)m * 4, (void**)&d_v);
+    if (!rc) {
+        c->prof_break = true;
+        hipError_t e = hipMemcpy(d_i, host_idx, (size_t)m * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_v, host_val, (size_t)m * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_scatter_u32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d_i, d_v, m, dev_dst);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            boa_set_error("boa_scatter_u32: %s", hipGetErrorString(e));
+            rc = BOA_EHIP;
+        }
+    }
+    boa_free(c, d_i);  // synchronises the stream
+    if (d_v) boa_free(c, d_v);
+    return rc;
+}
+
+__global__ __launch_bounds__(256) void k_ccl_fill_unmarked(const int* __restrict__ roots, const unsigned int* __restrict__ sizes, size_t n,
+                                                           unsigned int mark, unsigned char* __restrict__ seg, int fill) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = roots[i];
+    if (r >= 0 && sizes[r] != mark) seg[i] = (unsigned char)fill;
+}
+
+extern "C" int boa_ccl_fill_unmarked(boa_ctx* c, const int32_t* dev_roots, const uint32_t* dev_sizes, size_t n, uint32_t mark,
+                                     uint8_t* dev_seg, int fill_value) {
+    BOA_REQUIRE(c && dev_roots && dev_sizes && dev_seg, "boa_ccl_fill_unmarked: NULL argument");
+    if (n == 0) return BOA_OK;
+    KernelTimer t(c, BOA_K_MORPH, 0, (double)n * 6.0);
+    hipLaunchKernelGGL(k_ccl_fill_unmarked, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dev_roots, dev_sizes, n, mark,
+                       dev_seg, fill_value);
+    t.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
 }

@@ -295,6 +295,18 @@ int boa_ccl_filter_largest(boa_ctx* ctx, const int32_t* dev_roots, const uint32_
 /* remove_small_objects(mask, max_size): clear mask where the component has <= max_size voxels. */
 int boa_ccl_remove_small(boa_ctx* ctx, const int32_t* dev_roots, const uint32_t* dev_sizes, size_t n,
                          uint32_t max_size, uint8_t* dev_mask_inout);
+/* ---- z-slab sharded connected components: per-component tables for the host-side merge over slab interfaces ----
+ * boa_ccl_list_components: the (root index, size) pairs of boa_ccl26's result, in no particular order; *host_count is the
+ *   true number (may exceed max_out: call again with larger arrays).  Synchronous.
+ * boa_scatter_u32: dst[idx[i]] = val[i] (the merged sizes of the components that cross an interface go back into `sizes`,
+ *   so that boa_ccl_remove_small decides on the global size).  Synchronous.
+ * boa_ccl_fill_unmarked: seg = fill_value on every component whose sizes[root] != mark (_filter_largest_unique_segment when
+ *   the largest component was determined globally: its local pieces carry `mark`). */
+int boa_ccl_list_components(boa_ctx* ctx, const uint32_t* dev_sizes, size_t n, int max_out, int32_t* host_roots,
+                            uint32_t* host_sizes, int* host_count);
+int boa_scatter_u32(boa_ctx* ctx, uint32_t* dev_dst, const int32_t* host_idx, const uint32_t* host_val, int m);
+int boa_ccl_fill_unmarked(boa_ctx* ctx, const int32_t* dev_roots, const uint32_t* dev_sizes, size_t n, uint32_t mark,
+                          uint8_t* dev_seg, int fill_value);
 /* mask_out = (labels == value) [mode 0] | (lut-free) labels > 0 [mode 1] | labels in {a,b,c} [mode 2, vals[3]] */
 int boa_label_select(boa_ctx* ctx, const uint8_t* dev_labels, size_t n, int mode, const int vals[3],
                      uint8_t* dev_mask_out);

@@ -205,3 +205,26 @@ def test_rccl_plumbing_single_rank(single):
         c.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard", ["tiles", "models"])
+def test_bench_shared_volume_modes_run_over_gloo(shard):
+    """`bench.py --gpus 2 --shard tiles|models --backend gloo`: the bench's strong-scaling modes end to end (two ranks
+    share cuda:0, slabs staged through the host) on a 256^3 volume, `total+bca` incl. the z-slab sharded aggregation: one
+    JSON line that counts 2 ranks and the same table summary as the one-rank run."""
+    import json
+    import subprocess
+    common = ["--size", "256", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-parity", "--no-h2h", "--batch", "4"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(HERE, "bench.py")] + common + extra, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    one = run([])
+    two = run(["--gpus", "2", "--shard", shard, "--backend", "gloo"])
+    assert two["n_gpus"] == 2 and two["config"]["ranks_seen"] == 2 and two["scaling"] == "strong"
+    assert one["n_gpus"] == 1 and one["scaling"] == "weak"
+    assert two["tables"] == one["tables"]                       # same labels present, same aggregation groups
