@@ -68,6 +68,7 @@ _PROTOS = {
     "boa_net_destroy": (None, [vp]),
     "boa_net_weight_count": (u64, [C.POINTER(NetDesc)]),
     "boa_net_load_weights": (i32, [vp, vp, u64]),
+    "boa_net_set_mirroring": (i32, [vp, i32]),
     "boa_net_forward": (i32, [vp, vp, ip, ip, i32, vp]),
     "boa_net_predict_sliding_window": (i32, [vp, vp, ip, ip, ip, ip, i32, vp, vp, vp]),
     "boa_conv_block_test": (i32, [vp, vp, i32, i32, ip, vp, vp, vp, vp, i32, ip, ip, i32, i32, vp]),
@@ -86,6 +87,7 @@ _PROTOS = {
     "boa_ccl_fill_unmarked": (i32, [vp, vp, vp, u64, C.c_uint32, vp, i32]),
     "boa_label_select": (i32, [vp, vp, u64, i32, ip, vp]),
     "boa_fill_holes_2d": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+    "boa_binary_dilate_cross": (i32, [vp, vp, vp, vp, i32, i32, i32, i32]),
     "boa_mask_assign": (i32, [vp, vp, u64, i32, i32, vp]),
     "boa_label_overlay": (i32, [vp, vp, u64, vp]),
     "boa_median3_inplane": (i32, [vp, vp, i32, i32, i32, i32, vp]),

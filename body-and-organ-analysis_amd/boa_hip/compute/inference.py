@@ -2,9 +2,10 @@
 outputs and folder contract, on the device engine.
 
 Supported models: `total`, `bca`, `body_parts`, `body_regions` and the crop-cascade models of `--models all`
-(lung_vessels, cerebral_bleed, hip_implant, pleural_pericard_effusion, liver_vessels: rough 6 mm `total` -> crop ->
-native-resolution model, TS/python_api.py:670-757).  The licensed `heartchambers_highres` raises NotImplementedError --
-nothing is silently skipped.  Weights come from `$nnUNet_results` (boa_hip/model_store.py); nothing is downloaded.
+(lung_vessels, cerebral_bleed, hip_implant, pleural_pericard_effusion, liver_vessels, and the licensed
+heartchambers_highres: rough 6 mm / robust 3 mm `total` -> crop -> native-resolution model [-> remove_outside_of_mask],
+TS/python_api.py:670-757).  Anything else raises NotImplementedError -- nothing is silently skipped.  Weights come from
+`$nnUNet_results` (boa_hip/model_store.py); nothing is downloaded.
 """
 from __future__ import annotations
 
@@ -132,8 +133,11 @@ def _segment_one(ctx, name, ct, affine, hdr, folder, fast, recompute):
         if fast:
             raise ValueError(f"task {name} does not work with option --fast")   # TS/python_api.py:242 ff.
         info = model_store.TASKS[name]
-        seg = run_cascade_task(ctx, name, ct, affine, model_store.load_task_models("total_6mm"),
-                               model_store.load_task_models(name), info["crop"], model_store.effective_crop_addon(name))
+        rough = model_store.rough_model_key(name)
+        seg = run_cascade_task(ctx, name, ct, affine, model_store.load_task_models(rough),
+                               model_store.load_task_models(name), info["crop"], model_store.effective_crop_addon(name),
+                               rough_resample=model_store.TASKS[rough]["resample"], remove_outside=info.get("remove_outside"),
+                               remove_outside_dilation=info.get("remove_outside_dilation"))
         names = label_maps.class_map(name)
     nifti.save(target, seg, affine, like=hdr, extensions=[(0, nifti.label_xml(names))])
 

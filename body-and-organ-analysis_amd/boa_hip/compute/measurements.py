@@ -65,10 +65,16 @@ def compute_measurements(ct_path: pathlib.Path, segmentation_folder: pathlib.Pat
                 finally:
                     fat.free()
             else:
-                if cnr_adjustment and model_name in label_maps.cnr_adjusted_regions():
-                    raise NotImplementedError(f"CNR-adjusted measurements for {model_name!r} are not implemented on the device")
                 hist = M.label_hu_histogram(ctx, d_ct.buf, d_seg.buf, d_ct.size)
                 measurements["segmentations"][model_name] = M._metrics_from_hist(hist, label_map, am, asd, spacing)
+                if cnr_adjustment and model_name in label_maps.cnr_adjusted_regions():
+                    if am is None or asd is None:   # (:307-313)
+                        logger.warning("Skipping CNR-adjusted measurements for %s: autochthon reference is unavailable (the "
+                                       "'total' model did not run or did not produce a usable autochthon mask).", model_name)
+                    else:
+                        adj = M.cnr_adjusted_region_metrics(ctx, d_ct.buf, d_seg.buf, d_ct.shape, label_map,
+                                                            label_maps.cnr_adjusted_regions()[model_name], hist, am, asd, spacing)
+                        measurements.setdefault("cnr_adjusted", {}).update(adj)
         finally:
             d_seg.free()
     d_ct.free()

@@ -170,6 +170,30 @@ def _metrics_from_hist(hist, label_map, am, asd, spacing):
     return res
 
 
+def cnr_adjusted_region_metrics(ctx: Context, d_ct: DeviceBuffer, d_lab: DeviceBuffer, shape, label_map: Dict[str, int],
+                                regions: Iterable[str], hist: np.ndarray, am, asd, spacing) -> Dict[str, Any]:
+    """`metrics_for_each_region(..., cnr_adjustment=True)` for the `regions` of a model other than `total`
+    (BOA/compute/measurements.py:318-341; e.g. heartchambers_highres / pulmonary_artery): the region's mask (autochthon names:
+    minus fat) is eroded with the 6^3 kernel before the statistics (metrics_for_region, :85-93).  `hist`: the model's
+    per-label histogram (tells which labels are present)."""
+    shape = tuple(int(v) for v in shape)
+    n = int(np.prod(shape))
+    ml = np.prod(spacing) / 1000.0
+    d_m, d_e, d_t = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    out: Dict[str, Any] = {}
+    try:
+        for region in [r for r in label_map if r in set(regions)]:
+            is_auto = "autochthon" in region
+            label_hu_mask(ctx, d_ct, d_lab, [label_map[region]], 2 if is_auto else 0, n, d_m)
+            binary_erode(ctx, d_m, d_e, d_t, shape)
+            st = _masked_stats_local(ctx, d_ct, d_e, n) if hist[label_map[region]].any() else None
+            out[region] = _metrics(st, ml, am, asd, cnr_none=region.partition("_")[0] == "autochthon")
+    finally:
+        for b in (d_m, d_e, d_t):
+            b.free()
+    return out
+
+
 def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Optional[np.ndarray], label_map: Dict[str, int],
                        spacing, cnr_adjustment: bool = True, model_name: str = "total", d_ct: Optional[DeviceBuffer] = None,
                        d_lab: Optional[DeviceBuffer] = None, shape=None, mask_on_device: bool = False, shard=None):

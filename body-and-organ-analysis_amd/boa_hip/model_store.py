@@ -36,8 +36,20 @@ TASKS: Dict[str, dict] = {
                                            "lung_middle_lobe_right", "lung_lower_lobe_right"], "crop_addon": [50, 50, 50]},
     "liver_vessels": {"task_id": [8], "resample": None, "trainer": "nnUNetTrainer", "folds": [0], "crop": ["liver"],
                       "crop_addon": [20, 20, 20]},
+    # licensed (TS/python_api.py:493-505): robust_crop = the 3 mm `total` model (Dataset297) makes the crop mask, and the
+    # result is cleared outside the 10 mm-dilated union of heart / aorta / inferior vena cava (TS/postprocessing.py:101-131)
+    "heartchambers_highres": {"task_id": [301], "resample": None, "trainer": "nnUNetTrainer", "folds": [0], "crop": ["heart"],
+                              "crop_addon": [5, 5, 5], "robust_crop": True,
+                              "remove_outside": ["heart", "aorta", "inferior_vena_cava"], "remove_outside_dilation": 10},
 }
-CASCADE_MODELS = ("lung_vessels", "cerebral_bleed", "hip_implant", "pleural_pericard_effusion", "liver_vessels")
+CASCADE_MODELS = ("lung_vessels", "cerebral_bleed", "hip_implant", "pleural_pericard_effusion", "liver_vessels",
+                  "heartchambers_highres")
+
+
+def rough_model_key(task: str) -> str:
+    """The model that makes the crop mask of a cascade task (TS/python_api.py:679-699): Dataset298 at 6 mm, or with
+    `robust_crop` Dataset297 at 3 mm."""
+    return "total_fast" if TASKS[task].get("robust_crop") else "total_6mm"
 
 
 def effective_crop_addon(task: str) -> List[int]:

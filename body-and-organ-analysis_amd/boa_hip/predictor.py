@@ -26,10 +26,15 @@ from .plans import NetGeometry
 
 class HipPredictor:
     def __init__(self, ctx: Context, geometry: NetGeometry, tile_step_size: float = 0.5, use_gaussian: bool = True,
-                 use_mirroring: bool = False, max_batch: int = 4, verbose: bool = False, precision: Optional[str] = None):
-        if use_mirroring:
-            # BOA runs every model with tta=False / *NoMirroring trainers (TS/python_api.py:753)
-            raise NotImplementedError("test-time mirroring is not used by BOA and is not implemented on device")
+                 use_mirroring: bool = False, max_batch: int = 4, verbose: bool = False, precision: Optional[str] = None,
+                 allowed_mirroring_axes: Optional[Sequence[int]] = (0, 1, 2)):
+        # BOA runs every model with tta=False / *NoMirroring trainers (TS/python_api.py:753); use_mirroring=True is honoured
+        # as nnUNetPredictor does (predict_from_raw_data.py:541-557) with the checkpoint's `inference_allowed_mirroring_axes`
+        self.use_mirroring = bool(use_mirroring)
+        self.allowed_mirroring_axes = None if allowed_mirroring_axes is None else tuple(int(a) for a in allowed_mirroring_axes)
+        if self.use_mirroring and self.allowed_mirroring_axes is not None and \
+                any(a < 0 or a > 2 for a in self.allowed_mirroring_axes):
+            raise AssertionError("mirror_axes does not match the dimension of the input!")
         self.ctx = ctx
         self.lib = ctx.lib
         self.geom = geometry
@@ -74,6 +79,11 @@ class HipPredictor:
                                           self.max_batch, 1 if self.precision == "fp32" else 0, C.byref(h)), "boa_net_create")
             self._net = h
             self._loaded_fold = fold
+            if self.use_mirroring and self.allowed_mirroring_axes:
+                mask = 0
+                for a in self.allowed_mirroring_axes:
+                    mask |= 1 << a
+                check(self.lib.boa_net_set_mirroring(self._net, mask), "boa_net_set_mirroring")
         elif self._loaded_fold != fold:
             check(self.lib.boa_net_load_weights(self._net, w.ctypes.data_as(C.c_void_p), w.size), "boa_net_load_weights")
             self._loaded_fold = fold

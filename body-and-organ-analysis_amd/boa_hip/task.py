@@ -332,13 +332,36 @@ class SegmentationTask:
                     a.free()
 
 
+def remove_outside_of_mask(ctx: Context, seg: np.ndarray, mask: np.ndarray, addon: int = 1) -> np.ndarray:
+    """TS/postprocessing.py:101-131 on arrays of the same grid: dilate `mask != 0` `addon` times with the 6-neighbour cross
+    (scipy.ndimage.binary_dilation(mask, iterations=addon)), clear `seg` outside.  Runs on the device."""
+    if seg.shape != mask.shape:
+        raise ValueError("segmentation and mask must have the same shape")
+    if addon < 1:
+        raise NotImplementedError("remove_outside_of_mask with addon < 1 (scipy dilates until convergence)")
+    n = int(seg.size)
+    Z, Y, X = (int(v) for v in seg.shape)
+    d_seg = ctx.from_numpy(np.ascontiguousarray(seg, dtype=np.uint8))
+    d_m = ctx.from_numpy(np.ascontiguousarray(mask != 0, dtype=np.uint8))
+    d_o, d_t = ctx.alloc(n), ctx.alloc(n)
+    try:
+        check(ctx.lib.boa_binary_dilate_cross(ctx.h, d_m.vp, d_o.vp, d_t.vp, Z, Y, X, int(addon)), "boa_binary_dilate_cross")
+        check(ctx.lib.boa_mask_assign(ctx.h, d_o.vp, n, 1, 0, d_seg.vp), "boa_mask_assign")          # seg[mask == 0] = 0
+        return d_seg.download(seg.shape, np.uint8)
+    finally:
+        for b in (d_seg, d_m, d_o, d_t):
+            b.free()
+
+
 def run_cascade_task(ctx: Context, task: str, data: np.ndarray, affine: np.ndarray, rough_models, task_models,
-                     crop_names: Sequence[str], crop_addon=(3, 3, 3), max_batch: int = 8) -> np.ndarray:
+                     crop_names: Sequence[str], crop_addon=(3, 3, 3), max_batch: int = 8, rough_resample: float = 6.0,
+                     remove_outside: Optional[Sequence[str]] = None, remove_outside_dilation: Optional[float] = None) -> np.ndarray:
     """Crop-cascade task of `--models all` (TS/python_api.py:670-757): a rough `total` segmentation at 6 mm (single model
-    Dataset298, labels = the `total` map) -> crop mask = union of the `crop_names` structures -> the task's own model at
-    native resolution on the cropped image -> labels on the input grid.
+    Dataset298; 3 mm / Dataset297 with robust_crop: `rough_resample`), labels = the `total` map -> crop mask = union of the
+    `crop_names` structures -> the task's own model at native resolution on the cropped image -> labels on the input grid
+    -> optionally cleared outside the dilated union of the `remove_outside` structures (TS/nnunet.py:711-716).
     rough_models / task_models: [(task_id, ModelConfig, [weight blob per fold])] as `model_store.load_task_models` gives."""
-    rough = SegmentationTask(ctx, "total", rough_models, resample=6.0, multimodel=False, max_batch=max_batch)
+    rough = SegmentationTask(ctx, "total", rough_models, resample=rough_resample, multimodel=False, max_batch=max_batch)
     try:
         organ_seg = rough.predict_image(data, affine)
     finally:
@@ -347,6 +370,13 @@ def run_cascade_task(ctx: Context, task: str, data: np.ndarray, affine: np.ndarr
     crop_mask = np.isin(organ_seg, [inv[n] for n in crop_names]).astype(np.uint8)
     t = SegmentationTask(ctx, task, task_models, resample=None, multimodel=False, max_batch=max_batch)
     try:
-        return t.predict_image(data, affine, crop_mask=crop_mask, crop_addon=crop_addon)
+        seg = t.predict_image(data, affine, crop_mask=crop_mask, crop_addon=crop_addon)
     finally:
         t.close()
+    if remove_outside_dilation is not None:
+        remove_mask = np.isin(organ_seg, [inv[n] for n in (remove_outside or [])]).astype(np.uint8)
+        # header zooms are float32 (nibabel): int(mm / np.mean(img.header.get_zooms()))
+        zooms = np.asarray(orientation.zooms_from_affine(np.asarray(affine, dtype=np.float64)), dtype=np.float32)
+        vx = int(remove_outside_dilation / np.mean(zooms))
+        seg = remove_outside_of_mask(ctx, seg, remove_mask, addon=vx)
+    return seg

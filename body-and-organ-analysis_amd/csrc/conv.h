@@ -49,7 +49,7 @@ int conv_ws_nslots(int cu_count);
 // and outside the tile), fp32 VALU, stride 1.  w: dev fp32 [Cin][taps][Cout].
 int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins,
                       int N, int Cin, const int P[3], const int k[3], int Cout, const float* w, const float* bias,
-                      float* padded_scratch, __half* out, float* partials, int* nblk_out);
+                      float* padded_scratch, __half* out, float* partials, int* nblk_out, int flip_mask = 0);
 int conv_first_nblk(const int P[3], int cu_count);
 void conv_first_padded_dims(const int P[3], const int k[3], int out[3]);
 
@@ -124,7 +124,9 @@ int launch_convt_f32(boa_ctx* ctx, const float* src, const float* ss, int Cin, i
 int launch_stats_f32(boa_ctx* ctx, const float* act, int N, size_t vox, int C, const float* gamma, const float* beta, float eps,
                      float* ss_out);
 int launch_gather_tiles_f32(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins, int N,
-                            int Cin, const int P[3], float* out);
+                            int Cin, const int P[3], float* out, int flip_mask = 0);
+// test-time mirroring: dst[c][p] (=|+=) src[c][flip(p)] over fp32 logits [C][P0][P1][P2]; scale applied after the add
+int launch_flip_accumulate(boa_ctx* ctx, const float* src, float* dst, int C, const int P[3], int flip_mask, int add, float scale);
 int launch_head_f32(boa_ctx* ctx, const float* act, const float* ss, int F0, const int P[3], int C, const float* w,
                     const float* bias, float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc, uint16_t* nacc,
                     const int PV[3], const int start[3]);

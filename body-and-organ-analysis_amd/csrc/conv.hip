@@ -438,7 +438,7 @@ int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const Con
 __global__ __launch_bounds__(256) void k_gather_patches(const float* __restrict__ vol, const int* __restrict__ origins,
                                                         int V0, int V1, int V2, int o0, int o1, int o2, int Cin, int P0,
                                                         int P1, int P2, int pad0, int pad1, int pad2, int PX, int PY, int PZ,
-                                                        float* __restrict__ out) {
+                                                        int flip, float* __restrict__ out) {
     const int n = blockIdx.z, ci = blockIdx.y;
     const size_t pvol = (size_t)PX * PY * PZ;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -447,7 +447,9 @@ __global__ __launch_bounds__(256) void k_gather_patches(const float* __restrict_
     const int px = x - pad0, py = y - pad1, pz = z - pad2;  // patch coordinates
     float v = 0.f;
     if (px >= 0 && px < P0 && py >= 0 && py < P1 && pz >= 0 && pz < P2) {
-        const int vx = origins[n * 3 + 0] + px - o0, vy = origins[n * 3 + 1] + py - o1, vz = origins[n * 3 + 2] + pz - o2;
+        // test-time mirroring (predict_from_raw_data.py:541-557): the network sees torch.flip(tile, axes)
+        const int qx = (flip & 1) ? P0 - 1 - px : px, qy = (flip & 2) ? P1 - 1 - py : py, qz = (flip & 4) ? P2 - 1 - pz : pz;
+        const int vx = origins[n * 3 + 0] + qx - o0, vy = origins[n * 3 + 1] + qy - o1, vz = origins[n * 3 + 2] + qz - o2;
         if (vx >= 0 && vx < V0 && vy >= 0 && vy < V1 && vz >= 0 && vz < V2)
             v = vol[(size_t)ci * V0 * V1 * V2 + ((size_t)vx * V1 + vy) * V2 + vz];
     }
@@ -828,7 +830,7 @@ void conv_first_padded_dims(const int P[3], const int k[3], int out[3]) {
 
 int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins,
                       int N, int Cin, const int P[3], const int k[3], int Cout, const float* w, const float* bias,
-                      float* padded_scratch, __half* out, float* partials, int* nblk_out) {
+                      float* padded_scratch, __half* out, float* partials, int* nblk_out, int flip_mask) {
     BOA_REQUIRE(Cout % 32 == 0, "first conv: Cout=%d must be a multiple of 32", Cout);
     BOA_REQUIRE(Cin >= 1 && Cin <= 4, "first conv: Cin=%d unsupported (1..4)", Cin);
     const bool k333 = k[0] == 3 && k[1] == 3 && k[2] == 3, k133 = k[0] == 1 && k[1] == 3 && k[2] == 3;
@@ -841,7 +843,7 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
     hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)((pvol + 255) / 256), Cin, N), dim3(256), 0, ctx->stream, volume,
                        dev_origins, V[0], V[1], V[2], vol_off ? vol_off[0] : 0, vol_off ? vol_off[1] : 0,
                        vol_off ? vol_off[2] : 0, Cin, P[0], P[1], P[2], (k[0] - 1) / 2, (k[1] - 1) / 2, (k[2] - 1) / 2, PD[0],
-                       PD[1], PD[2], padded_scratch);
+                       PD[1], PD[2], flip_mask, padded_scratch);
     const int nblk_tab = conv_first_nblk(P, ctx->cu_count);
     if (nblk_out) *nblk_out = nblk_tab;
     if (first_mfma_ok(Cin, P, k, Cout)) {

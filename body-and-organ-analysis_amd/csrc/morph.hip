@@ -6,6 +6,8 @@
 //   boa_median3_inplane scipy.ndimage.median_filter(size 3 on two axes, 1 on the slice axis, mode="reflect") of
 //                       tissue/subclassification.py:21-36 on int16 HU.
 //   boa_mask_assign     out[mask (!)= 0] = value   (`out[filled] = label`, body_parts/postprocess.py:50).
+#include <algorithm>
+
 #include "common.h"
 
 #define AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -439,5 +441,49 @@ extern "C" int boa_nonzero_bbox(boa_ctx* c, const void* dev_in, int dtype, const
         host_bbox[2 * a] = any ? bb[2 * a] : 0;
         host_bbox[2 * a + 1] = any ? bb[2 * a + 1] + 1 : dims[a];
     }
+    return BOA_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// remove_outside_of_mask (TS/postprocessing.py:101-131): mask = scipy.ndimage.binary_dilation(mask, iterations=addon)
+// with the default structuring element (the 6-neighbour cross, border_value 0), then seg[mask == 0] = 0.
+__global__ __launch_bounds__(256) void k_dilate_cross(const unsigned char* __restrict__ in, int Z, int Y, int X, unsigned char* __restrict__ out) {
+    const size_t n = (size_t)Z * Y * X;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % X), y = (int)((i / X) % Y), z = (int)(i / ((size_t)X * Y));
+    const size_t sy = X, sz = (size_t)X * Y;
+    bool v = in[i] != 0;
+    if (!v) {
+        v = (x > 0 && in[i - 1]) || (x < X - 1 && in[i + 1]) || (y > 0 && in[i - sy]) || (y < Y - 1 && in[i + sy]) ||
+            (z > 0 && in[i - sz]) || (z < Z - 1 && in[i + sz]);
+    }
+    out[i] = v ? 1 : 0;
+}
+
+extern "C" int boa_binary_dilate_cross(boa_ctx* c, const uint8_t* dev_mask, uint8_t* dev_out, uint8_t* dev_tmp, int Z, int Y, int X,
+                                       int iterations) {
+    BOA_REQUIRE(c && dev_mask && dev_out && dev_tmp && Z > 0 && Y > 0 && X > 0 && iterations >= 0, "boa_binary_dilate_cross: bad argument");
+    BOA_REQUIRE(dev_out != dev_tmp && dev_out != dev_mask && dev_tmp != dev_mask, "boa_binary_dilate_cross: buffers must not alias");
+    const size_t n = (size_t)Z * Y * X;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    KernelTimer t(c, BOA_K_MORPH, 0, (double)n * 2.0 * std::max(iterations, 1));
+    if (iterations == 0) {
+        // scipy: iterations < 1 repeats until nothing changes; the reference only passes int(mm / mean spacing) >= 0 and a
+        // 0 there means "until convergence" = everything reachable: the whole volume if the mask is not empty
+        BOA_HIP_TRY(hipMemcpyAsync(dev_out, dev_mask, n, hipMemcpyDeviceToDevice, c->stream));
+        boa_set_error("boa_binary_dilate_cross: iterations == 0 (dilate until convergence) is not supported");
+        return BOA_EINVAL;
+    }
+    // ping-pong so that the last iteration lands in dev_out
+    const unsigned char* src = dev_mask;
+    for (int it = 0; it < iterations; ++it) {
+        unsigned char* dst = ((iterations - it) % 2 == 1) ? dev_out : dev_tmp;
+        hipLaunchKernelGGL(k_dilate_cross, dim3(grid), dim3(256), 0, c->stream, src, Z, Y, X, dst);
+        src = dst;
+    }
+    t.stop();
+    BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
 }

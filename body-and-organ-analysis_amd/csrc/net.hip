@@ -50,6 +50,9 @@ struct boa_net {
     boa_net_desc d{};
     int maxN = 1;
     int precision = 0;         // 0: fp16 storage + f16 MFMA (production); 1: fp32 "exact" mode (net_f32.hip)
+    int mirror_mask = 0;       // test-time mirroring axes (bit a = array axis a), predict_from_raw_data.py:541-557
+    float* mirror_tmp = nullptr;  // [maxN][C][P] fp32 logits of one mirror variant
+    float* mirror_sum = nullptr;  // [maxN][C][P] running sum / mean
     float* tiles32 = nullptr;  // fp32 mode: gathered input tiles [N][P][Cin]
     std::vector<std::vector<ConvLayer>> enc;  // [stage][conv]
     std::vector<UpLayer> up;                  // decoder order (deepest first)
@@ -410,13 +413,13 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
 
 // fp32 mode: the same layer sequence through net_f32.hip; leaves the last decoder activation in dec.back().back().out32
 static int net_forward_stack_f32(boa_net* net, const float* volume, const int V[3], const int vol_off[3],
-                                 const int* host_origins, int N) {
+                                 const int* host_origins, int N, int flip_mask) {
     boa_ctx* c = net->ctx;
     const boa_net_desc& d = net->d;
     BOA_REQUIRE(N >= 1 && N <= net->maxN, "forward: batch %d exceeds max_batch %d", N, net->maxN);
     BOA_HIP_TRY(hipMemcpyAsync(net->dev_origins, host_origins, (size_t)N * 3 * sizeof(int), hipMemcpyHostToDevice, c->stream));
     c->prof_break = true;
-    BOA_TRY(launch_gather_tiles_f32(c, volume, V, vol_off, net->dev_origins, N, d.in_channels, d.patch, net->tiles32));
+    BOA_TRY(launch_gather_tiles_f32(c, volume, V, vol_off, net->dev_origins, N, d.in_channels, d.patch, net->tiles32, flip_mask));
     struct Src {
         const float* data = nullptr;
         const float* ss = nullptr;
@@ -474,8 +477,8 @@ static int net_head(boa_net* net, int i, const int P[3], int plane_skip, float* 
 
 // run the conv stack for N tiles; leaves the last decoder activation (+ its ss) in net->dec.back().back()
 static int net_forward_stack(boa_net* net, const float* volume, const int V[3], const int vol_off[3],
-                             const int* host_origins, int N) {
-    if (net->precision == 1) return net_forward_stack_f32(net, volume, V, vol_off, host_origins, N);
+                             const int* host_origins, int N, int flip_mask = 0) {
+    if (net->precision == 1) return net_forward_stack_f32(net, volume, V, vol_off, host_origins, N, flip_mask);
     boa_ctx* c = net->ctx;
     const boa_net_desc& d = net->d;
     BOA_REQUIRE(N >= 1 && N <= net->maxN, "forward: batch %d exceeds max_batch %d", N, net->maxN);
@@ -506,7 +509,7 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
         if (L.first) {
             int nblk = 0;
             BOA_TRY(launch_conv_first(c, volume, V, vol_off, net->dev_origins, N, d.in_channels, d.patch, L.g.k, L.g.Cout,
-                                      L.wfirst, L.bias, net->first_padded, L.out, L.partials, &nblk));
+                                      L.wfirst, L.bias, net->first_padded, L.out, L.partials, &nblk, flip_mask));
         } else {
             BOA_TRY(launch_conv_mfma(c, a, b, g, L.t, L.wpk, L.bias, d.lrelu_slope, L.out, L.partials));
         }
@@ -555,6 +558,49 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
     return BOA_OK;
 }
 
+// `_internal_maybe_mirror_and_predict` (predict_from_raw_data.py:541-557) for the nb tiles of one batch: the fp32 logits of
+// the plain forward plus, for every non-empty combination of the allowed mirror axes (itertools.combinations order: single
+// axes, pairs, the triple), the logits of the flipped tile flipped back, divided by the number of variants.  Result in
+// net->mirror_sum [nb][C][P].
+static int net_mirrored_logits(boa_net* net, const float* volume, const int V[3], const int vol_off[3], const int* host_origins, int nb) {
+    const boa_net_desc& d = net->d;
+    const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2], per = (size_t)d.num_classes * pv;
+    if (!net->mirror_tmp) {
+        BOA_TRY(net_alloc(net, (size_t)net->maxN * per * sizeof(float), (void**)&net->mirror_tmp));
+        BOA_TRY(net_alloc(net, (size_t)net->maxN * per * sizeof(float), (void**)&net->mirror_sum));
+    }
+    std::vector<int> combos = {0};
+    int axes[3], na = 0;
+    for (int a = 0; a < 3; ++a)
+        if (net->mirror_mask & (1 << a)) axes[na++] = a;
+    for (int size = 1; size <= na; ++size)
+        for (int m = 1; m < (1 << na); ++m) {   // subsets of `size` axes in lexicographic order of their axis tuples
+            if (__builtin_popcount(m) != size) continue;
+            combos.push_back(m);
+        }
+    // lexicographic order of tuples: for size 1: (a0), (a1), (a2); size 2: (a0,a1), (a0,a2), (a1,a2) = ascending bit masks
+    // 3, 5, 6 -- the ascending-mask enumeration above already yields that order for up to three axes
+    for (size_t k = 0; k < combos.size(); ++k) {
+        int flip = 0;
+        for (int j = 0; j < na; ++j)
+            if (combos[k] & (1 << j)) flip |= 1 << axes[j];
+        BOA_TRY(net_forward_stack(net, volume, V, vol_off, host_origins, nb, flip));
+        const bool last = k + 1 == combos.size();
+        for (int i = 0; i < nb; ++i) {
+            BOA_TRY(net_head(net, i, d.patch, 0, net->mirror_tmp + (size_t)i * per, nullptr, nullptr, nullptr, nullptr, nullptr));
+            BOA_TRY(launch_flip_accumulate(net->ctx, net->mirror_tmp + (size_t)i * per, net->mirror_sum + (size_t)i * per, d.num_classes,
+                                           d.patch, flip, k > 0, last ? (float)combos.size() : 1.0f));
+        }
+    }
+    return BOA_OK;
+}
+
+extern "C" int boa_net_set_mirroring(boa_net* net, int axes_mask) {
+    BOA_REQUIRE(net && axes_mask >= 0 && axes_mask < 8, "boa_net_set_mirroring: axes mask %d", axes_mask);
+    net->mirror_mask = axes_mask;
+    return BOA_OK;
+}
+
 extern "C" int boa_net_forward(boa_net* net, const float* dev_volume, const int V[3], const int* host_origins,
                                int n_tiles, float* dev_logits_out) {
     BOA_REQUIRE(net && dev_volume && V && host_origins && dev_logits_out, "boa_net_forward: NULL argument");
@@ -563,6 +609,13 @@ extern "C" int boa_net_forward(boa_net* net, const float* dev_volume, const int 
     const int zero[3] = {0, 0, 0};
     for (int t0 = 0; t0 < n_tiles; t0 += net->maxN) {
         int nb = std::min(net->maxN, n_tiles - t0);
+        if (net->mirror_mask) {
+            BOA_TRY(net_mirrored_logits(net, dev_volume, V, zero, host_origins + (size_t)t0 * 3, nb));
+            BOA_HIP_TRY(hipMemcpyAsync(dev_logits_out + (size_t)t0 * d.num_classes * pv, net->mirror_sum,
+                                       (size_t)nb * d.num_classes * pv * sizeof(float), hipMemcpyDeviceToDevice, net->ctx->stream));
+            net->ctx->prof_break = true;
+            continue;
+        }
         BOA_TRY(net_forward_stack(net, dev_volume, V, zero, host_origins + (size_t)t0 * 3, nb));
         for (int i = 0; i < nb; ++i)
             BOA_TRY(net_head(net, i, d.patch, 0, dev_logits_out + (size_t)(t0 + i) * d.num_classes * pv, nullptr, nullptr, nullptr,
@@ -586,6 +639,13 @@ extern "C" int boa_net_predict_sliding_window(boa_net* net, const float* dev_vol
     const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2];
     for (int t0 = 0; t0 < n_tiles; t0 += net->maxN) {
         int nb = std::min(net->maxN, n_tiles - t0);
+        if (net->mirror_mask) {  // mirrored mean of the fp32 logits first, then the reference's accumulate step on it
+            BOA_TRY(net_mirrored_logits(net, dev_volume, V, off, host_origins + (size_t)t0 * 3, nb));
+            for (int i = 0; i < nb; ++i)
+                BOA_TRY(boa_accumulate_tile(net->ctx, net->mirror_sum + (size_t)i * d.num_classes * pv, dev_gauss, dev_acc, dev_n,
+                                            d.num_classes, d.patch, PV, host_origins + (size_t)(t0 + i) * 3));
+            continue;
+        }
         BOA_TRY(net_forward_stack(net, dev_volume, V, off, host_origins + (size_t)t0 * 3, nb));
         for (int i = 0; i < nb; ++i) {  // canonical order: one launch per tile, serialised on the stream
             const int* st = host_origins + (size_t)(t0 + i) * 3;
@@ -626,6 +686,7 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
                 "boa_net_predict_sliding_window_deferred: NULL argument");
     const boa_net_desc& d = net->d;
     BOA_REQUIRE(net->precision == 0, "deferred sliding window (tile sharding) is not available in the fp32 exact mode");
+    BOA_REQUIRE(net->mirror_mask == 0, "deferred sliding window (tile sharding) is not available with test-time mirroring");
     const int zero[3] = {0, 0, 0};
     const int* off = vol_off ? vol_off : zero;
     for (int a = 0; a < 3; ++a)

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_stats_f32(const float* __restrict__ act
 
 // tiles out of the resident volume [Cin][V] into channels-last fp32 [N][P][Cin]; voxels outside the volume read 0 (pad_nd_image)
 __global__ __launch_bounds__(256) void k_gather_tiles_f32(const float* __restrict__ vol, const int* __restrict__ origins, int V0, int V1,
-                                                          int V2, int o0, int o1, int o2, int Cin, int P0, int P1, int P2,
+                                                          int V2, int o0, int o1, int o2, int Cin, int P0, int P1, int P2, int flip,
                                                           float* __restrict__ out) {
     const int n = blockIdx.y;
     const size_t pv = (size_t)P0 * P1 * P2;
@@ -187,7 +187,10 @@ __global__ __launch_bounds__(256) void k_gather_tiles_f32(const float* __restric
     if (i >= pv * Cin) return;
     const int ci = (int)(i % Cin);
     const size_t v = i / Cin;
-    const int pz = (int)(v % P2), py = (int)((v / P2) % P1), px = (int)(v / ((size_t)P2 * P1));
+    int pz = (int)(v % P2), py = (int)((v / P2) % P1), px = (int)(v / ((size_t)P2 * P1));
+    if (flip & 1) px = P0 - 1 - px;  // test-time mirroring: the network sees torch.flip(tile, axes)
+    if (flip & 2) py = P1 - 1 - py;
+    if (flip & 4) pz = P2 - 1 - pz;
     const int vx = origins[n * 3 + 0] + px - o0, vy = origins[n * 3 + 1] + py - o1, vz = origins[n * 3 + 2] + pz - o2;
     float x = 0.f;
     if (vx >= 0 && vx < V0 && vy >= 0 && vy < V1 && vz >= 0 && vz < V2) x = vol[(size_t)ci * V0 * V1 * V2 + ((size_t)vx * V1 + vy) * V2 + vz];
@@ -257,7 +260,32 @@ __global__ void k_ndhwc32_to_nchw_f32(const float* __restrict__ in, const float*
     out[i] = f;
 }
 
+__global__ void k_flip_accumulate(const float* __restrict__ src, float* __restrict__ dst, int P0, int P1, int P2, int flip, int add,
+                                  float scale) {
+    const size_t pv = (size_t)P0 * P1 * P2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pv) return;
+    const int c = blockIdx.y;
+    int z = (int)(i % P2), y = (int)((i / P2) % P1), x = (int)(i / ((size_t)P2 * P1));
+    if (flip & 1) x = P0 - 1 - x;
+    if (flip & 2) y = P1 - 1 - y;
+    if (flip & 4) z = P2 - 1 - z;
+    float v = src[(size_t)c * pv + ((size_t)x * P1 + y) * P2 + z];
+    if (add) v = dst[(size_t)c * pv + i] + v;   // prediction += torch.flip(network(torch.flip(x, axes)), axes)   (fp32)
+    dst[(size_t)c * pv + i] = v / scale;        // prediction /= (len(axes_combinations) + 1) on the last one (scale 1 before)
+}
+
 }  // namespace
+
+int launch_flip_accumulate(boa_ctx* ctx, const float* src, float* dst, int C, const int P[3], int flip_mask, int add, float scale) {
+    const size_t pv = (size_t)P[0] * P[1] * P[2];
+    KernelTimer tm(ctx, BOA_K_HEAD_ACCUM, 0, (double)pv * C * (add ? 12.0 : 8.0));
+    hipLaunchKernelGGL(k_flip_accumulate, dim3((unsigned)((pv + 255) / 256), C), dim3(256), 0, ctx->stream, src, dst, P[0], P[1], P[2],
+                       flip_mask, add, scale);
+    tm.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
 
 int launch_ndhwc32_to_nchw_f32(boa_ctx* ctx, const float* in, const float* ss, float slope, int C, size_t vox, float* out) {
     hipLaunchKernelGGL(k_ndhwc32_to_nchw_f32, dim3((unsigned)((vox * C + 255) / 256)), dim3(256), 0, ctx->stream, in, ss, slope, C, vox, out);
@@ -311,12 +339,12 @@ int launch_stats_f32(boa_ctx* ctx, const float* act, int N, size_t vox, int C, c
 }
 
 int launch_gather_tiles_f32(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins, int N,
-                            int Cin, const int P[3], float* out) {
+                            int Cin, const int P[3], float* out, int flip_mask) {
     const size_t tot = (size_t)P[0] * P[1] * P[2] * Cin;
     KernelTimer tm(ctx, BOA_K_CONV_FIRST, 0, 8.0 * N * (double)tot);
     hipLaunchKernelGGL(k_gather_tiles_f32, dim3((unsigned)((tot + 255) / 256), N), dim3(256), 0, ctx->stream, volume, dev_origins,
                        V[0], V[1], V[2], vol_off ? vol_off[0] : 0, vol_off ? vol_off[1] : 0, vol_off ? vol_off[2] : 0, Cin, P[0], P[1],
-                       P[2], out);
+                       P[2], flip_mask, out);
     ctx->counters[BOA_CNT_F32]++;
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());

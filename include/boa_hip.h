@@ -164,6 +164,12 @@ size_t boa_net_weight_count(const boa_net_desc* desc); /* expected n_floats, 0 o
 /* swap weights (next fold), NN/inference/predict_from_raw_data.py:486-489 `load_state_dict(params)` */
 int boa_net_load_weights(boa_net* net, const float* host_weights, size_t n_floats);
 
+/* Test-time mirroring, `_internal_maybe_mirror_and_predict` (predict_from_raw_data.py:541-557): with axes_mask != 0 (bit a =
+ * array axis a of the allowed mirroring axes) every tile's logits become the fp32 mean over the plain forward and the
+ * forwards of all non-empty axis combinations of the flipped tile, flipped back -- (2^axes) x the network cost.  BOA runs
+ * every model with tta=False (TS/python_api.py:753); the switch exists because nnUNetPredictor(use_mirroring=True) does. */
+int boa_net_set_mirroring(boa_net* net, int axes_mask);
+
 /* network(x) for a batch of tiles gathered from a resident volume
  * (replaces `self.network(workon)` predict_from_raw_data.py:543 + producer thread :568-571):
  *   volume   dev fp32 [Cin][V0][V1][V2] (already normalised); tile voxels outside the volume read as 0
@@ -316,6 +322,11 @@ int boa_label_select(boa_ctx* ctx, const uint8_t* dev_labels, size_t n, int mode
  * to the slice border through background.  scratch_i32: dev int32 [n]; scratch_u8: dev uint8 [n]; out must not alias. */
 int boa_fill_holes_2d(boa_ctx* ctx, const uint8_t* dev_mask, int Z, int Y, int X, int32_t* dev_scratch_i32,
                       uint8_t* dev_scratch_u8, uint8_t* dev_out);
+/* remove_outside_of_mask (TS/postprocessing.py:101-131, `heartchambers_highres`): scipy.ndimage.binary_dilation(mask,
+ * iterations) with the default 6-neighbour cross and border_value 0; the caller then clears the labels where the result is
+ * 0 (boa_mask_assign with invert = 1).  iterations >= 1; tmp: dev uint8 scratch of the same size; no aliasing. */
+int boa_binary_dilate_cross(boa_ctx* ctx, const uint8_t* dev_mask, uint8_t* dev_out, uint8_t* dev_tmp, int Z, int Y, int X,
+                            int iterations);
 /* `out[filled] = label` (BCA/body_parts/postprocess.py:50): out[i] = value where (mask[i] != 0) != invert. */
 int boa_mask_assign(boa_ctx* ctx, const uint8_t* dev_mask, size_t n, int invert, int value, uint8_t* dev_out);
 /* the part -> combined merge `seg_combined[seg == jdx] = class_map_inv[name]` (TS/nnunet.py:553-556) on label volumes that

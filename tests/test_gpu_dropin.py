@@ -84,7 +84,7 @@ def test_compute_all_models_total_bca(tmp_path, monkeypatch):
     compute_all_models(ct_path, out, ["total"], params, recompute=False)
     assert os.path.getmtime(out / "total.nii.gz") == before
     with pytest.raises(NotImplementedError):
-        compute_all_models(ct_path, out, ["heartchambers_highres"], params)
+        compute_all_models(ct_path, out, ["coronary_arteries"], params)
     # crop-cascade model: rough 6 mm `total` -> lung mask -> native-resolution model; same result as the array-level driver
     from boa_hip.task import run_cascade_task
     compute_all_models(ct_path, out, ["lung_vessels"], params)
@@ -153,3 +153,63 @@ def test_error_conventions(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="inf"):
         p.predict_sliding_window_return_logits(x)
     p.close()
+
+
+def test_heartchambers_highres_cascade_with_remove_outside(tmp_path, monkeypatch):
+    """The licensed cascade task (TS/python_api.py:493-505): robust_crop -> the 3 mm `total` model (Dataset297) makes the crop
+    mask (margin 20 mm, python_api.py:726), the task model runs at native resolution on the crop, and the result is cleared
+    outside the union of heart / aorta / inferior_vena_cava dilated by int(10 mm / mean spacing) voxels
+    (TS/nnunet.py:711-716, TS/postprocessing.py:101-131).  File-level result == the array-level composition with the
+    dilation done by scipy (the reference's own call)."""
+    from scipy import ndimage
+    from boa_hip import label_maps, model_store, nifti, plans
+    from boa_hip.compute.inference import compute_all_models, get_context
+    from boa_hip.synthetic import ct_phantom
+    from boa_hip.task import SegmentationTask
+    root = tmp_path / "results"
+    for tid, nc, name, trainer, sp in ((297, 118, "TotalSegmentator_3mm", "nnUNetTrainer_4000epochs_NoMirroring", (3.0, 3.0, 3.0)),
+                                       (301, 8, "heartchambers_highres", "nnUNetTrainer", (1.5, 1.5, 1.5))):
+        pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc, spacing=sp)
+        geom = plans.model_config_from_plans(pj, dj).geometry
+        model_store.write_model_folder(str(root), tid, name, trainer, pj, dj, [plans.synthetic_state_dict(geom, seed=tid)])
+    monkeypatch.setenv("nnUNet_results", str(root))
+    ct = ct_phantom((64, 56, 60), seed=9)
+    aff = np.diag([1.5, 1.5, 1.5, 1.0])
+    ct_path = tmp_path / "ct.nii.gz"
+    nifti.save(ct_path, ct, aff)
+    out = tmp_path / "seg"
+    params = {"preview": False, "fast": False, "ml": True, "nr_thr_resamp": 1, "nr_thr_saving": 1, "quiet": True, "verbose": False,
+              "device": "gpu", "license_number": "aca_XXXXXXXXXXXXXXX"}
+    compute_all_models(ct_path, out, ["heartchambers_highres"], params)
+    got = nifti.load(out / "heartchambers_highres.nii.gz")[0]
+    ctx = get_context("gpu")
+    rough = SegmentationTask(ctx, "total", model_store.load_task_models("total_fast"), resample=3.0, multimodel=False)
+    organ = rough.predict_image(ct, aff)
+    rough.close()
+    inv = label_maps.CLASS_MAP_TOTAL_INV
+    crop_mask = (organ == inv["heart"]).astype(np.uint8)
+    t = SegmentationTask(ctx, "heartchambers_highres", model_store.load_task_models("heartchambers_highres"), resample=None, multimodel=False)
+    seg = t.predict_image(ct, aff, crop_mask=crop_mask, crop_addon=[20, 20, 20])
+    t.close()
+    rm = np.isin(organ, [inv[n] for n in ("heart", "aorta", "inferior_vena_cava")])
+    vx = int(10 / np.mean(np.array([1.5, 1.5, 1.5], dtype=np.float32)))
+    want = seg.copy()
+    want[ndimage.binary_dilation(rm, iterations=vx) == 0] = 0
+    np.testing.assert_array_equal(got, want)
+    assert (seg != want).any() and (want > 0).any()      # the post-processing removed something and kept something
+
+
+def test_remove_outside_of_mask_vs_scipy():
+    from scipy import ndimage
+    from boa_hip.compute.inference import get_context
+    from boa_hip.task import remove_outside_of_mask
+    rng = np.random.default_rng(2)
+    seg = rng.integers(0, 9, size=(23, 31, 19)).astype(np.uint8)
+    mask = np.zeros(seg.shape, np.uint8)
+    mask[5:9, 10:14, 3:6] = 1
+    mask[20, 29, 17] = 3
+    mask[0, 0, 0] = 1
+    for addon in (1, 2, 5):
+        want = seg.copy()
+        want[ndimage.binary_dilation(mask, iterations=addon) == 0] = 0
+        np.testing.assert_array_equal(remove_outside_of_mask(get_context("gpu"), seg, mask, addon), want)

@@ -145,3 +145,47 @@ def test_fp32_total_pipeline_labels_vs_oracle(ctx):
     print(f"total pipeline: exact mode label flips {flips32} of {want.size}; fp16 mode flip fraction {flips16:.3g}")
     assert flips32 <= max(1, FP32_FLIP_TOL * want.size)
     assert flips16 <= FP16_FLIP_BOUND
+
+
+@pytest.mark.parametrize("axes", [(0, 1, 2), (1, 2), (0,)])
+def test_mirroring_tta_vs_oracle(ctx, axes):
+    """use_mirroring=True (predict_from_raw_data.py:541-557): mean over the plain forward and all axis combinations of the
+    flipped tile, in exact mode against the same loop over the torch-CPU fp32 network; then the fp16 production mode's flip
+    fraction.  (BOA itself never mirrors: tta=False, TS/python_api.py:753.)"""
+    import itertools
+    import torch
+    from boa_hip.predictor import HipPredictor
+    from oracle import sliding_window as osw
+    geom, blob, net = _small_net((32, 32, 32), (32, 64), 4, 2)
+
+    def mirrored(patch):                              # patch [1, C, *P] fp32
+        with torch.inference_mode():
+            x = torch.from_numpy(np.ascontiguousarray(patch))
+            pred = net(x)
+            m = [a + 2 for a in axes]
+            combos = [c for i in range(len(m)) for c in itertools.combinations(m, i + 1)]
+            for c in combos:
+                pred += torch.flip(net(torch.flip(x, c)), c)
+            pred /= (len(combos) + 1)
+            return pred.numpy()
+
+    torch.set_num_threads(8)
+    vol = np.random.default_rng(12).standard_normal((1, 40, 36, 44)).astype(np.float32)
+    ref = osw.predict_sliding_window_return_logits(mirrored, vol, [32, 32, 32], 4, 0.5)
+    res = {}
+    for prec in ("fp32", "fp16"):
+        p = HipPredictor(ctx, geom, tile_step_size=0.5, max_batch=3, precision=prec, use_mirroring=True, allowed_mirroring_axes=axes)
+        p.set_parameters([blob])
+        res[prec] = p.predict_segmentation(vol)
+        p.close()
+    p = HipPredictor(ctx, geom, tile_step_size=0.5, max_batch=3, precision="fp32")
+    p.set_parameters([blob])
+    plain = p.predict_segmentation(vol)
+    p.close()
+    want = ref.argmax(0)
+    flips32 = int((res["fp32"] != want).sum())
+    print(f"mirroring {axes}: exact mode flips {flips32} of {want.size}; fp16 flip fraction {float((res['fp16'] != want).mean()):.3g}; "
+          f"differs from the unmirrored prediction on {float((plain != want).mean()):.3g} of the voxels")
+    assert flips32 <= max(1, FP32_FLIP_TOL * want.size)
+    assert float((res["fp16"] != want).mean()) <= FP16_FLIP_BOUND
+    assert (plain != want).mean() > 1e-3        # mirroring really changed the prediction
