@@ -262,11 +262,21 @@ def main():
 
     d_ct = DevArray.from_numpy(ctx, ct)                                  # resident int16 CT, file axis order
 
+    stage_log = {}
+
+    def stage(name, t0):
+        if os.environ.get("BOA_BENCH_STAGES"):
+            ctx.sync()
+            stage_log[name] = stage_log.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
     def step(d_in, download=False):
         """One CT through total -> total measurements -> bca.  `download`: also bring the label volumes to the host."""
         outs = []
+        ts_ = time.perf_counter()
         d_total = total_task.predict_image(d_in, affine, return_device=True)
         outs.append(d_total)
+        ts_ = stage("total", ts_)
         # compute_measurements' view: SimpleITK (z,y,x) arrays of the file (BOA/compute/measurements.py:257-258)
         c_zyx = d_in.transpose((2, 1, 0)).contiguous(np.int16, force_copy=True)
         s_zyx = d_total.transpose((2, 1, 0)).contiguous(force_copy=True)
@@ -275,10 +285,12 @@ def main():
         d_mask.free()
         c_zyx.free()
         s_zyx.free()
+        ts_ = stage("total measurements", ts_)
         res = None
         if pipe is not None:
             res = pipe.run_resident(d_in, affine, d_total)
             outs += [res["body_parts"], res["body_regions"], res["tissues"]]
+            ts_ = stage("bca", ts_)
         host = [a.download() for a in outs] if download else None
         chk = None
         if download:
@@ -342,6 +354,8 @@ def main():
             if v["launches"]:
                 log(f"  {k:16s} {v['ms']:10.1f} ms  {v['launches']:8d} launches  "
                     f"{v['flops'] / max(v['ms'], 1e-9) / 1e9:9.1f} TFLOP/s  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:9.1f} GB/s")
+        if stage_log:
+            log("  stage wall times (s, synchronised, all steps): " + ", ".join(f"{k} {v:.3f}" for k, v in stage_log.items()))
         log(f"  sum of event-timed kernel classes {total_ms:.1f} ms of {elapsed * 1e3:.1f} ms wall; kernel variants {counters}")
         n_vol = (1 if shared else args.gpus) * args.steps
         res = {

@@ -246,13 +246,32 @@ extern "C" int boa_tissue_projections(boa_ctx* c, const uint8_t* dev_tissues, co
 
 // ------------------------------------------------------------------------------------------------------
 // per-label HU histogram (label 0 = background is never measured by the reference and is skipped)
-// Each thread takes 16 consecutive voxels (one 16-byte label load, two 16-byte HU loads) and issues one atomic per RUN of
-// equal (label, bin) keys; a wave whose 1 024 voxels all carry the same key (air around the patient, the inside of a large
-// organ at constant HU) issues ONE atomic -- or none when that key is "not measured".  A volume of a few constant regions
-// used to serialise ~10^8 atomics on a handful of addresses (57 ms per pass at 512^3; now memory bound).
+// Per-label HU histogram with a workgroup-private table in LDS.  A CT's histogram is concentrated -- a label's voxels fall
+// into ~100 neighbouring HU bins, i.e. a handful of cache lines -- so per-voxel global atomics serialise in the L2 (57 ms
+// per pass at 512^3, however the voxels are batched).  Each workgroup walks a contiguous range of voxels (few distinct
+// labels: organs are compact) and counts into LDS: up to HIST_SLOTS labels (assigned on first sight) x HIST_WIN bins
+// starting at HU -1024; voxels of further labels or outside the window go to the global table directly.  The LDS table is
+// added to the global one once at the end (only its non-zero entries).  A wave whose 1 024 voxels all carry the same key
+// (air around the patient) issues one LDS atomic, or none when the key is "not measured".
+#define HIST_SLOTS 8
+#define HIST_WIN 4096
+
 __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
                                                     const unsigned char* __restrict__ mask, size_t n_all, size_t head, int hu_min,
-                                                    int nbins, unsigned int* __restrict__ hist) {
+                                                    int nbins, unsigned int* __restrict__ hist, size_t groups_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hist_smem[];
+    unsigned int (*cnt)[HIST_WIN] = (unsigned int (*)[HIST_WIN])hist_smem;   // [HIST_SLOTS][HIST_WIN]: 128 KiB (dynamic LDS)
+    __shared__ unsigned char lut[256];                   // label -> slot, 0xFF unseen, 0xFE no slot left
+    __shared__ unsigned char fresh[256];
+    __shared__ int slot_label[HIST_SLOTS];
+    __shared__ int nslots;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HIST_SLOTS * HIST_WIN; i += 256) (&cnt[0][0])[i] = 0u;
+    lut[tid] = 0xFF;
+    fresh[tid] = 0;
+    if (tid == 0) nslots = 0;
+    __syncthreads();
+    const int win_lo = -1024 - hu_min;  // first bin of the LDS window
     // voxels [0, head) and the last (n - head) % 16 are handled one by one (unaligned views: z-slabs of a volume)
     const unsigned char* labels0 = labels;
     const short* ct0 = ct;
@@ -262,16 +281,23 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
     if (mask) mask += head;
     const size_t n = n_all - head;
     const size_t n16 = n / 16;
-    const size_t stride = (size_t)gridDim.x * 256;
-    auto key_of = [&](int l, int hu, int m) {
-        if (l == 0 || !m) return -1;
+    auto bin_of = [&](int hu) {
         int b = hu - hu_min;
-        b = b < 0 ? 0 : (b >= nbins ? nbins - 1 : b);
-        return l * nbins + b;
+        return b < 0 ? 0 : (b >= nbins ? nbins - 1 : b);
     };
-    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g - threadIdx.x % 64 < n16; g += stride) {  // whole waves iterate together
+    auto count = [&](int l, int b, unsigned c) {  // l != 0
+        const int s = lut[l];
+        const int w = b - win_lo;
+        if (s < HIST_SLOTS && (unsigned)w < (unsigned)HIST_WIN)
+            atomicAdd(&cnt[s][w], c);
+        else
+            atomicAdd(&hist[(size_t)l * nbins + b], c);
+    };
+    const size_t g_begin = (size_t)blockIdx.x * groups_per_block * 256;   // groups of 16 voxels, 256 per iteration
+    for (size_t it = 0; it < groups_per_block; ++it) {
+        const size_t g = g_begin + it * 256 + tid;
         const bool live = g < n16;
-        int key[16];
+        int lab[16], bin[16];
         if (live) {
             union {
                 uint4 u;
@@ -286,47 +312,71 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
             hb.u[1] = *(const uint4*)(ct + g * 16 + 8);
             if (mask) mb.u = *(const uint4*)(mask + g * 16);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) key[i] = key_of(lb.b[i], hb.h[i], mask ? mb.b[i] : 1);
+            for (int i = 0; i < 16; ++i) {
+                lab[i] = (mask && !mb.b[i]) ? 0 : lb.b[i];
+                bin[i] = bin_of(hb.h[i]);
+                if (lab[i] && lut[lab[i]] == 0xFF) fresh[lab[i]] = 1;   // benign race: every writer stores 1
+            }
         } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) key[i] = -1;
+            for (int i = 0; i < 16; ++i) lab[i] = 0, bin[i] = 0;
         }
+        __syncthreads();
+        if (fresh[tid]) {   // a label seen for the first time by this workgroup: give it a slot while there are any
+            const int sidx = atomicAdd(&nslots, 1);
+            lut[tid] = sidx < HIST_SLOTS ? (unsigned char)sidx : 0xFE;
+            if (sidx < HIST_SLOTS) slot_label[sidx] = tid;
+            fresh[tid] = 0;
+        }
+        __syncthreads();
+        // whole wave on one key: one atomic (or none)
         bool uni = true;
 #pragma unroll
-        for (int i = 1; i < 16; ++i) uni = uni && key[i] == key[0];
-        const int k0 = __builtin_amdgcn_readfirstlane(key[0]);
-        // dead lanes of the last wave count as "same as the wave" with weight 0
-        const bool same = live ? (uni && key[0] == k0) : true;
+        for (int i = 1; i < 16; ++i) uni = uni && lab[i] == lab[0] && (lab[0] == 0 || bin[i] == bin[0]);
+        const int l0 = __builtin_amdgcn_readfirstlane(lab[0]), b0 = __builtin_amdgcn_readfirstlane(bin[0]);
+        const bool same = live ? (uni && lab[0] == l0 && (l0 == 0 || bin[0] == b0)) : true;
         if (__builtin_amdgcn_ballot_w64(!same) == 0) {
-            const unsigned cnt = 16u * (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
-            if (k0 >= 0 && (threadIdx.x & 63) == 0 && cnt) atomicAdd(&hist[k0], cnt);
+            const unsigned c = 16u * (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
+            if (l0 != 0 && (tid & 63) == 0 && c) count(l0, b0, c);
             continue;
         }
         if (!live) continue;
-        int run_key = key[0];
+        int rl = lab[0], rb = bin[0];
         unsigned run = 1;
 #pragma unroll
         for (int i = 1; i < 16; ++i) {
-            if (key[i] == run_key) {
+            if (lab[i] == rl && (rl == 0 || bin[i] == rb)) {
                 ++run;
             } else {
-                if (run_key >= 0) atomicAdd(&hist[run_key], run);
-                run_key = key[i];
+                if (rl) count(rl, rb, run);
+                rl = lab[i];
+                rb = bin[i];
                 run = 1;
             }
         }
-        if (run_key >= 0) atomicAdd(&hist[run_key], run);
+        if (rl) count(rl, rb, run);
     }
-    // tail (n % 16 voxels) and head
-    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n16 * 16)) {
-        const size_t i = n16 * 16 + threadIdx.x;
-        const int k = key_of(labels[i], ct[i], mask ? mask[i] : 1);
-        if (k >= 0) atomicAdd(&hist[k], 1u);
+    // tail (n % 16 voxels) and head, one by one straight into the global table
+    if (blockIdx.x == 0) {
+        if (tid < (int)(n - n16 * 16)) {
+            const size_t i = n16 * 16 + tid;
+            const int l = (mask && !mask[i]) ? 0 : labels[i];
+            if (l) atomicAdd(&hist[(size_t)l * nbins + bin_of(ct[i])], 1u);
+        }
+        if (tid < (int)head) {
+            const int l = (mask0 && !mask0[tid]) ? 0 : labels0[tid];
+            if (l) atomicAdd(&hist[(size_t)l * nbins + bin_of(ct0[tid])], 1u);
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (unsigned)head) {
-        const size_t i = threadIdx.x;
-        const int k = key_of(labels0[i], ct0[i], mask0 ? mask0[i] : 1);
-        if (k >= 0) atomicAdd(&hist[k], 1u);
+    __syncthreads();
+    const int ns = min(nslots, HIST_SLOTS);
+    for (int i = tid; i < ns * HIST_WIN; i += 256) {
+        const unsigned c = (&cnt[0][0])[i];
+        if (c) {
+            const int sidx = i / HIST_WIN, w = i - sidx * HIST_WIN;
+            const int b = win_lo + w;
+            if (b >= 0 && b < nbins) atomicAdd(&hist[(size_t)slot_label[sidx] * nbins + b], c);
+        }
     }
 }
 
@@ -354,10 +404,16 @@ extern "C" int boa_label_hu_histogram(boa_ctx* c, const int16_t* dev_ct, const u
     size_t head = (size_t)((16 - ((uintptr_t)dev_labels & 15)) & 15);
     if (head > n) head = n;
     const bool together = (((uintptr_t)dev_ct + 2 * head) & 15) == 0 && (!dev_mask || (((uintptr_t)dev_mask + head) & 15) == 0);
-    int grid = (int)std::min<size_t>((n / 16 + 255) / 256 + 1, (size_t)c->cu_count * 16);
+    // contiguous voxel ranges per workgroup (few labels each): ~4 workgroups per CU, at least one 4 096-voxel iteration
+    const size_t iters = ((n - head) / 16 + 255) / 256;
+    const size_t gpb = std::max<size_t>(1, (iters + (size_t)c->cu_count * 4 - 1) / ((size_t)c->cu_count * 4));
+    const int grid = (int)std::max<size_t>(1, (iters + gpb - 1) / gpb);
     KernelTimer t(c, BOA_K_AGG, 0, (double)n * (3.0 + (dev_mask ? 1 : 0)));
     if (together) {
-        hipLaunchKernelGGL(k_label_hist, dim3(grid), dim3(256), 0, c->stream, dev_ct, dev_labels, dev_mask, n, head, hu_min, nbins, dev_hist);
+        static bool once = (hipFuncSetAttribute((const void*)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024), true);
+        (void)once;
+        hipLaunchKernelGGL(k_label_hist, dim3(grid), dim3(256), (size_t)HIST_SLOTS * HIST_WIN * 4, c->stream, dev_ct, dev_labels, dev_mask, n,
+                           head, hu_min, nbins, dev_hist, gpb);
     } else {
         hipLaunchKernelGGL(k_label_hist_scalar, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 32)), dim3(256), 0,
                            c->stream, dev_ct, dev_labels, dev_mask, n, hu_min, nbins, dev_hist);
@@ -631,7 +687,7 @@ extern "C" int boa_ccl26(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int 
     BOA_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
     BOA_HIP_TRY(hipMemsetAsync(dev_sizes, 0, n * sizeof(uint32_t), c->stream));
     unsigned grid = (unsigned)((n + 255) / 256);
-    KernelTimer t(c, BOA_K_AGG, 0, (double)n * 14.0);
+    KernelTimer t(c, BOA_K_MORPH, 0, (double)n * 14.0);
     hipLaunchKernelGGL(k_ccl_init, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, dev_roots);
     hipLaunchKernelGGL(k_ccl_merge, dim3(grid), dim3(256), 0, c->stream, dev_mask, Z, Y, X, dev_roots);
     hipLaunchKernelGGL(k_ccl_compress, dim3((unsigned)((n + 256 * CCL_VPT - 1) / (256 * CCL_VPT))), dim3(256), 0, c->stream, n, dev_roots,

@@ -2,8 +2,11 @@
 #pragma once
 #include "common.h"
 
-// Activation tensors are channels-last fp16: [N][D][H][W][C] (D,H,W = nnU-Net array axes X,Y,Z; W contiguous
-// in space, C contiguous in memory).  A "source" is an activation plus the deferred InstanceNorm+LeakyReLU of
+// Activation tensors are CHUNK-PLANAR fp16: [N][C/16][D][H][W][16] (D,H,W = nnU-Net array axes X,Y,Z): the 16 channels of
+// one MFMA K-chunk of a voxel are 32 contiguous bytes and consecutive voxels of a row are consecutive in memory, so a
+// producer's wave load of one chunk reads 1 KiB of consecutive bytes (a channels-last record layout wastes half of every
+// fetched line when one chunk is staged per pass: tools/load_pattern.hip measures 3.2 against 6.3 TB/s of useful bytes).
+// The ncdhw helpers below convert from / to PyTorch order.  A "source" is an activation plus the deferred InstanceNorm+LeakyReLU of
 // its producer: y = lrelu(x * scale[n][c] + shift[n][c]); ss == nullptr means identity (raw tensor).
 struct ActSrc {
     const __half* data = nullptr;
@@ -67,7 +70,7 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
 // mode 1: pred * gauss accumulated into fp16 acc/n at `start` (NN/inference/predict_from_raw_data.py:611-614).
 int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const int P[3], int C, const float* w,
                 const float* bias, float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc,
-                uint16_t* nacc, const int PV[3], const int start[3]);
+                uint16_t* nacc, const int PV[3], const int start[3], size_t plane_stride = 0);
 
 // ---- shared device-side definitions -------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

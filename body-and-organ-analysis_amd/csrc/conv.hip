@@ -251,16 +251,18 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs p) {
             const __half* base;
             const float* ss;
             int C;
+            // chunk-planar activations [N][C/16][voxel][16]: plane of this chunk + this thread's octet
             if (cg < p.C0) {
-                base = p.src0 + (size_t)n * in_vox * p.C0 + cg;
+                base = p.src0 + ((size_t)n * p.C0 + (cg & ~15)) * in_vox + (cg & 15);
                 ss = p.ss0 ? p.ss0 + ((size_t)n * p.C0 + cg) * 2 : nullptr;
                 C = p.C0;
             } else {
                 cg -= p.C0;
-                base = p.src1 + (size_t)n * in_vox * p.C1 + cg;
+                base = p.src1 + ((size_t)n * p.C1 + (cg & ~15)) * in_vox + (cg & 15);
                 ss = p.ss1 ? p.ss1 + ((size_t)n * p.C1 + cg) * 2 : nullptr;
                 C = p.C1;
             }
+            (void)C;
             float sc[8], sh[8];
             if (ss) {
 #pragma unroll
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs p) {
                 int gi = lds_tab[v];
                 uint4 val = make_uint4(0, 0, 0, 0);
                 if (gi >= 0) {
-                    val = *(const uint4*)(base + (size_t)gi * C);
+                    val = *(const uint4*)(base + (size_t)gi * 16);
                     if (ss) val = norm_act8(val, sc, sh, p.slope);
                 }
                 *(uint4*)(dstp + v * 16) = val;
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs p) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (ovox[r] < 0) continue;
-        __half* op = p.out + ((size_t)n * out_vox + ovox[r]) * p.Cout + cout0 + 4 * kh;
+        // couts cout0 + 8 g + 4 kh + j -> plane cout0 / 16 + g / 2, offset 8 (g % 2) + 4 kh + j
+        __half* op = p.out + ((size_t)n * p.Cout + cout0) * out_vox + (size_t)ovox[r] * 16 + 4 * kh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             union {
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs p) {
                 s[g * 4 + j] += vr;
                 q[g * 4 + j] = __builtin_fmaf(vr, vr, q[g * 4 + j]);
             }
-            *(uint2*)(op + 8 * g) = pk.u;
+            *(uint2*)(op + (size_t)(g >> 1) * 16 * out_vox + 8 * (g & 1)) = pk.u;
         }
     }
 #pragma unroll
@@ -551,7 +554,8 @@ __global__ __launch_bounds__(256) void k_conv_first(FirstArgs p) {
 #pragma unroll
     for (int v = 0; v < FV; ++v) {
         if (ox < p.P0 && oy < p.P1 && oz + v < p.P2) {
-            __half* op = p.out + (((size_t)n * p.P0 + ox) * p.P1 + oy) * (size_t)p.P2 * p.Cout + (size_t)(oz + v) * p.Cout + cout0;
+            const size_t pvox = (size_t)p.P0 * p.P1 * p.P2;
+            __half* op = p.out + ((size_t)n * p.Cout + cout0) * pvox + ((((size_t)ox) * p.P1 + oy) * (size_t)p.P2 + (oz + v)) * 16;
             union {
                 uint4 u[4];
                 __half h[32];
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(256) void k_conv_first(FirstArgs p) {
                 q[c] = __builtin_fmaf(vr, vr, q[c]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ((uint4*)op)[j] = pk.u[j];
+            for (int j = 0; j < 4; ++j) *(uint4*)(op + (size_t)(j >> 1) * 16 * pvox + 8 * (j & 1)) = pk.u[j];  // chunk-planar
         }
     }
     // recursive-halving reduction over the wave: after step m a lane keeps half of its channels, summed with its
@@ -802,7 +806,8 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
                 c.h[0] = __float2half_rn(hi4[0]); c.h[1] = __float2half_rn(hi4[1]); w8[pr * 4 + 2] = c.u;
                 c.h[0] = __float2half_rn(hi4[2]); c.h[1] = __float2half_rn(hi4[3]); w8[pr * 4 + 3] = c.u;
             }
-            __half* dst = p.out + ((size_t)n * ovox + ((size_t)(tx * MF0 + x) * p.P1 + ty * MF1 + y) * p.P2 + tz * MF2 + l31) * 32 + kh * 16;
+            // chunk-planar [N][2][voxel][16]: lane (voxel, kh) owns plane kh -> a wave stores two runs of 1 KiB
+            __half* dst = p.out + ((size_t)(n * 2 + kh) * ovox + ((size_t)(tx * MF0 + x) * p.P1 + ty * MF1 + y) * p.P2 + tz * MF2 + l31) * 16;
             *(uint4*)dst = make_uint4(w8[0], w8[1], w8[2], w8[3]);
             *(uint4*)(dst + 8) = make_uint4(w8[4], w8[5], w8[6], w8[7]);
         }
@@ -971,7 +976,7 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int cc = min(c0 + b, ncc - 1);
-            val[b] = *(const uint4*)(p.src + ((size_t)n * in_vox + vi) * p.Cin + cc * 16 + kh * 8);
+            val[b] = *(const uint4*)(p.src + (((size_t)n * ncc + cc) * in_vox + vi) * 16 + kh * 8);  // chunk-planar
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -998,7 +1003,8 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     const int npairs = taps * nco;
     // after the slab transpose this lane stores couts [8 sq, 8 sq + 8) of input voxels sv and sv + 16 of the wave
     const int sv = lane >> 2, sq = lane & 3;
-    size_t obase[2];
+    size_t obase[2];  // (sample * Cout/16) * ovox_total is added per store; this is the spatial part
+    size_t onn[2];
     bool ovalid[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -1007,7 +1013,8 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
         const int nn = ovalid[half] ? (int)(gg / in_vox) : 0;
         const size_t v2 = ovalid[half] ? gg % in_vox : 0;
         const int iz = (int)(v2 % p.Wi), iy = (int)((v2 / p.Wi) % p.Hi), ix = (int)(v2 / ((size_t)p.Wi * p.Hi));
-        obase[half] = (size_t)nn * Do * Ho * Wo + ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2);
+        onn[half] = (size_t)nn;
+        obase[half] = ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2);
     }
     for (int pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
         const int tap = pr / nco, co = pr - tap * nco;
@@ -1047,7 +1054,9 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const uint4 d = *(const uint4*)(slab + (sv + 16 * half) * 80 + sq * 16);
-            if (ovalid[half]) *(uint4*)(p.out + (obase[half] + toff) * p.Cout + co * 32 + sq * 8) = d;
+            // couts co * 32 + 8 sq .. + 8 -> plane co * 2 + sq / 2, offset 8 (sq % 2)
+            if (ovalid[half])
+                *(uint4*)(p.out + ((onn[half] * (p.Cout / 16) + co * 2 + (sq >> 1)) * ((size_t)Do * Ho * Wo) + obase[half] + toff) * 16 + 8 * (sq & 1)) = d;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1092,6 +1101,7 @@ struct HeadArgs {
     unsigned short* acc;
     unsigned short* nacc;
     int V0, V1, V2, s0, s1, s2;
+    size_t plane_stride;  // voxels between the 16-channel planes of `act` (the tile's voxel count; a stash: its own)
 };
 
 template <int F0, int VPT>
@@ -1110,14 +1120,13 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs p) {
     float y[VPT][F0];
 #pragma unroll
     for (int u = 0; u < VPT; ++u) {
-        const uint4* ap = (const uint4*)(p.act + (i + u) * F0);
 #pragma unroll
         for (int v = 0; v < F0 / 8; ++v) {
             union {
                 uint4 u4;
                 __half h[8];
             } x;
-            x.u4 = ap[v];
+            x.u4 = *(const uint4*)(p.act + ((size_t)(v >> 1) * p.plane_stride + (i + u)) * 16 + 8 * (v & 1));  // chunk-planar
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 int c = v * 8 + j;
@@ -1256,8 +1265,10 @@ __global__ __launch_bounds__(256, 5) void k_head_mfma(HeadArgs p) {
         const int zb = (mt % mpr) * 32, row = mt / mpr, p1 = row % p.P1, p0 = row / p.P1;
         const size_t t0 = ((size_t)p0 * p.P1 + p1) * p.P2 + zb;       // first voxel of the M-tile within the tile
         const size_t v0 = ((size_t)(p.s0 + p0) * p.V1 + (p.s1 + p1)) * p.V2 + (p.s2 + zb);  // ... within the volume
-        const uint4* rec = (const uint4*)(p.act + (t0 + l31) * 32);
-        const uint4 r0 = rec[kh], r1 = rec[2 + kh];
+        // chunk-planar: plane 0 = channels 0-15 (MFMA step 0 takes its octet kh), plane 1 = channels 16-31 (step 1); a wave
+        // reads 1 KiB of consecutive bytes per plane
+        const uint4 r0 = *(const uint4*)(p.act + (t0 + l31) * 16 + kh * 8);
+        const uint4 r1 = *(const uint4*)(p.act + (p.plane_stride + t0 + l31) * 16 + kh * 8);
         // the RMW operands of this lane's items: issued before the MFMAs so that their latency overlaps
         uint4 gq8[2], old8[2];
         if (!LOGITS) {
@@ -1319,11 +1330,12 @@ __global__ __launch_bounds__(256, 5) void k_head_mfma(HeadArgs p) {
 
 int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const int P[3], int C, const float* w,
                 const float* bias, float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc,
-                uint16_t* nacc, const int PV[3], const int start[3]) {
+                uint16_t* nacc, const int PV[3], const int start[3], size_t plane_stride) {
     BOA_REQUIRE(F0 == 32 || F0 == 64, "head: features[0]=%d unsupported (32 or 64)", F0);
     HeadArgs a;
     a.act = act; a.ss = ss; a.F0 = F0; a.P0 = P[0]; a.P1 = P[1]; a.P2 = P[2]; a.C = C; a.w = w; a.bias = bias;
     a.slope = slope; a.logits = logits_out; a.gauss = gauss; a.acc = acc; a.nacc = nacc;
+    a.plane_stride = plane_stride ? plane_stride : (size_t)P[0] * P[1] * P[2];
     bool pair = (P[2] % 2 == 0) && F0 == 32;
     if (!logits_out) {
         for (int d = 0; d < 3; ++d)
@@ -1365,12 +1377,14 @@ int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const 
 
 // ======================================================================================================
 // layout helpers
+// PyTorch [N][C][vox] fp32 -> the engine's chunk-planar fp16 layout [N][C/16][vox][16]
 __global__ void k_nchw_to_ndhwc_f16(const float* __restrict__ in, int C, size_t vox, __half* __restrict__ out) {
     const int n = blockIdx.y;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over vox * C, channel fastest
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over C * vox in the output order
     if (i >= vox * C) return;
-    int c = (int)(i % C);
-    size_t v = i / C;
+    const int j = (int)(i % 16);
+    const size_t v = (i / 16) % vox;
+    const int c = (int)(i / (16 * vox)) * 16 + j;
     out[(size_t)n * vox * C + i] = __float2half_rn(in[((size_t)n * C + c) * vox + v]);
 }
 
@@ -1389,7 +1403,7 @@ __global__ void k_ndhwc_to_nchw_f32(const __half* __restrict__ in, const float* 
     if (i >= vox * C) return;
     size_t v = i % vox;
     int c = (int)(i / vox);
-    float f = __half2float(in[((size_t)n * vox + v) * C + c]);
+    float f = __half2float(in[(((size_t)n * (C / 16) + c / 16) * vox + v) * 16 + (c & 15)]);  // chunk-planar
     if (ss) {
         f = __builtin_fmaf(f, ss[((size_t)n * C + c) * 2], ss[((size_t)n * C + c) * 2 + 1]);
         f = f > 0.f ? f : f * slope;

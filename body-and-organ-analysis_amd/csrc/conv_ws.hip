@@ -313,23 +313,25 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
     const __half* base;
     const unsigned* ss;  // 16 words per chunk: 8 channel pairs x {packed scales, packed shifts}
     int C;
+    // chunk-planar activations [N][C/16][voxel][16]: the chunk's plane starts at ((n * C + cg) * in_vox) halves
     if (cg < p.C0) {
-        base = p.src0 + (size_t)tc.n * in_vox * p.C0 + cg;
+        base = p.src0 + ((size_t)tc.n * p.C0 + cg) * in_vox;
         ss = p.ss16_0 ? p.ss16_0 + ((size_t)tc.n * p.C0 + cg) : nullptr;
         C = p.C0;
     } else {
         cg -= p.C0;
-        base = p.src1 + (size_t)tc.n * in_vox * p.C1 + cg;
+        base = p.src1 + ((size_t)tc.n * p.C1 + cg) * in_vox;
         ss = p.ss16_1 ? p.ss16_1 + ((size_t)tc.n * p.C1 + cg) : nullptr;
         C = p.C1;
     }
+    (void)C;
     if (dbg & 64) ss = nullptr;
     rg.skip_halo = skip_halo;
     if (skip_halo) return;
     rg.ok = it.ok;
     rg.live = live;
     rg.has_ss = ss != nullptr;
-    const unsigned cb2 = (unsigned)C * 2u;  // bytes per voxel record; per-sample offsets fit 32 bits (checked on the host)
+    const unsigned cb2 = 32u;  // bytes per voxel in a 16-channel plane: a wave load reads 1 KiB of consecutive bytes per 32 voxels of a row
     // wave-uniform 64-bit base (SGPR pair) + 32-bit lane offset: the `global_load v, v_off, s[base]` form.  The form with a
     // 64-bit VGPR address is starved next to a wave that keeps the matrix pipe busy (tools/valu_under_mfma.hip: 660
     // instead of 64 cycles per load instruction), the scalar-base form is not.
@@ -758,8 +760,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         const int cout0 = tc.cy * 32;
         const bool full = tc.ox0 + p.b0 * p.w0 <= p.Do && tc.oy0 + p.b1 * p.w1 <= p.Ho && tc.oz0 + p.b2 * p.w2 <= p.Wo;
         // wave-uniform base + 32-bit lane offset (scalar-base global_store / global_load forms, see prod_issue)
-        const size_t obase = ((size_t)tc.n * out_vox + ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * p.Cout + cout0;
-        const unsigned olane = ((unsigned)srel0 * (unsigned)p.Cout + (unsigned)kh * 16u) * 2u;
+        // chunk-planar output [N][Cout/16][voxel][16]: this lane writes the 16 couts of plane (cout0 / 16 + kh) of its voxel
+        const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + (((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * 16;
+        const unsigned olane = ((unsigned)kh * (unsigned)out_vox + (unsigned)srel0) * 32u;
         // the tile's 16 bias values of this lane (4 independent loads, one wait)
         float4 bq[4];
         const WS_GLOBAL unsigned char* bbase = sgpr_ptr(p.bias + cout0);
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 c.h[0] = __float2half_rn(hi4[2]); c.h[1] = __float2half_rn(hi4[3]); w[pr * 4 + 3] = c.u;
             }
             if (ok && !(dbg & 4)) {
-                WS_GLOBAL unsigned char* dst = sgpr_ptr(p.out + (obase + (size_t)mrel * p.Cout));
+                WS_GLOBAL unsigned char* dst = sgpr_ptr(p.out + (obase + (size_t)mrel * 16));
                 unsigned ol = olane;
                 asm volatile("" : "+v"(ol));  // keep the 32 -> 64 bit extension in this block (instruction selection is per block)
                 *(WS_GLOBAL u32x4_t*)(dst + ol) = u32x4_t{w[0], w[1], w[2], w[3]};

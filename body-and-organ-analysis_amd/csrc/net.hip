@@ -466,13 +466,15 @@ static int net_head(boa_net* net, int i, const int P[3], int plane_skip, float* 
     const boa_net_desc& d = net->d;
     ConvLayer& last = net->dec.back().back();
     const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2];
-    const size_t skip = (size_t)plane_skip * d.patch[1] * d.patch[2] * d.features[0];
     const float* ss = last.ss + (size_t)i * d.features[0] * 2;
-    if (net->precision == 1)
-        return launch_head_f32(net->ctx, last.out32 + (size_t)i * pv * d.features[0] + skip, ss, d.features[0], P, d.num_classes,
-                               net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc, PV, start);
-    return launch_head(net->ctx, last.out + (size_t)i * pv * d.features[0] + skip, ss, d.features[0], P, d.num_classes, net->head_w,
-                       net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc, PV, start);
+    if (net->precision == 1)   // fp32 mode: channels-last records
+        return launch_head_f32(net->ctx, last.out32 + (size_t)i * pv * d.features[0] + (size_t)plane_skip * d.patch[1] * d.patch[2] * d.features[0],
+                               ss, d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc,
+                               nacc, PV, start);
+    // chunk-planar fp16: skipping leading axis-0 planes is an offset inside every 16-channel plane; plane stride = whole tile
+    return launch_head(net->ctx, last.out + (size_t)i * pv * d.features[0] + (size_t)plane_skip * d.patch[1] * d.patch[2] * 16, ss,
+                       d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc, PV,
+                       start, pv);
 }
 
 // run the conv stack for N tiles; leaves the last decoder activation (+ its ss) in net->dec.back().back()
@@ -732,8 +734,13 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
             int dp = host_defer_planes[t0 + i];
             if (dp > 0) {
                 const boa_stash::Item& it = st->items[item++];
-                if (hipMemcpyAsync(st->arena + it.act_off, act, (size_t)dp * plane * F * 2, hipMemcpyDeviceToDevice,
-                                   net->ctx->stream) != hipSuccess ||
+                // chunk-planar: the first dp axis-0 planes of every 16-channel plane; the stash keeps them planar with its own
+                // plane stride (dp * plane voxels)
+                bool ok_copy = true;
+                for (int k = 0; k < F / 16 && ok_copy; ++k)
+                    ok_copy = hipMemcpyAsync(st->arena + it.act_off + (size_t)k * dp * plane * 32, act + (size_t)k * pv * 16,
+                                             (size_t)dp * plane * 32, hipMemcpyDeviceToDevice, net->ctx->stream) == hipSuccess;
+                if (!ok_copy ||
                     hipMemcpyAsync(st->arena + it.ss_off, ss, (size_t)F * 2 * 4, hipMemcpyDeviceToDevice,
                                    net->ctx->stream) != hipSuccess) {
                     boa_set_error("deferred sliding window: stash copy failed");
@@ -745,9 +752,9 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
             if (dp < d.patch[0]) {
                 int P[3] = {d.patch[0] - dp, d.patch[1], d.patch[2]};
                 int s2[3] = {stt[0] + dp, stt[1], stt[2]};
-                rc = launch_head(net->ctx, act + (size_t)dp * plane * F, ss, F, P, d.num_classes, net->head_w, net->head_b,
+                rc = launch_head(net->ctx, act + (size_t)dp * plane * 16, ss, F, P, d.num_classes, net->head_w, net->head_b,
                                  d.lrelu_slope, nullptr, dev_gauss ? dev_gauss + (size_t)dp * plane : nullptr, dev_acc, dev_n,
-                                 PV, s2);
+                                 PV, s2, pv);
             }
         }
     }
@@ -767,7 +774,7 @@ extern "C" int boa_net_apply_deferred(boa_net* net, const boa_stash* st, const u
         int P[3] = {it.planes, d.patch[1], d.patch[2]};
         BOA_TRY(launch_head(net->ctx, (const __half*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
                             d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
-                            dev_acc, dev_n, PV, it.start));
+                            dev_acc, dev_n, PV, it.start, (size_t)it.planes * d.patch[1] * d.patch[2]));
     }
     return BOA_OK;
 }

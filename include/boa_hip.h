@@ -224,7 +224,8 @@ int boa_net_debug_activation(boa_net* net, int kind, int stage, int conv, int ti
 /* Unit-test seam: the fused 1x1x1 head + Gaussian-weighted fp16 accumulation of ONE tile, launched exactly as the tile
  * loop of boa_net_predict_sliding_window launches it (same kernel selection: the MFMA head when F0 == 32, C <= 31,
  * P[2] % 32 == 0 and the z origin / extent are 8-voxel aligned, else the fp32 VALU head; boa_debug_counter tells which).
- *   act  dev fp16 [P0][P1][P2][F0]: the last decoder conv's raw output;  ss dev fp32 [F0][2] its InstanceNorm (scale, shift)
+ *   act  dev fp16 [F0/16][P0][P1][P2][16] (the engine's chunk-planar activation layout): the last decoder conv's raw output;
+ *        ss dev fp32 [F0][2] its InstanceNorm (scale, shift)
  *   w    dev fp32 [C][F0], b dev fp32 [C]
  *   logits_out != NULL: write the tile's fp32 logits [C][P0][P1][P2] (what `self.network(x)` returns, :543);
  *   logits_out == NULL: `pred *= gauss; acc[sl] += pred; n[sl] += gauss` (:611-614) on acc [C][PV] / n [PV] at `start`.

@@ -39,8 +39,15 @@ class _Head:
         self.b = (rng.standard_normal(Cn) * 0.5).astype(np.float32)
         self.d_w, self.d_b = ctx.from_numpy(self.w), ctx.from_numpy(self.b)
 
+    @staticmethod
+    def planar(act):
+        """channels-last [P0][P1][P2][F0] -> the engine's chunk-planar layout [F0/16][P0][P1][P2][16]."""
+        P, F0 = act.shape[:3], act.shape[3]
+        return np.ascontiguousarray(act.reshape(*P, F0 // 16, 16).transpose(3, 0, 1, 2, 4))
+
     def tile_inputs(self, P, seed):
-        """fp16 activation [P0][P1][P2][F0] (as the last decoder conv stores it, pre-norm) and its (scale, shift)."""
+        """fp16 activation [P0][P1][P2][F0] (the last decoder conv's pre-norm output, channels-last here; `planar` gives the
+        engine's layout) and its (scale, shift)."""
         rng = np.random.default_rng(seed)
         act = (rng.standard_normal((*P, self.F0)) * 1.5).astype(np.float16)
         ss = np.stack([rng.uniform(0.5, 1.5, self.F0), rng.normal(0, 0.3, self.F0)], axis=1).astype(np.float32)
@@ -85,7 +92,7 @@ def _run_case(ctx, PV, P, step, Cn, use_gaussian, seed, n_distinct=None):
     for t, o in enumerate(origins):
         k = t % n_distinct
         if k not in cache:                                                   # a few distinct activations ...
-            cache[k] = ctx.from_numpy(head.tile_inputs(P, seed * 1000 + k)[0].view(np.uint16))
+            cache[k] = ctx.from_numpy(head.planar(head.tile_inputs(P, seed * 1000 + k)[0]).view(np.uint16))
         d_ss = ctx.from_numpy(head.tile_inputs((1, 1, 1), seed * 77 + t)[1])  # ... and every tile its own (scale, shift)
         L = head.logits(cache[k], d_ss, P)                                  # this tile's fp32 logits, from the kernel itself
         head.accumulate(cache[k], d_ss, P, d_g, acc, n, PV, o)
@@ -134,7 +141,7 @@ def test_head_logits_vs_fp32(ctx):
     P, Cn = (8, 8, 64), 25
     head = _Head(ctx, Cn, seed=3)
     act, ss = head.tile_inputs(P, 99)
-    d_act, d_ss = ctx.from_numpy(act.view(np.uint16)), ctx.from_numpy(ss)
+    d_act, d_ss = ctx.from_numpy(head.planar(act).view(np.uint16)), ctx.from_numpy(ss)
     ctx.counters(reset=True)
     got = head.logits(d_act, d_ss, P)
     assert ctx.counters()["head_mfma"] == 1
@@ -158,7 +165,7 @@ def test_unaligned_z_origin_takes_the_fallback_and_agrees(ctx):
     P, PV, Cn = (16, 16, 32), (16, 16, 70), 4
     head = _Head(ctx, Cn, seed=8)
     act, ss = head.tile_inputs(P, 5)
-    d_act, d_ss = ctx.from_numpy(act.view(np.uint16)), ctx.from_numpy(ss)
+    d_act, d_ss = ctx.from_numpy(head.planar(act).view(np.uint16)), ctx.from_numpy(ss)
     g16 = np.ascontiguousarray(sw.compute_gaussian(P, 1. / 8, 10))
     d_g = ctx.from_numpy(g16.view(np.uint16))
     nv = int(np.prod(PV))
