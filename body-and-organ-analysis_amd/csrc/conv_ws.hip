@@ -264,6 +264,16 @@ __device__ __forceinline__ WS_GLOBAL unsigned char* sgpr_ptr(const void* p) {
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_h2(float a, float b) {  // {half(a), half(b)}, round to nearest even
+    union {
+        h2_t v;
+        unsigned u;
+    } c;
+    c.v = __builtin_convertvector(f2_t{a, b}, h2_t);
+    return c.u;
+}
+
 // Deferred InstanceNorm + LeakyReLU on 8 channels in packed fp16: y = fma(x, s, t); y = max(y, slope * y).
 // (scale, shift) are the fp16 roundings produced by k_norm_finalize; one rounding per element (fp16 fma), i.e. the
 // result differs from the fp32-evaluated transform by the rounding of s and t only (numerics).
@@ -341,7 +351,7 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
         // no per-lane test: voxels beyond the halo / outside the tensor have gi == 0 (a valid address, data discarded)
-        if (j < nrounds)
+        if (j < nrounds && !(dbg & 128))  // (dbg 128: ablation without the halo loads)
         // v_mad_u32_u24 (full rate; the plain 32-bit form compiled to the quarter-rate v_mad_u64_u32): voxel index and
         // record size are below 2^24 (checked on the host)
         rg.d[j] = *(const uint4*)(sbase + (__umul24((unsigned)it.gi[j], cb2) + lane_off));
@@ -436,7 +446,7 @@ __device__ __forceinline__ void prod_commit(const ConvArgs& p, ChunkRegs& rg, un
 
 template <int R, int K0, int K1, int K2, bool FIRST>
 __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R], const unsigned char* ap, int h1, int h2,
-                                              f32x16 (&acc)[R]) {
+                                              f32x16 (&acc)[R], const f32x16& c0) {
     // Software pipeline over the (compile-time) taps: the A/B fragments of tap t + WS_PF are read while the MFMAs of
     // tap t issue.  The sched_group_barrier sequence pins that order: [PF x (R+1) reads] then per tap
     // [(R+1) reads][R MFMAs].  The prologue groups matter: without them the per-tap groups are filled one tap late
@@ -462,10 +472,10 @@ __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R
         const int cb = t % NS;
         if (t + WS_PF < T) fetch(t + WS_PF, (t + WS_PF) % NS);
         if (FIRST && t == 0) {
-            // first tap of a tile: C = 0 as an inline constant instead of 16 R zeroed accumulator registers
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // first tap of a tile: C = the conv bias in the D-fragment layout (the accumulators start at bias: no zeroing,
+            // no bias add in the epilogue)
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb], b[cb][r], zero, 0, 0, 0);
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb], b[cb][r], c0, 0, 0, 0);
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb], b[cb][r], acc[r], 0, 0, 0);
@@ -482,7 +492,7 @@ __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R
 // 32 clk), more than the 128 B/clk it has; this form needs 96 B/clk.
 template <int R, int K0, int K2, bool FIRST>
 __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const unsigned char* ap, int h1, int h2,
-                                                f32x16 (&acc)[R]) {
+                                                f32x16 (&acc)[R], const f32x16& c0) {
     // MFMAs run in input-row order (row j feeds the pairs r + dy = j), so row j's registers are dead after its last
     // MFMA and take the same row of the next (dx, dz) group straight away: one set of R + 2 row fragments streams
     // through the groups, only the 3 weight fragments are double-buffered.
@@ -519,8 +529,7 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
                 if (r < 0 || r >= R) continue;
                 ++cnt;
                 if (FIRST && g == 0 && dy == 0) {
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][0], b[jj], zero, 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][0], b[jj], c0, 0, 0, 0);  // C = bias (see consume_chunk)
                 } else {
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][dy], b[jj], acc[r], 0, 0, 0);
                 }
@@ -763,16 +772,6 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         // chunk-planar output [N][Cout/16][voxel][16]: this lane writes the 16 couts of plane (cout0 / 16 + kh) of its voxel
         const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + (((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * 16;
         const unsigned olane = ((unsigned)kh * (unsigned)out_vox + (unsigned)srel0) * 32u;
-        // the tile's 16 bias values of this lane (4 independent loads, one wait)
-        float4 bq[4];
-        const WS_GLOBAL unsigned char* bbase = sgpr_ptr(p.bias + cout0);
-        unsigned bl = (unsigned)kh * 16u;
-        asm volatile("" : "+v"(bl));
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4_t bv = *(const WS_GLOBAL f32x4_t*)(bbase + bl + 32 * gq);
-            bq[gq] = make_float4(bv[0], bv[1], bv[2], bv[3]);
-        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int m = cw * R + r;  // wave-uniform M-tile origin within the block tile
@@ -785,14 +784,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 ok = tc.ox0 + mx + x < p.Do && tc.oy0 + my + y < p.Ho && tc.oz0 + mz + z < p.Wo;
             }
             const float dm = ok ? 1.f : 0.f;
-            float v[16];
+            float v[16];  // conv + bias: the accumulators were started at the bias
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                v[gq * 4 + 0] = acc[r][gq * 4 + 0] + bq[gq].x;
-                v[gq * 4 + 1] = acc[r][gq * 4 + 1] + bq[gq].y;
-                v[gq * 4 + 2] = acc[r][gq * 4 + 2] + bq[gq].z;
-                v[gq * 4 + 3] = acc[r][gq * 4 + 3] + bq[gq].w;
-            }
+            for (int i = 0; i < 16; ++i) v[i] = acc[r][i];
             if (TWO_SETS && two && tc.cy != 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -808,6 +802,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     stA.q[i] = __builtin_fmaf(vm, vm, stA.q[i]);
                 }
             }
+            // (the statistics read v before the swaps below destroy it: without this fence hipcc hoists the swaps and pays 16
+            //  register copies per M-tile to keep v alive)
+            __builtin_amdgcn_sched_barrier(0);
             // D fragment -> voxel records without LDS: v_permlane32_swap exchanges the upper half of one register
             // with the lower half of another.  Lane (kh, voxel) holds couts 8 gq + 4 kh + e; swapping group gq with
             // group gq + 2 leaves the kh = 0 lane with couts [0, 16) and the kh = 1 lane with couts [16, 32) of its
@@ -822,14 +819,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     lo4[e] = __uint_as_float(sw[0]);  // kh 0: cout 8 pr + e      | kh 1: cout 16 + 8 pr + e
                     hi4[e] = __uint_as_float(sw[1]);  // kh 0: cout 8 pr + 4 + e  | kh 1: cout 16 + 8 pr + 4 + e
                 }
-                union {
-                    unsigned u;
-                    __half h[2];
-                } c;
-                c.h[0] = __float2half_rn(lo4[0]); c.h[1] = __float2half_rn(lo4[1]); w[pr * 4 + 0] = c.u;
-                c.h[0] = __float2half_rn(lo4[2]); c.h[1] = __float2half_rn(lo4[3]); w[pr * 4 + 1] = c.u;
-                c.h[0] = __float2half_rn(hi4[0]); c.h[1] = __float2half_rn(hi4[1]); w[pr * 4 + 2] = c.u;
-                c.h[0] = __float2half_rn(hi4[2]); c.h[1] = __float2half_rn(hi4[3]); w[pr * 4 + 3] = c.u;
+                // one v_cvt_pk_f16_f32 (RTNE) per output word
+                w[pr * 4 + 0] = cvt_pk_h2(lo4[0], lo4[1]);
+                w[pr * 4 + 1] = cvt_pk_h2(lo4[2], lo4[3]);
+                w[pr * 4 + 2] = cvt_pk_h2(hi4[0], hi4[1]);
+                w[pr * 4 + 3] = cvt_pk_h2(hi4[2], hi4[3]);
             }
             if (ok && !(dbg & 4)) {
                 WS_GLOBAL unsigned char* dst = sgpr_ptr(p.out + (obase + (size_t)mrel * 16));
@@ -840,6 +834,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             }
         }
     };
+    f32x16 biasv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) biasv[i] = 0.f;
+    int bias_cy = -1;
     TileCoord done_tc;
     done_tc.n = done_tc.cy = done_tc.ox0 = done_tc.oy0 = done_tc.oz0 = done_tc.sp = 0;
     // (one extra iteration for the last tile's deferred epilogue: a single call site -- two inlined copies of the epilogue
@@ -860,6 +858,17 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             st_n = -1;
             slot = cseq.j * 4 + cw;
         }
+        if (tc.cy != bias_cy) {  // this lane's 16 biases of the cout chunk, D-fragment layout (entry 4 gq + e <-> cout 8 gq + 4 kh + e)
+            bias_cy = tc.cy;
+            const WS_GLOBAL unsigned char* bbase = sgpr_ptr(p.bias + tc.cy * 32);
+            unsigned bl = (unsigned)kh * 16u;
+            asm volatile("" : "+v"(bl));
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4_t bv = *(const WS_GLOBAL f32x4_t*)(bbase + bl + 32 * gq);
+                biasv[gq * 4 + 0] = bv[0]; biasv[gq * 4 + 1] = bv[1]; biasv[gq * 4 + 2] = bv[2]; biasv[gq * 4 + 3] = bv[3];
+            }
+        }
         for (int cc = 0; cc < ncc; ++cc) {
             const int g = k * ncc + cc;
             const unsigned char* cur = bufs + (g & 1) * buf_bytes;
@@ -875,13 +884,13 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             WS_STAMP(4);
             if constexpr (YR) {
                 if (cc == 0)
-                    consume_chunk_y<R, K0, K2, true>(bp[0], ap, p.h1, p.h2, acc);
+                    consume_chunk_y<R, K0, K2, true>(bp[0], ap, p.h1, p.h2, acc, biasv);
                 else
-                    consume_chunk_y<R, K0, K2, false>(bp[0], ap, p.h1, p.h2, acc);
+                    consume_chunk_y<R, K0, K2, false>(bp[0], ap, p.h1, p.h2, acc, biasv);
             } else if (cc == 0)
-                consume_chunk<R, K0, K1, K2, true>(bp, ap, p.h1, p.h2, acc);
+                consume_chunk<R, K0, K1, K2, true>(bp, ap, p.h1, p.h2, acc, biasv);
             else
-                consume_chunk<R, K0, K1, K2, false>(bp, ap, p.h1, p.h2, acc);
+                consume_chunk<R, K0, K1, K2, false>(bp, ap, p.h1, p.h2, acc, biasv);
             WS_STAMP(5);
 #if !WS_DEFER_EPILOGUE
             if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc);
