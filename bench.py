@@ -308,6 +308,15 @@ def main():
     for _ in range(args.warmup):
         step(d_ct)
     ctx.sync()
+    if os.environ.get("BOA_BENCH_CPROFILE") and rank == 0:   # host-side hot spots of one step (development aid)
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        step(d_ct)
+        ctx.sync()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
     ctx.counters(reset=True)
     ctx.prof_reset()
     ctx.prof_enable(not args.no_prof)

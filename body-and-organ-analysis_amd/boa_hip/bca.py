@@ -173,21 +173,40 @@ def _slicewise(counts_a: np.ndarray, ml_per_voxel: float):
     return df[["slice_idx"] + COLS]
 
 
+_STAT_ROWS = ["Mean", "StdDev", "Minimum", "25%", "Median", "75%", "Maximum", "Total", "MeanHU"]
+
+
 def _descriptive(df, counts_a, sums_a, lo, hi):
-    """_descriptive_statistics_from_measurements (builder.py:263-307) for slices [lo, hi)."""
-    sw = df[(df.slice_idx >= lo) & (df.slice_idx < hi)].drop("slice_idx", axis=1)
-    m = sw.describe()
-    m.drop("count", inplace=True)
-    m.index = ["Mean", "StdDev", "Minimum", "25%", "Median", "75%", "Maximum"]
-    m.loc["Total"] = sw.sum()
+    """_descriptive_statistics_from_measurements (builder.py:263-307) for slices [lo, hi): pandas `describe()` of the
+    slice-wise volumes (mean, std with ddof 1, min, linear-interpolated quartiles, max) + Total + MeanHU.  Evaluated with the
+    numpy operations pandas itself dispatches to (sum / count, sqrt(sum((x - mean)^2) / (n - 1)), numpy's linear percentile):
+    the same numbers as `DataFrame.describe()` without its ~6 ms of frame bookkeeping per group (0.43 s per volume)."""
+    import pandas as pd
+    cols = [c for c in df.columns if c != "slice_idx"]
+    sel = (df["slice_idx"].to_numpy() >= lo) & (df["slice_idx"].to_numpy() < hi)
+    # one contiguous row per tissue: numpy then reduces each row with the pairwise summation pandas gets on a column
+    x = np.ascontiguousarray(df[cols].to_numpy(dtype=np.float64)[sel].T)      # [tissues, slices]
+    n = x.shape[1]
+    out = np.full((len(_STAT_ROWS), len(cols)), np.nan)
+    if n:
+        mean = x.sum(axis=1) / n
+        out[0] = mean
+        if n > 1:
+            d = mean[:, None] - x
+            out[1] = np.sqrt((d * d).sum(axis=1) / (n - 1))
+        out[2] = x.min(axis=1)
+        out[3:6] = np.percentile(x, [25, 50, 75], axis=1)
+        out[6] = x.max(axis=1)
+    out[7] = x.sum(axis=1)
+    m = pd.DataFrame(out, index=_STAT_ROWS, columns=cols).astype(object)
     c = counts_a[lo:hi].astype(np.int64).sum(axis=0)
     s = sums_a[lo:hi].sum(axis=0)
-    for n, v in TISSUES:
-        m.loc["MeanHU", _tname(n)] = (float(s[v]) / float(c[v])) if c[v] else None
+    for nme, v in TISSUES:
+        m.loc["MeanHU", _tname(nme)] = (float(s[v]) / float(c[v])) if c[v] else None
     adip = [5, 3, 4, 6, 7]
     ca, sa = int(c[adip].sum()), int(s[adip].sum())
     m.loc["MeanHU", "TAT"] = (float(sa) / float(ca)) if ca else None
-    return m.replace({np.nan: None})
+    return m.where(m.notna(), None)
 
 
 def bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae=None, body_parts_override=None) -> dict:

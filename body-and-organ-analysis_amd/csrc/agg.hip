@@ -246,32 +246,33 @@ extern "C" int boa_tissue_projections(boa_ctx* c, const uint8_t* dev_tissues, co
 
 // ------------------------------------------------------------------------------------------------------
 // per-label HU histogram (label 0 = background is never measured by the reference and is skipped)
-// Per-label HU histogram with a workgroup-private table in LDS.  A CT's histogram is concentrated -- a label's voxels fall
-// into ~100 neighbouring HU bins, i.e. a handful of cache lines -- so per-voxel global atomics serialise in the L2 (57 ms
-// per pass at 512^3, however the voxels are batched).  Each workgroup walks a contiguous range of voxels (few distinct
-// labels: organs are compact) and counts into LDS: up to HIST_SLOTS labels (assigned on first sight) x HIST_WIN bins
-// starting at HU -1024; voxels of further labels or outside the window go to the global table directly.  The LDS table is
-// added to the global one once at the end (only its non-zero entries).  A wave whose 1 024 voxels all carry the same key
-// (air around the patient) issues one LDS atomic, or none when the key is "not measured".
-#define HIST_SLOTS 8
-#define HIST_WIN 4096
+// Per-label HU histogram with a workgroup-private HASH TABLE in LDS.  Per-voxel global atomics are hopeless here: a CT's
+// histogram is concentrated (a label's voxels fall into ~100 neighbouring HU bins, a handful of cache lines), and
+// device-scope atomics from the 8 XCDs on the same lines are serialised on the memory side (57 ms per pass at 512^3,
+// however the voxels are batched).  Each workgroup counts its voxels into an open-addressing table keyed by
+// (label, bin) -- HIST_TAB entries of {key, count} in LDS, linear probing, claimed with an LDS compare-and-swap -- whatever
+// the mix of labels (compact organs or the salt-and-pepper output of a random-weight net), and adds the table to the
+// global one when it fills up and at the end: one global atomic per DISTINCT key of ~10^5 voxels instead of one per
+// voxel.  A wave whose 1 024 voxels all carry the same key (air around the patient) issues one LDS atomic, or none when
+// the key is "not measured".
+#define HIST_TAB 16384          // entries: 64 KiB keys + 64 KiB counts
+#define HIST_FLUSH 11000        // distinct keys in the table that trigger a flush (load factor 2/3)
+#define HIST_EMPTY 0xFFFFFFFFu
 
 __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
                                                     const unsigned char* __restrict__ mask, size_t n_all, size_t head, int hu_min,
                                                     int nbins, unsigned int* __restrict__ hist, size_t groups_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hist_smem[];
-    unsigned int (*cnt)[HIST_WIN] = (unsigned int (*)[HIST_WIN])hist_smem;   // [HIST_SLOTS][HIST_WIN]: 128 KiB (dynamic LDS)
-    __shared__ unsigned char lut[256];                   // label -> slot, 0xFF unseen, 0xFE no slot left
-    __shared__ unsigned char fresh[256];
-    __shared__ int slot_label[HIST_SLOTS];
-    __shared__ int nslots;
+    unsigned int* keys = (unsigned int*)hist_smem;   // [HIST_TAB]
+    unsigned int* cnts = keys + HIST_TAB;            // [HIST_TAB]
+    __shared__ int nkeys;
     const int tid = threadIdx.x;
-    for (int i = tid; i < HIST_SLOTS * HIST_WIN; i += 256) (&cnt[0][0])[i] = 0u;
-    lut[tid] = 0xFF;
-    fresh[tid] = 0;
-    if (tid == 0) nslots = 0;
+    for (int i = tid; i < HIST_TAB; i += 256) {
+        keys[i] = HIST_EMPTY;
+        cnts[i] = 0u;
+    }
+    if (tid == 0) nkeys = 0;
     __syncthreads();
-    const int win_lo = -1024 - hu_min;  // first bin of the LDS window
     // voxels [0, head) and the last (n - head) % 16 are handled one by one (unaligned views: z-slabs of a volume)
     const unsigned char* labels0 = labels;
     const short* ct0 = ct;
@@ -285,19 +286,43 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
         int b = hu - hu_min;
         return b < 0 ? 0 : (b >= nbins ? nbins - 1 : b);
     };
-    auto count = [&](int l, int b, unsigned c) {  // l != 0
-        const int s = lut[l];
-        const int w = b - win_lo;
-        if (s < HIST_SLOTS && (unsigned)w < (unsigned)HIST_WIN)
-            atomicAdd(&cnt[s][w], c);
-        else
-            atomicAdd(&hist[(size_t)l * nbins + b], c);
+    auto count = [&](unsigned key, unsigned c) {  // key = label << 16 | bin  (nbins <= 65536)
+        unsigned h = (key * 2654435761u) >> 18;   // 14 bits
+#pragma unroll 1
+        for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (HIST_TAB - 1)) {
+            unsigned k = keys[h];
+            if (k == HIST_EMPTY) {
+                k = atomicCAS(&keys[h], HIST_EMPTY, key);
+                if (k == HIST_EMPTY) {
+                    atomicAdd(&nkeys, 1);
+                    k = key;
+                }
+            }
+            if (k == key) {
+                atomicAdd(&cnts[h], c);
+                return;
+            }
+        }
+        atomicAdd(&hist[(size_t)(key >> 16) * nbins + (key & 0xFFFFu)], c);   // a long probe chain: straight to the global table
+    };
+    auto flush = [&]() {  // whole workgroup
+        for (int i = tid; i < HIST_TAB; i += 256) {
+            const unsigned k = keys[i];
+            if (k != HIST_EMPTY) {
+                atomicAdd(&hist[(size_t)(k >> 16) * nbins + (k & 0xFFFFu)], cnts[i]);
+                keys[i] = HIST_EMPTY;
+                cnts[i] = 0u;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) nkeys = 0;
+        __syncthreads();
     };
     const size_t g_begin = (size_t)blockIdx.x * groups_per_block * 256;   // groups of 16 voxels, 256 per iteration
     for (size_t it = 0; it < groups_per_block; ++it) {
         const size_t g = g_begin + it * 256 + tid;
         const bool live = g < n16;
-        int lab[16], bin[16];
+        unsigned key[16];   // 0 = not measured (label 0 / masked out)
         if (live) {
             union {
                 uint4 u;
@@ -313,48 +338,38 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
             if (mask) mb.u = *(const uint4*)(mask + g * 16);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                lab[i] = (mask && !mb.b[i]) ? 0 : lb.b[i];
-                bin[i] = bin_of(hb.h[i]);
-                if (lab[i] && lut[lab[i]] == 0xFF) fresh[lab[i]] = 1;   // benign race: every writer stores 1
+                const unsigned l = (mask && !mb.b[i]) ? 0u : lb.b[i];
+                key[i] = l ? ((l << 16) | (unsigned)bin_of(hb.h[i])) : 0u;   // label >= 1: never 0
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) lab[i] = 0, bin[i] = 0;
+            for (int i = 0; i < 16; ++i) key[i] = 0u;
         }
-        __syncthreads();
-        if (fresh[tid]) {   // a label seen for the first time by this workgroup: give it a slot while there are any
-            const int sidx = atomicAdd(&nslots, 1);
-            lut[tid] = sidx < HIST_SLOTS ? (unsigned char)sidx : 0xFE;
-            if (sidx < HIST_SLOTS) slot_label[sidx] = tid;
-            fresh[tid] = 0;
-        }
-        __syncthreads();
         // whole wave on one key: one atomic (or none)
         bool uni = true;
 #pragma unroll
-        for (int i = 1; i < 16; ++i) uni = uni && lab[i] == lab[0] && (lab[0] == 0 || bin[i] == bin[0]);
-        const int l0 = __builtin_amdgcn_readfirstlane(lab[0]), b0 = __builtin_amdgcn_readfirstlane(bin[0]);
-        const bool same = live ? (uni && lab[0] == l0 && (l0 == 0 || bin[0] == b0)) : true;
+        for (int i = 1; i < 16; ++i) uni = uni && key[i] == key[0];
+        const unsigned k0 = __builtin_amdgcn_readfirstlane(key[0]);
+        const bool same = live ? (uni && key[0] == k0) : true;
         if (__builtin_amdgcn_ballot_w64(!same) == 0) {
             const unsigned c = 16u * (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
-            if (l0 != 0 && (tid & 63) == 0 && c) count(l0, b0, c);
-            continue;
-        }
-        if (!live) continue;
-        int rl = lab[0], rb = bin[0];
-        unsigned run = 1;
+            if (k0 != 0u && (tid & 63) == 0 && c) count(k0, c);
+        } else if (live) {
+            unsigned rk = key[0], run = 1;
 #pragma unroll
-        for (int i = 1; i < 16; ++i) {
-            if (lab[i] == rl && (rl == 0 || bin[i] == rb)) {
-                ++run;
-            } else {
-                if (rl) count(rl, rb, run);
-                rl = lab[i];
-                rb = bin[i];
-                run = 1;
+            for (int i = 1; i < 16; ++i) {
+                if (key[i] == rk) {
+                    ++run;
+                } else {
+                    if (rk) count(rk, run);
+                    rk = key[i];
+                    run = 1;
+                }
             }
+            if (rk) count(rk, run);
         }
-        if (rl) count(rl, rb, run);
+        __syncthreads();
+        if (nkeys > HIST_FLUSH) flush();   // (uniform: nkeys is read after the barrier by everyone)
     }
     // tail (n % 16 voxels) and head, one by one straight into the global table
     if (blockIdx.x == 0) {
@@ -369,15 +384,7 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
         }
     }
     __syncthreads();
-    const int ns = min(nslots, HIST_SLOTS);
-    for (int i = tid; i < ns * HIST_WIN; i += 256) {
-        const unsigned c = (&cnt[0][0])[i];
-        if (c) {
-            const int sidx = i / HIST_WIN, w = i - sidx * HIST_WIN;
-            const int b = win_lo + w;
-            if (b >= 0 && b < nbins) atomicAdd(&hist[(size_t)slot_label[sidx] * nbins + b], c);
-        }
-    }
+    flush();
 }
 
 __global__ __launch_bounds__(256) void k_label_hist_scalar(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256) void k_label_hist_scalar(const short* __restri
 
 extern "C" int boa_label_hu_histogram(boa_ctx* c, const int16_t* dev_ct, const uint8_t* dev_labels,
                                       const uint8_t* dev_mask, size_t n, int hu_min, int nbins, uint32_t* dev_hist) {
-    BOA_REQUIRE(c && dev_ct && dev_labels && dev_hist && nbins > 0, "boa_label_hu_histogram: bad argument");
+    BOA_REQUIRE(c && dev_ct && dev_labels && dev_hist && nbins > 0 && nbins <= 65536, "boa_label_hu_histogram: bad argument");
     BOA_HIP_TRY(hipMemsetAsync(dev_hist, 0, (size_t)256 * nbins * sizeof(uint32_t), c->stream));
     if (n == 0) return BOA_OK;
     // 16-byte vector loads need the three arrays aligned at the same voxel: skip `head` voxels (views into a volume start
@@ -412,7 +419,7 @@ extern "C" int boa_label_hu_histogram(boa_ctx* c, const int16_t* dev_ct, const u
     if (together) {
         static bool once = (hipFuncSetAttribute((const void*)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024), true);
         (void)once;
-        hipLaunchKernelGGL(k_label_hist, dim3(grid), dim3(256), (size_t)HIST_SLOTS * HIST_WIN * 4, c->stream, dev_ct, dev_labels, dev_mask, n,
+        hipLaunchKernelGGL(k_label_hist, dim3(grid), dim3(256), (size_t)HIST_TAB * 8, c->stream, dev_ct, dev_labels, dev_mask, n,
                            head, hu_min, nbins, dev_hist, gpb);
     } else {
         hipLaunchKernelGGL(k_label_hist_scalar, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 32)), dim3(256), 0,

@@ -234,3 +234,29 @@ def test_cnr_with_constant_autochthon_follows_numpy_semantics():
     assert np.isposinf(M._metrics(st, 0.003375, 30.0, 0.0)["cnr"])
     assert np.isnan(M._metrics(st, 0.003375, 50.0, 0.0)["cnr"])
     assert M._metrics(st, 0.003375, None, None)["cnr"] is None
+
+
+def test_descriptive_statistics_equal_pandas_describe():
+    """bca._descriptive evaluates `DataFrame.describe()` (builder.py:263-307) with the numpy reductions pandas dispatches to;
+    it must give the very same doubles (the reference calls pandas)."""
+    import pandas as pd
+    from boa_hip import bca
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        Z = int(rng.integers(2, 300))
+        counts = rng.integers(0, 50000, size=(Z, 8)).astype(np.uint32)
+        counts[:, 0] = 0
+        sums = rng.integers(-10 ** 6, 10 ** 6, size=(Z, 8)).astype(np.int64)
+        df = bca._slicewise(counts, float(rng.uniform(0.3, 5)) ** 3 / 1000)
+        lo = int(rng.integers(0, Z - 1))
+        hi = int(rng.integers(lo + 1, Z + 1))
+        m = bca._descriptive(df, counts, sums, lo, hi)
+        sw = df[(df.slice_idx >= lo) & (df.slice_idx < hi)].drop("slice_idx", axis=1)
+        ref = sw.describe()
+        ref.drop("count", inplace=True)
+        ref.index = ["Mean", "StdDev", "Minimum", "25%", "Median", "75%", "Maximum"]
+        ref.loc["Total"] = sw.sum()
+        a = m.loc[ref.index, ref.columns].to_numpy(dtype=object)
+        b = ref.replace({np.nan: None}).to_numpy(dtype=object)
+        for x, y in zip(a.ravel(), b.ravel()):
+            assert (x is None and y is None) or float(x) == float(y)
