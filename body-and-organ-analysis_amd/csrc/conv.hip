@@ -954,6 +954,12 @@ struct ConvTArgs {
     float slope;
 };
 
+// One wave = 32 consecutive (flattened) input voxels.  Per (tx, ty, cout chunk) it computes BOTH z taps (TZ = s2
+// accumulators): in the chunk-planar output the voxels 2 iz and 2 iz + 1 of a row are neighbours, so the wave's result for
+// one 16-cout plane is one run of 2 KiB (TZ = 2) of consecutive bytes.  The D fragments go through a per-wave LDS slab
+// [2 planes][32 TZ voxels][16 couts] and leave as 16-byte pieces, lane L taking pieces L, L + 64, ...: every store
+// instruction writes 1 KiB of consecutive bytes (the one-tap-per-pass form wrote 32-byte pieces 64 bytes apart).
+template <int TZ>
 __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -964,9 +970,11 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     const int ncc = p.Cin / 16;
     const size_t in_vox = (size_t)p.Di * p.Hi * p.Wi;
     const size_t total = (size_t)p.N * in_vox;
-    unsigned char* lds = smem + (size_t)wave * (ncc * 1024 + 32 * 80);  // [cc][khalf][32 voxels][8 halves] + slab
+    constexpr int SLAB = 2 * 32 * TZ * 32;  // bytes: [2 planes][32 * TZ output voxels][16 halves]
+    unsigned char* lds = smem + (size_t)wave * (ncc * 1024 + SLAB);  // [cc][khalf][32 voxels][8 halves] + slab
     unsigned char* slab = lds + ncc * 1024;
-    const size_t g = ((size_t)blockIdx.x * 4 + wave) * 32 + l31;  // flattened (n, voxel)
+    const size_t g0 = ((size_t)blockIdx.x * 4 + wave) * 32;  // first flattened (n, voxel) of this wave
+    const size_t g = g0 + l31;
     const bool valid = g < total;
     const int n = valid ? (int)(g / in_vox) : 0;
     const size_t vi = valid ? g % in_vox : 0;
@@ -998,66 +1006,79 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     }
     __builtin_amdgcn_wave_barrier();
     const int Do = p.Di * p.s0, Ho = p.Hi * p.s1, Wo = p.Wi * p.s2;
-    const int taps = p.s0 * p.s1 * p.s2;
+    const size_t ovox = (size_t)Do * Ho * Wo;
     const int nco = p.Cout / 32;
-    const int npairs = taps * nco;
-    // after the slab transpose this lane stores couts [8 sq, 8 sq + 8) of input voxels sv and sv + 16 of the wave
-    const int sv = lane >> 2, sq = lane & 3;
-    size_t obase[2];  // (sample * Cout/16) * ovox_total is added per store; this is the spatial part
-    size_t onn[2];
-    bool ovalid[2];
+    const int npairs = p.s0 * p.s1 * nco;  // (tx, ty, cout chunk); every pair covers the TZ z taps
+    // store side: the slab of one plane holds 32 * TZ output voxels = 64 * TZ pieces of 16 bytes; this lane takes pieces
+    // lane + 64 k (k < TZ) of each plane: output voxel ov = piece / 2 -> input voxel j = ov / TZ, z tap ov % TZ
+    size_t ospat[TZ];
+    size_t onn[TZ];
+    bool ovalid[TZ];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const size_t gg = ((size_t)blockIdx.x * 4 + wave) * 32 + sv + 16 * half;
-        ovalid[half] = gg < total;
-        const int nn = ovalid[half] ? (int)(gg / in_vox) : 0;
-        const size_t v2 = ovalid[half] ? gg % in_vox : 0;
+    for (int k = 0; k < TZ; ++k) {
+        const int ov = (lane + 64 * k) >> 1;
+        const int j = ov / TZ, tz = ov % TZ;
+        const size_t gg = g0 + j;
+        ovalid[k] = gg < total;
+        const size_t nn = ovalid[k] ? gg / in_vox : 0;
+        const size_t v2 = ovalid[k] ? gg % in_vox : 0;
         const int iz = (int)(v2 % p.Wi), iy = (int)((v2 / p.Wi) % p.Hi), ix = (int)(v2 / ((size_t)p.Wi * p.Hi));
-        onn[half] = (size_t)nn;
-        obase[half] = ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2);
+        onn[k] = nn;
+        ospat[k] = ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2 + tz);
     }
     for (int pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
-        const int tap = pr / nco, co = pr - tap * nco;
-        const int tz = tap % p.s2, ty = (tap / p.s2) % p.s1, tx = tap / (p.s2 * p.s1);
-        f32x16 acc;
+        const int txy = pr / nco, co = pr - txy * nco;
+        const int ty = txy % p.s1, tx = txy / p.s1;
+        f32x16 acc[TZ];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const __half* wb = p.wpk + (((size_t)tap * ncc * 2 + kh) * p.Cout + co * 32 + l31) * 8;
-        for (int c0 = 0; c0 < ncc; c0 += 4) {
-            f16x8 a[4];
+        for (int t = 0; t < TZ; ++t)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) a[b] = *(const f16x8*)(wb + (size_t)min(c0 + b, ncc - 1) * 2 * p.Cout * 8);
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        const int tap0 = (tx * p.s1 + ty) * p.s2;
+        for (int c0 = 0; c0 < ncc; c0 += 2) {
+            f16x8 a[TZ][2];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int t = 0; t < TZ; ++t)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    a[t][b] = *(const f16x8*)(p.wpk + ((((size_t)(tap0 + t) * ncc + min(c0 + b, ncc - 1)) * 2 + kh) * p.Cout + co * 32 + l31) * 8);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
                 if (c0 + b < ncc) {
-                    f16x8 bf = *(const f16x8*)(lds + (((c0 + b) * 2 + kh) * 32 + l31) * 16);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[b], bf, acc, 0, 0, 0);
+                    const f16x8 bf = *(const f16x8*)(lds + (((c0 + b) * 2 + kh) * 32 + l31) * 16);
+#pragma unroll
+                    for (int t = 0; t < TZ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][b], bf, acc[t], 0, 0, 0);
                 }
             }
         }
-        // + bias, fp16, transpose through the slab, 16-byte stores of whole 64-byte channel groups
+        // + bias, fp16, into the slab: lane (voxel l31, kh) holds couts 8 gq + 4 kh + e -> plane gq / 2, offset 8 (gq % 2) + 4 kh
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const float4 bq = *(const float4*)(p.bias + co * 32 + 8 * gq + 4 * kh);
-            union {
-                uint2 u;
-                __half h[4];
-            } pk;
-            pk.h[0] = __float2half_rn(acc[gq * 4 + 0] + bq.x);
-            pk.h[1] = __float2half_rn(acc[gq * 4 + 1] + bq.y);
-            pk.h[2] = __float2half_rn(acc[gq * 4 + 2] + bq.z);
-            pk.h[3] = __float2half_rn(acc[gq * 4 + 3] + bq.w);
-            *(uint2*)(slab + l31 * 80 + (8 * gq + 4 * kh) * 2) = pk.u;
+#pragma unroll
+            for (int t = 0; t < TZ; ++t) {
+                union {
+                    uint2 u;
+                    __half h[4];
+                } pk;
+                pk.h[0] = __float2half_rn(acc[t][gq * 4 + 0] + bq.x);
+                pk.h[1] = __float2half_rn(acc[t][gq * 4 + 1] + bq.y);
+                pk.h[2] = __float2half_rn(acc[t][gq * 4 + 2] + bq.z);
+                pk.h[3] = __float2half_rn(acc[t][gq * 4 + 3] + bq.w);
+                *(uint2*)(slab + ((gq >> 1) * 32 * TZ + l31 * TZ + t) * 32 + (8 * (gq & 1) + 4 * kh) * 2) = pk.u;
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        const size_t toff = ((size_t)tx * Ho + ty) * Wo + tz;
+        const size_t toff = ((size_t)tx * Ho + ty) * Wo;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const uint4 d = *(const uint4*)(slab + (sv + 16 * half) * 80 + sq * 16);
-            // couts co * 32 + 8 sq .. + 8 -> plane co * 2 + sq / 2, offset 8 (sq % 2)
-            if (ovalid[half])
-                *(uint4*)(p.out + ((onn[half] * (p.Cout / 16) + co * 2 + (sq >> 1)) * ((size_t)Do * Ho * Wo) + obase[half] + toff) * 16 + 8 * (sq & 1)) = d;
-        }
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int k = 0; k < TZ; ++k) {
+                const int piece = lane + 64 * k;
+                const uint4 d = *(const uint4*)(slab + pl * 32 * TZ * 32 + piece * 16);
+                if (ovalid[k])
+                    *(uint4*)(p.out + ((onn[k] * (p.Cout / 16) + co * 2 + pl) * ovox + ospat[k] + toff) * 16 + 8 * (piece & 1)) = d;
+            }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1073,15 +1094,20 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
     int gx = (int)((total + 127) / 128);
     // split the (tap, cout-chunk) pairs over gridDim.y only as far as needed to fill the chip: every y-slice
     // re-stages the block's input voxels
-    const int npairs = s[0] * s[1] * s[2] * (Cout / 32);
+    BOA_REQUIRE(s[2] == 1 || s[2] == 2, "convT: stride %d along the contiguous axis is not instantiated (1 or 2)", s[2]);
+    const int npairs = s[0] * s[1] * (Cout / 32);   // (tx, ty, cout chunk); a pair covers the s2 z taps
     int gy = std::min(npairs, std::max(1, ceil_div(2 * ctx->cu_count, gx)));
-    size_t lds = (size_t)4 * ((src.C / 16) * 1024 + 32 * 80);
+    size_t lds = (size_t)4 * ((src.C / 16) * 1024 + 2 * 32 * s[2] * 32);
     BOA_REQUIRE(lds <= 160 * 1024, "convT: Cin=%d needs %zu bytes of LDS", src.C, lds);
-    static bool once = (hipFuncSetAttribute((const void*)k_convt_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    static bool once = (hipFuncSetAttribute((const void*)k_convt_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                        hipFuncSetAttribute((const void*)k_convt_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
     const double taps = (double)s[0] * s[1] * s[2];
     KernelTimer tm(ctx, BOA_K_CONVT, 2.0 * total * taps * src.C * Cout, 2.0 * total * (src.C + taps * Cout));
-    hipLaunchKernelGGL(k_convt_mfma, dim3(gx, gy), dim3(256), lds, ctx->stream, a);
+    if (s[2] == 2)
+        hipLaunchKernelGGL(k_convt_mfma<2>, dim3(gx, gy), dim3(256), lds, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_convt_mfma<1>, dim3(gx, gy), dim3(256), lds, ctx->stream, a);
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
