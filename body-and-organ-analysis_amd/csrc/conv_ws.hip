@@ -18,8 +18,9 @@
 // Same arithmetic as k_conv_mfma (conv.hip).  Statistics: partials[n][cout][2][nslots], one slot per (workgroup,
 // consumer wave), written once per (sample, cout chunk) a wave works on; the table is zero elsewhere (zeroed at
 // allocation, re-zeroed by k_norm_finalize).
-// Debug: `dbg` bits (BOA_WS_DBG) skip stages for ablation -- 1 MFMA loop, 2 producers, 4 output stores, 8 epilogue,
-// 16 weight staging, 32 halo commit, 64 transform, 256/512 producer priority; results are then wrong by design.
+// Debug: `dbg` bits (BOA_WS_DBG) skip stages for ablation -- 2 producers, 4 output stores, 8 epilogue,
+// 16 weight staging, 32 halo commit, 64 transform, 128 halo loads, 256 / 1024 default wave priorities off; results are then
+// wrong by design (except 256 / 1024).
 // BOA_WS_TRACE=1 records s_memtime stamps of block 0 (consumer wave 0: 4 chunk start, 5 MFMA loop done, 6 epilogue done;
 // producer wave 4: 1 barrier passed, 7 loads landed, 2 committed, 8 tile set up, 3 next loads issued).
 #include <stdlib.h>
@@ -587,8 +588,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         // ---- producer waves: chunk g + 1 is committed to LDS while the consumers work on chunk g; its global loads
         // were issued one barrier earlier (prod_issue), those of chunk g + 2 are issued right after the commit.
         const int q = tid - 256;
-        if (dbg & 256) __builtin_amdgcn_s_setprio(1);
-        if (dbg & 512) __builtin_amdgcn_s_setprio(3);
+        // R = 1 kernels (stride-2 and thin deep layers) are producer-bound: the producers win issue arbitration there
+        // (measured +8 % on the 32 -> 64 stride-2 layer); the stride-1 kernels give the consumers the higher priority
+        if (R == 1 && !(dbg & 256)) __builtin_amdgcn_s_setprio(3);
         const ProdConst pc = prod_const(p, q, HV);
         TileSeq pseq;
         pseq.n = pseq.left = pseq.j = 0;
@@ -654,6 +656,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     }
 
     // ---- consumer waves --------------------------------------------------------------------------------
+    if (R > 1 && !(dbg & 1024)) __builtin_amdgcn_s_setprio(3);  // MFMA / fragment-read issue before the SIMD's producer wave (+1-6 %)
     // per-lane constants (tile independent)
     const int cw = wave & 3;
     int hoff[R];
