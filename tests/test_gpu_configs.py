@@ -56,6 +56,14 @@ def test_config0_total_fast_128_dropin_vs_oracle(tmp_path, monkeypatch):
     agree = float((got == want).mean())
     print("configs[0] total_fast 128^3 label agreement with the oracle pipeline", agree, "labels", len(np.unique(got)))
     assert agree >= 0.99            # 118 classes of a random-weight fp16 net; every other step is exact
+    # the same call in exact mode ($BOA_NET_PRECISION=fp32: the reference's CPU arithmetic): identical label file
+    monkeypatch.setenv("BOA_NET_PRECISION", "fp32")
+    out32 = tmp_path / "seg32"
+    compute_all_models(ct_path, out32, "total", params)
+    got32, _, _ = nifti.load(out32 / "total.nii.gz")
+    flips = int((got32 != want).sum())
+    print("configs[0] exact mode: label flips", flips, "of", want.size)
+    assert flips <= max(1, 1e-5 * want.size)
 
 
 def _bca_models(folds):
