@@ -44,6 +44,7 @@ _PROTOS = {
     "boa_device_info": (i32, [vp, C.c_char_p, i32, ip, C.POINTER(u64), C.POINTER(u64)]),
     "boa_malloc": (i32, [vp, u64, C.POINTER(vp)]),
     "boa_free": (i32, [vp, vp]),
+    "boa_trim": (i32, [vp]),
     "boa_memset": (i32, [vp, vp, i32, u64]),
     "boa_h2d": (i32, [vp, vp, vp, u64]),
     "boa_d2h": (i32, [vp, vp, vp, u64]),

@@ -176,16 +176,16 @@ def _slicewise(counts_a: np.ndarray, ml_per_voxel: float):
 _STAT_ROWS = ["Mean", "StdDev", "Minimum", "25%", "Median", "75%", "Maximum", "Total", "MeanHU"]
 
 
-def _descriptive(df, counts_a, sums_a, lo, hi):
-    """_descriptive_statistics_from_measurements (builder.py:263-307) for slices [lo, hi): pandas `describe()` of the
-    slice-wise volumes (mean, std with ddof 1, min, linear-interpolated quartiles, max) + Total + MeanHU.  Evaluated with the
-    numpy operations pandas itself dispatches to (sum / count, sqrt(sum((x - mean)^2) / (n - 1)), numpy's linear percentile):
-    the same numbers as `DataFrame.describe()` without its ~6 ms of frame bookkeeping per group (0.43 s per volume)."""
-    import pandas as pd
-    cols = [c for c in df.columns if c != "slice_idx"]
-    sel = (df["slice_idx"].to_numpy() >= lo) & (df["slice_idx"].to_numpy() < hi)
+def _descriptive(x_all: np.ndarray, cols, counts_a, sums_a, lo, hi) -> dict:
+    """_descriptive_statistics_from_measurements (builder.py:263-307) for slices [lo, hi), returned the way run_pipeline
+    stores it (`m.rename(...).to_dict()`: {column: {statistic: float | None}}): pandas `describe()` of the slice-wise
+    volumes (mean, std with ddof 1, min, linear-interpolated quartiles, max) + Total + MeanHU.  Evaluated with the numpy
+    operations pandas itself dispatches to (sum / count, sqrt(sum((x - mean)^2) / (n - 1)), numpy's linear percentile) and
+    written into plain dicts: the same numbers as `DataFrame.describe()` + `.loc[]` + `.where()` + `.to_dict()` without
+    their frame bookkeeping (~8 ms per group and variant, 0.4 s per volume, with the GPU idle behind it).
+    `x_all` [slices, len(cols)] float64 = the slice-wise table without its index column."""
     # one contiguous row per tissue: numpy then reduces each row with the pairwise summation pandas gets on a column
-    x = np.ascontiguousarray(df[cols].to_numpy(dtype=np.float64)[sel].T)      # [tissues, slices]
+    x = np.ascontiguousarray(x_all[max(lo, 0):max(hi, 0)].T)      # [tissues, slices]; rows with lo <= slice_idx < hi
     n = x.shape[1]
     out = np.full((len(_STAT_ROWS), len(cols)), np.nan)
     if n:
@@ -198,15 +198,20 @@ def _descriptive(df, counts_a, sums_a, lo, hi):
         out[3:6] = np.percentile(x, [25, 50, 75], axis=1)
         out[6] = x.max(axis=1)
     out[7] = x.sum(axis=1)
-    m = pd.DataFrame(out, index=_STAT_ROWS, columns=cols).astype(object)
     c = counts_a[lo:hi].astype(np.int64).sum(axis=0)
     s = sums_a[lo:hi].sum(axis=0)
-    for nme, v in TISSUES:
-        m.loc["MeanHU", _tname(nme)] = (float(s[v]) / float(c[v])) if c[v] else None
+    mean_hu = {_tname(nme): ((float(s[v]) / float(c[v])) if c[v] else None) for nme, v in TISSUES}
     adip = [5, 3, 4, 6, 7]
     ca, sa = int(c[adip].sum()), int(s[adip].sum())
-    m.loc["MeanHU", "TAT"] = (float(sa) / float(ca)) if ca else None
-    return m.where(m.notna(), None)
+    mean_hu["TAT"] = (float(sa) / float(ca)) if ca else None
+    keys = [_ROW[r] for r in _STAT_ROWS[:-1]]
+    res = {}
+    for ci, col in enumerate(cols):
+        vals = out[:len(keys), ci].tolist()
+        m = {k: (None if v != v else v) for k, v in zip(keys, vals)}
+        m[_ROW["MeanHU"]] = mean_hu[col]
+        res[col.lower()] = m
+    return res
 
 
 def bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebrae=None, body_parts_override=None) -> dict:
@@ -218,14 +223,14 @@ def bca_measurements_from_tables(counts, hu_sums, present, spacing_xyz, vertebra
     parts = dict(body_parts_override) if body_parts_override is not None else examined_body_part(present, spacing_xyz)
     groups = aggregation_groups(present, depth, parts, vertebrae)
     agg = {}
+    x1 = df[COLS].to_numpy(dtype=np.float64)          # (slice_idx is 0 .. depth-1: rows [lo, hi) are the group's slices)
+    x2 = d2[COLS].to_numpy(dtype=np.float64)
     for name, lo, hi in groups:
-        m = _descriptive(df, counts[:, 0], hu_sums[:, 0], lo, hi)
-        m2 = _descriptive(d2, counts[:, 1], hu_sums[:, 1], lo, hi)
         key = name.lower().replace(" ", "_").replace("-", "_")
         agg[key] = {
             "num_slices": int(hi - lo), "min_slice_idx": int(lo), "max_slice_idx": int(hi),
-            "measurements": m.rename(index=_ROW, columns={c: c.lower() for c in m.columns}).to_dict(),
-            "measurements_no_extremities": m2.rename(index=_ROW, columns={c: c.lower() for c in m2.columns}).to_dict(),
+            "measurements": _descriptive(x1, COLS, counts[:, 0], hu_sums[:, 0], lo, hi),
+            "measurements_no_extremities": _descriptive(x2, COLS, counts[:, 1], hu_sums[:, 1], lo, hi),
         }
 
     def recs(d):

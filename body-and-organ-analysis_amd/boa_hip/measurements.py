@@ -42,6 +42,18 @@ def _lerp(a: float, b: float, t: float) -> float:
     return r
 
 
+def occupied_window(hist: np.ndarray):
+    """[b0, b1): the bin range outside which every row of `hist` [rows, nbins] is empty (one OR-reduction over the rows
+    instead of a 65 536-bin scan per label: CT values occupy a few thousand of the int16 bins)."""
+    h = np.ascontiguousarray(hist)
+    cols = np.bitwise_or.reduce(h.view(np.uint64) if (h.dtype.itemsize == 4 and h.shape[1] % 2 == 0) else h, axis=0)
+    nz = np.flatnonzero(cols)
+    if nz.size == 0:
+        return 0, 0
+    k = 2 if cols.shape[0] != h.shape[1] else 1
+    return int(nz[0]) * k, (int(nz[-1]) + 1) * k
+
+
 def stats_from_hist(h: np.ndarray, hu_min: int = HU_MIN) -> Optional[Dict[str, float]]:
     """h: uint32/int64 [nbins] counts of value hu_min + bin.  Returns None for an empty region."""
     nz = np.nonzero(h)[0]
@@ -137,9 +149,15 @@ def erode_region(ctx: Context, mask: np.ndarray, kernel_value: int = 6) -> np.nd
 
 
 def _masked_stats_local(ctx, d_ct, d_mask, n):
-    """stats of ct[mask != 0]: histogram with the mask itself as the (0/1) label volume."""
-    h = _label_hu_histogram_local(ctx, d_ct, d_mask, n)
-    return stats_from_hist(h[1])
+    """stats of ct[mask != 0]: histogram with the mask itself as the (0/1) label volume; only row 1 comes back."""
+    from .device import BufferView
+    d_hist = ctx.alloc(256 * NBINS * 4)
+    try:
+        check(ctx.lib.boa_label_hu_histogram(ctx.h, d_ct.vp, d_mask.vp, None, n, HU_MIN, NBINS, d_hist.vp), "boa_label_hu_histogram")
+        row = BufferView(d_hist, NBINS * 4, NBINS * 4).download((NBINS,), np.uint32)
+    finally:
+        d_hist.free()
+    return stats_from_hist(row)
 
 
 _masked_stats = _masked_stats_local
@@ -162,11 +180,13 @@ def metrics_for_each_region(ctx: Context, ct: np.ndarray, region_data: np.ndarra
 def _metrics_from_hist(hist, label_map, am, asd, spacing):
     ml = np.prod(spacing) / 1000.0
     res = {}
+    b0, b1 = occupied_window(hist)
+    hw, hu0 = hist[:, b0:b1], HU_MIN + b0          # same statistics: bin b of the window is HU hu0 + b
     for region, label in label_map.items():
-        res[region] = _metrics(stats_from_hist(hist[label]) if 0 < label < 256 else None, ml, am, asd)
+        res[region] = _metrics(stats_from_hist(hw[label], hu0) if 0 < label < 256 else None, ml, am, asd)
     if "autochthon_left" in label_map and "autochthon_right" in label_map:
-        h = hist[label_map["autochthon_left"]].astype(np.int64) + hist[label_map["autochthon_right"]]
-        res["autochthon"] = _metrics(stats_from_hist(h), ml, am, asd)
+        h = hw[label_map["autochthon_left"]].astype(np.int64) + hw[label_map["autochthon_right"]]
+        res["autochthon"] = _metrics(stats_from_hist(h, hu0), ml, am, asd)
     return res
 
 
@@ -251,10 +271,10 @@ def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Option
         lo, hi = ADIPOSE_TISSUE[0] - HU_MIN, ADIPOSE_TISSUE[1] - HU_MIN
 
         def fat_metrics(names):
-            h = np.zeros(NBINS, dtype=np.int64)
+            h = np.zeros(hi + 1 - lo, dtype=np.int64)
             for nm in names:
-                h[lo:hi + 1] += hist[label_map[nm]][lo:hi + 1]
-            return _metrics(stats_from_hist(h), ml, am, asd)
+                h += hist[label_map[nm]][lo:hi + 1]
+            return _metrics(stats_from_hist(h, ADIPOSE_TISSUE[0]), ml, am, asd)
 
         pf = {}
         for nm in LUNG_MASKS:

@@ -186,6 +186,11 @@ class BcaPipelineHip:
         affine = np.asarray(affine, dtype=np.float64)
         live = []
         keep = []
+        # both nets see the same CT at the same (sx, sy, 5 mm) grid: the cubic resampling runs once (unless the second net
+        # works on a body crop)
+        rs_cache: dict = {}
+        for t in self.tasks.values():
+            t.resample_cache = rs_cache
         try:
             d_parts = self._inference_device("body_parts", d_ct, affine, force_split, None, raw_parts, done_parts)
             keep.append(d_parts)
@@ -233,6 +238,10 @@ class BcaPipelineHip:
             keep = []
             return out
         finally:
+            for t in self.tasks.values():
+                t.resample_cache = None
+            for b in rs_cache.values():
+                b.free()
             seen = set()
             for a in live + keep:
                 if id(a.buf) not in seen:

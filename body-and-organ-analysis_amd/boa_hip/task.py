@@ -79,6 +79,9 @@ class SegmentationTask:
         self.task_name = task_name
         self.resample = None if resample is None else float(resample)
         self.resample_only_thickness = bool(resample_only_thickness)
+        # {key: DeviceBuffer} shared between tasks that resample the SAME resident volume to the same grid (the two BCA
+        # nets both take the CT to (sx, sy, 5 mm)): the owner of the dict frees the buffers.  None = resample every time.
+        self.resample_cache: Optional[dict] = None
         self.multimodel = (len(models) > 1) if multimodel is None else bool(multimodel)
         # TS/nnunet.py:507-514
         self.step_size = 0.8 if (task_name == "total" and self.resample is not None and self.resample < 3.0) else 0.5
@@ -279,14 +282,24 @@ class SegmentationTask:
                 if np.array_equal(zooms, new_spacing):
                     zoom = None
             if zoom is not None:
-                src = view.contiguous(cast)
-                if src.buf is not view.buf:
-                    own(src)
-                if src.dtype == np.uint8:
-                    src = own(src.contiguous(np.int16, force_copy=True))
                 out_shape = rs.zoomed_shape(in_shape, zoom)
-                buf = rs.resample_cubic_device(ctx, src.buf, src.dtype, src.shape, out_shape, np.int32)
-                img_rsp = own(DevArray(ctx, buf, out_shape, np.int32))
+                key = None
+                if self.resample_cache is not None and resident:
+                    key = (data.buf.ptr, view.offset, view.shape, view.strides, str(view.dtype), str(cast), tuple(out_shape))
+                if key is not None and key in self.resample_cache:
+                    img_rsp = DevArray(ctx, self.resample_cache[key], out_shape, np.int32)      # (not owned: the cache's)
+                else:
+                    src = view.contiguous(cast)
+                    if src.buf is not view.buf:
+                        own(src)
+                    if src.dtype == np.uint8:
+                        src = own(src.contiguous(np.int16, force_copy=True))
+                    buf = rs.resample_cubic_device(ctx, src.buf, src.dtype, src.shape, out_shape, np.int32)
+                    img_rsp = DevArray(ctx, buf, out_shape, np.int32)
+                    if key is not None:
+                        self.resample_cache[key] = buf
+                    else:
+                        own(img_rsp)
                 sp_rsp = np.array(resample, dtype=np.float64)
             else:
                 img_rsp = view if cast is None else own(view.contiguous(cast))

@@ -833,18 +833,20 @@ extern "C" int boa_scatter_u32(boa_ctx* c, uint32_t* dev_dst, const int32_t* hos
     int rc = boa_malloc(c, (size_t)m * 4, (void**)&d_v);
     if (!rc) {
         c->prof_break = true;
-        hipError_t e = hipMemcpy(d_i, host_idx, (size_t)m * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_v, host_val, (size_t)m * 4, hipMemcpyHostToDevice);
+        // (stream-ordered copies: d_i / d_v may be recycled blocks whose previous user still has work queued on the stream)
+        hipError_t e = hipMemcpyAsync(d_i, host_idx, (size_t)m * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_v, host_val, (size_t)m * 4, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_scatter_u32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d_i, d_v, m, dev_dst);
             e = hipGetLastError();
         }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // the host arrays are borrowed for the duration of the call
         if (e != hipSuccess) {
             boa_set_error("boa_scatter_u32: %s", hipGetErrorString(e));
             rc = BOA_EHIP;
         }
     }
-    boa_free(c, d_i);  // synchronises the stream
+    boa_free(c, d_i);
     if (d_v) boa_free(c, d_v);
     return rc;
 }

@@ -1,5 +1,8 @@
 // Context, memory, timing and error plumbing of libboa_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <iterator>
 #include <string.h>
 
 #include "common.h"
@@ -52,6 +55,8 @@ extern "C" void boa_destroy(boa_ctx* c) {
     for (auto& r : c->prof_pending) hipEventDestroy(r.ev);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto& r : c->ws_runs) hipFree(r.second);
+    for (auto& b : c->pool_free) hipFree(b.second);
+    for (auto& b : c->pool_live) hipFree(b.first);  // buffers the caller never freed
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -72,11 +77,16 @@ extern "C" int boa_device_info(boa_ctx* c, char* name, int name_len, int* cu_cou
     return BOA_OK;
 }
 
-extern "C" int boa_malloc(boa_ctx* c, size_t bytes, void** dev_out) {
+int boa_malloc_raw(boa_ctx* c, size_t bytes, void** dev_out) {
     BOA_REQUIRE(c && dev_out, "boa_malloc: NULL argument");
     BOA_HIP_TRY(hipSetDevice(c->device));
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess && c->pool_bytes) {  // give the parked blocks back and try once more
+        (void)hipGetLastError();
+        boa_trim(c);
+        e = hipMalloc(&p, bytes ? bytes : 1);
+    }
     if (e != hipSuccess) {
         boa_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         (void)hipGetLastError();
@@ -86,12 +96,64 @@ extern "C" int boa_malloc(boa_ctx* c, size_t bytes, void** dev_out) {
     return BOA_OK;
 }
 
+static size_t pool_round(size_t bytes) {
+    if (bytes <= (1u << 20)) return (std::max<size_t>(bytes, 1) + 4095) & ~(size_t)4095;
+    return (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+}
+
+extern "C" int boa_malloc(boa_ctx* c, size_t bytes, void** dev_out) {
+    BOA_REQUIRE(c && dev_out, "boa_malloc: NULL argument");
+    if (c->pool_cap == 0) {
+        const char* e = getenv("BOA_POOL_GB");
+        const double gb = e ? atof(e) : 48.0;
+        c->pool_cap = gb > 0 ? (size_t)(gb * (double)(1ull << 30)) : 1;  // 1 byte: nothing is ever parked
+    }
+    const size_t sz = pool_round(bytes);
+    auto it = c->pool_free.lower_bound(sz);
+    if (it != c->pool_free.end() && it->first - sz <= std::max<size_t>(sz / 4, 2u << 20)) {
+        *dev_out = it->second;
+        c->pool_bytes -= it->first;
+        c->pool_live[it->second] = it->first;
+        c->pool_free.erase(it);
+        return BOA_OK;
+    }
+    BOA_TRY(boa_malloc_raw(c, sz, dev_out));
+    c->pool_live[*dev_out] = sz;
+    return BOA_OK;
+}
+
 extern "C" int boa_free(boa_ctx* c, void* dev) {
     BOA_REQUIRE(c, "ctx is NULL");
-    if (dev) {
+    if (!dev) return BOA_OK;
+    auto it = c->pool_live.find(dev);
+    if (it == c->pool_live.end()) {  // not one of ours (or allocated raw): synchronise, then release
         BOA_HIP_TRY(hipStreamSynchronize(c->stream));
         BOA_HIP_TRY(hipFree(dev));
+        return BOA_OK;
     }
+    const size_t sz = it->second;
+    c->pool_live.erase(it);
+    c->pool_free.emplace(sz, dev);
+    c->pool_bytes += sz;
+    if (c->pool_bytes > c->pool_cap) {  // over the cap: release the largest parked blocks
+        BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+        while (c->pool_bytes > c->pool_cap && !c->pool_free.empty()) {
+            auto last = std::prev(c->pool_free.end());
+            BOA_HIP_TRY(hipFree(last->second));
+            c->pool_bytes -= last->first;
+            c->pool_free.erase(last);
+        }
+    }
+    return BOA_OK;
+}
+
+extern "C" int boa_trim(boa_ctx* c) {
+    BOA_REQUIRE(c, "ctx is NULL");
+    if (c->pool_free.empty()) return BOA_OK;
+    BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& b : c->pool_free) hipFree(b.second);
+    c->pool_free.clear();
+    c->pool_bytes = 0;
     return BOA_OK;
 }
 

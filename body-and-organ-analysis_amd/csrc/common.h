@@ -4,6 +4,8 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "boa_hip.h"
@@ -61,7 +63,16 @@ struct boa_ctx {
     // k_conv_ws run tables (first tile + length of every virtual workgroup's run), one per distinct layer geometry,
     // built on first use and kept for the life of the context: (key, device pointer)
     std::vector<std::pair<std::vector<int>, void*>> ws_runs;
+    // boa_malloc / boa_free: stream-ordered caching allocator for the transient volume-sized buffers of the host code
+    // (a freed block goes back to `pool_free` without a device synchronisation and is handed out again for a request of
+    // about its size; every use of a block is enqueued on `stream`, so reuse is ordered).  Network activations and weight
+    // arenas use boa_malloc_raw / hipFree and never enter the pool.
+    std::multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_live;
+    size_t pool_bytes = 0;          // bytes parked in pool_free
+    size_t pool_cap = 0;            // 0 = not initialised (BOA_POOL_GB, default 48; 0 disables pooling)
 };
+int boa_malloc_raw(boa_ctx* c, size_t bytes, void** dev_out);
 
 // RAII-less explicit bracket: KernelTimer t(ctx, klass, flops, bytes); <launch>; t.stop();
 struct KernelTimer {

@@ -45,8 +45,8 @@ void pack_convt_weights(const float* w /*[Cin][Cout][s0][s1][s2]*/, int Cin, int
 // sums of (x, x^2) per (n, cout) into partials[N][Cout][2][nblk]; returns nblk through *nblk_out.
 int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const ConvGeom& g, const ConvTile& t,
                      const __half* wpk, const float* bias, float slope, __half* out, float* partials);
-int conv_nblk(const ConvTile& t, int cu_count);
-int conv_ws_nslots(int cu_count);
+int conv_nblk(const ConvTile& t, int cu_count, int Cout);
+int conv_ws_nslots(int tiles_per_sample, int cu_count);
 
 // First conv: reads tiles straight out of the resident fp32 volume [Cin][V0][V1][V2] (zero outside the volume
 // and outside the tile), fp32 VALU, stride 1.  w: dev fp32 [Cin][taps][Cout].

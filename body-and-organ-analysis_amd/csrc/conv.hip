@@ -171,8 +171,9 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
 }
 
 // number of per-(n, cout) partial-statistics entries the conv kernel writes
-int conv_nblk(const ConvTile& t, int cu_count) {
-    return t.variant == 1 ? conv_ws_nslots(cu_count) : t.tiles[0] * t.tiles[1] * t.tiles[2];
+int conv_nblk(const ConvTile& t, int cu_count, int Cout) {
+    const int spatial = t.tiles[0] * t.tiles[1] * t.tiles[2];
+    return t.variant == 1 ? conv_ws_nslots(spatial * (Cout / 32), cu_count) : spatial;
 }
 
 // ======================================================================================================

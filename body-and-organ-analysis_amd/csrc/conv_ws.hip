@@ -625,6 +625,18 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             if (live && g + 1 < my_chunks) {
                 unsigned char* nxt = bufs + ((g + 1) & 1) * buf_bytes;
                 WS_STAMP(1);
+                // The next tile's address setup runs BEFORE the commit, while the loads of the chunk to commit are still in
+                // flight: its scalar loads (run table, kernel arguments) wait on lgkmcnt, the counter the commit's ds_writes
+                // share -- placed after the commit the setup waited for all of them to drain (~1 500 cycles per tile on the
+                // producers' critical path, s_memtime trace) before the next loads could be issued.  (The commit only
+                // reads `rg`, the DMA the (chunk, cout chunk) saved at issue time.)
+                const bool do_issue = g + 2 < my_chunks;
+                if (do_issue && pcc == 0) {
+                    const bool new_run = seq_next(p, pseq);
+                    reuse = p.cy_fast && ptc.cy != 0 && !new_run;  // same spatial tile as the previous tile of this run
+                    if (!reuse) prod_setup(p, ptc, pc, items);
+                    WS_STAMP(8);
+                }
                 if (p.trace) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     WS_STAMP(7);
@@ -636,13 +648,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 // slower.)
                 if (want_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 WS_STAMP(2);
-                if (g + 2 < my_chunks) {
-                    if (pcc == 0) {
-                        const bool new_run = seq_next(p, pseq);
-                        reuse = p.cy_fast && ptc.cy != 0 && !new_run;  // same spatial tile as the previous tile of this run
-                        if (!reuse) prod_setup(p, ptc, pc, items);
-                        WS_STAMP(8);
-                    }
+                if (do_issue) {
                     prod_issue(p, ptc, items, pc.in_halo, pcc, reuse, q, dbg, rg);
                     w_cc = pcc;
                     w_cy = ptc.cy;
@@ -929,7 +935,14 @@ size_t conv_ws_lds_bytes(int HV, int taps, int ncc, int Cout) {
     return 2 * (2 * ws_plane_host(HV) + (size_t)taps * 1024);
 }
 
-int conv_ws_nslots(int cu_count) { return cu_count * 4; }
+// virtual workgroups per sample (a function of the layer geometry only; BOA_WS_VW: experiment hook, changes the statistics
+// grouping) and the statistics slots of a layer: one per (virtual workgroup, consumer wave) -- sized per layer, so that
+// k_norm_finalize reads and re-zeroes 4 vw entries per (n, cout), not 4 x CUs (the deep layers have 10-64 tiles per sample)
+int conv_ws_vw(int tiles_per_sample, int cu_count) {
+    static const int vw_cap = getenv("BOA_WS_VW") ? atoi(getenv("BOA_WS_VW")) : 0;
+    return std::min(tiles_per_sample, vw_cap > 0 ? std::min(vw_cap, cu_count) : cu_count);
+}
+int conv_ws_nslots(int tiles_per_sample, int cu_count) { return conv_ws_vw(tiles_per_sample, cu_count) * 4; }
 
 bool conv_ws_supported(const int k[3], int HV) {
     const bool k333 = k[0] == 3 && k[1] == 3 && k[2] == 3;
@@ -1022,8 +1035,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     const ConvArgs& a0 = a_in;
     // tiles of one sample; its virtual workgroups (batch-invariant statistics, see tile_walk); physical grid
     const int total = t.tiles[0] * t.tiles[1] * t.tiles[2] * (a0.Cout / 32);
-    static const int vw_cap = getenv("BOA_WS_VW") ? atoi(getenv("BOA_WS_VW")) : 0;  // experiment hook (changes the statistics grouping)
-    const int vw = std::min(total, vw_cap > 0 ? std::min(vw_cap, ctx->cu_count) : ctx->cu_count);
+    const int vw = conv_ws_vw(total, ctx->cu_count);
     const int grid = (int)std::min<long long>((long long)vw * a0.N, ctx->cu_count);
     const int taps = a0.k0 * a0.k1 * a0.k2;
     const int HV = t.h[0] * t.h[1] * t.h[2];
@@ -1036,7 +1048,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     ConvArgs a = a_in;
     a.trace = nullptr;
     // statistics slots: one per (workgroup, consumer wave); waves that never touch an (n, cout chunk) leave zeros
-    a.nslots = conv_ws_nslots(ctx->cu_count);
+    a.nslots = 4 * vw;  // = conv_nblk(t, cu_count, Cout): the stride the caller allocated and k_norm_finalize reads
     a.vw = vw;
     a.vstep_n = grid / vw;
     a.vstep_j = grid % vw;

@@ -73,7 +73,7 @@ struct boa_net {
 };
 
 static int net_alloc(boa_net* net, size_t bytes, void** out) {
-    BOA_TRY(boa_malloc(net->ctx, bytes, out));
+    BOA_TRY(boa_malloc_raw(net->ctx, bytes, out));   // (long-lived: not through the caching allocator; freed with hipFree)
     net->allocs.push_back(*out);
     return BOA_OK;
 }
@@ -156,7 +156,7 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
         gref.N = 8;
         BOA_REQUIRE(choose_conv_tile(gref, net->ctx->cu_count, &L.t), "no tile configuration fits conv %dx%dx%d", din[0],
                     din[1], din[2]);
-        L.nblk = conv_nblk(L.t, net->ctx->cu_count);
+        L.nblk = conv_nblk(L.t, net->ctx->cu_count, cout);
     }
     size_t vox = (size_t)dout[0] * dout[1] * dout[2];
     BOA_TRY(net_alloc(net, (size_t)N * vox * cout * sizeof(__half), (void**)&L.out));
@@ -225,7 +225,6 @@ extern "C" int boa_net_load_weights(boa_net* net, const float* w, size_t n_float
     size_t expect = boa_net_weight_count(&net->d);
     BOA_REQUIRE(n_floats == expect, "weight blob has %zu floats, geometry needs %zu", n_floats, expect);
     boa_ctx* c = net->ctx;
-    BOA_HIP_TRY(hipStreamSynchronize(c->stream));
     // cached set of the same host blob (fold switching in predict_logits_from_preprocessed_data, :483-489)?
     unsigned long long hsh = 1469598103934665603ull;
     {
@@ -238,9 +237,10 @@ extern "C" int boa_net_load_weights(boa_net* net, const float* w, size_t n_float
     }
     for (auto& ws : net->wsets)
         if (ws.key == w && ws.n == n_floats && ws.sample_hash == hsh) {
-            point_layers_at(net, ws.arena);
+            point_layers_at(net, ws.arena);  // (host-side pointers of later launches only: queued work keeps its own)
             return BOA_OK;
         }
+    BOA_HIP_TRY(hipStreamSynchronize(c->stream));
     size_t total = 0;
     for_each_weight_piece(net, [&](int, ConvLayer*, UpLayer*, size_t bytes) { total += align256(bytes); });
     std::vector<unsigned char> stage(total, 0);
@@ -297,7 +297,7 @@ extern "C" int boa_net_load_weights(boa_net* net, const float* w, size_t n_float
         net->wsets.erase(net->wsets.begin());
     }
     unsigned char* arena = nullptr;
-    BOA_TRY(boa_malloc(c, total, (void**)&arena));
+    BOA_TRY(boa_malloc_raw(c, total, (void**)&arena));
     hipError_t e = hipMemcpy(arena, stage.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         hipFree(arena);
@@ -803,7 +803,7 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     size_t vin = (size_t)dims[0] * dims[1] * dims[2], vout = (size_t)dout[0] * dout[1] * dout[2];
     __half *in16 = nullptr, *out16 = nullptr, *wpk = nullptr;
     float *bias = nullptr, *gamma = nullptr, *beta = nullptr, *partials = nullptr, *ss = nullptr;
-    int nblk = conv_nblk(t, ctx->cu_count);
+    int nblk = conv_nblk(t, ctx->cu_count, Cout);
     std::vector<__half> tmp(conv_wpk_halves(Cin, Cout, kernel));
     pack_conv_weights(host_w, Cin, Cout, kernel, tmp.data());
     std::vector<float> ones(Cout, 1.f), zeros(Cout, 0.f);

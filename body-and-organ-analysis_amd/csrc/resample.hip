@@ -427,7 +427,7 @@ extern "C" int boa_resize_skimage_f32(boa_ctx* c, const float* dev_in, const int
     hipLaunchKernelGGL(k_resize_cubic_f32, dim3((unsigned)((on + 255) / 256)), dim3(256), 0, c->stream, coef, ra, mm, dev_out);
     t.stop();
     hipError_t e = hipGetLastError();
-    rc = boa_free(c, coef);  // synchronises the stream
+    rc = boa_free(c, coef);
     boa_free(c, mm);
     BOA_HIP_TRY(e);
     return rc;

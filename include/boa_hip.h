@@ -47,8 +47,14 @@ int boa_version(void);
 int boa_init(int device, void* stream, boa_ctx** out);
 void boa_destroy(boa_ctx* ctx);
 int boa_device_info(boa_ctx* ctx, char* name, int name_len, int* cu_count, size_t* total_mem, size_t* free_mem);
+/* Device memory for the caller's buffers (what `torch.empty(..., device="cuda")` / the caching allocator behind it is to the
+ * reference).  Stream-ordered caching allocator: boa_free parks the block without synchronising the device, boa_malloc hands
+ * a parked block of about the requested size out again; every use of a block must therefore be enqueued on the context's
+ * stream (all boa_* calls are).  At most $BOA_POOL_GB (default 48; 0 = no caching) stays parked; boa_trim releases all of it.
+ * Pointers that did not come from boa_malloc may be passed to boa_free (synchronise + hipFree). */
 int boa_malloc(boa_ctx* ctx, size_t bytes, void** dev_out);
 int boa_free(boa_ctx* ctx, void* dev);
+int boa_trim(boa_ctx* ctx);
 int boa_memset(boa_ctx* ctx, void* dev, int value, size_t bytes);
 int boa_h2d(boa_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);   /* synchronous */
 int boa_d2h(boa_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);   /* synchronous */

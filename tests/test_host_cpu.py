@@ -250,13 +250,25 @@ def test_descriptive_statistics_equal_pandas_describe():
         df = bca._slicewise(counts, float(rng.uniform(0.3, 5)) ** 3 / 1000)
         lo = int(rng.integers(0, Z - 1))
         hi = int(rng.integers(lo + 1, Z + 1))
-        m = bca._descriptive(df, counts, sums, lo, hi)
+        m = bca._descriptive(df[bca.COLS].to_numpy(dtype=np.float64), bca.COLS, counts, sums, lo, hi)
         sw = df[(df.slice_idx >= lo) & (df.slice_idx < hi)].drop("slice_idx", axis=1)
         ref = sw.describe()
         ref.drop("count", inplace=True)
         ref.index = ["Mean", "StdDev", "Minimum", "25%", "Median", "75%", "Maximum"]
         ref.loc["Total"] = sw.sum()
-        a = m.loc[ref.index, ref.columns].to_numpy(dtype=object)
-        b = ref.replace({np.nan: None}).to_numpy(dtype=object)
-        for x, y in zip(a.ravel(), b.ravel()):
-            assert (x is None and y is None) or float(x) == float(y)
+        # the reference's own tail (builder.py:284-307 + run_pipeline's rename / to_dict): MeanHU row, NaN -> None, dict
+        ref = ref.astype(object)
+        c = counts[lo:hi].astype(np.int64).sum(axis=0)
+        sm = sums[lo:hi].sum(axis=0)
+        for nme, v in bca.TISSUES:
+            ref.loc["MeanHU", bca._tname(nme)] = (float(sm[v]) / float(c[v])) if c[v] else None
+        adip = [5, 3, 4, 6, 7]
+        ref.loc["MeanHU", "TAT"] = (float(sm[adip].sum()) / float(c[adip].sum())) if c[adip].sum() else None
+        ref = ref.where(ref.notna(), None)
+        want = ref.rename(index=bca._ROW, columns={k: k.lower() for k in ref.columns}).to_dict()
+        assert list(m) == list(want)
+        for col in want:
+            assert list(m[col]) == list(want[col]), (list(m[col]), list(want[col]))
+            for k, y in want[col].items():
+                x = m[col][k]
+                assert (x is None and y is None) or (type(x) is float and x == float(y)), (col, k, x, y)
