@@ -610,6 +610,208 @@ __global__ __launch_bounds__(256) void k_ccl_merge(const unsigned char* __restri
     }
 }
 
+// ---- two-level labelling: tiles of CCL_TX x CCL_TY x CCL_TZ voxels are labelled in LDS first, then only the unions that
+// cross a tile face go through global memory.  The per-voxel global version above spends its time in device-scope atomics and
+// pointer chasing through HBM (5.7 ms per 512^3 mask); inside a tile the same union-find runs on LDS words.  The result is the
+// same forest invariant (parent index <= own index, root = smallest linear index of the component), so k_ccl_compress and
+// everything downstream see identical roots and sizes.
+#define CCL_TX 32
+#define CCL_TY 16
+#define CCL_TZ 16
+#define CCL_TILE (CCL_TX * CCL_TY * CCL_TZ)
+
+__device__ __forceinline__ int lds_find(volatile int* L, int i) {
+    int p = L[i];
+    while (p != i) {
+        const int gp = L[p];
+        if (gp != p) L[i] = gp;  // path halving (a racing walker at worst takes the longer way)
+        i = p;
+        p = gp;
+    }
+    return i;
+}
+
+__device__ __forceinline__ void lds_union(int* L, int a, int b) {
+    while (true) {
+        a = lds_find(L, a);
+        b = lds_find(L, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_local(const unsigned char* __restrict__ mask, int Z, int Y, int X, int tiles_x, int tiles_y,
+                                                   int* __restrict__ L, unsigned int* __restrict__ sizes) {
+    __shared__ int lab[CCL_TILE];  // union-find parents; reused for the component sizes once every voxel knows its root
+    __shared__ unsigned int rowbits[CCL_TY * CCL_TZ];  // bit lx of word (lz, ly): voxel is foreground
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, tz = t / tiles_y;
+    const int x0 = tx * CCL_TX, y0 = ty * CCL_TY, z0 = tz * CCL_TZ;
+    // one wave-wide ballot per row pair: lane (row r of the pair, lx)
+    for (int r2 = tid >> 5; r2 < CCL_TY * CCL_TZ; r2 += 8) {
+        const int lx = tid & 31, ly = r2 % CCL_TY, lz = r2 / CCL_TY;
+        const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+        const bool fg = x < X && y < Y && z < Z && mask[((size_t)z * Y + y) * X + x] != 0;
+        const unsigned long long b = __ballot(fg);
+        if (lx == 0) rowbits[r2] = (unsigned int)(b >> (32 * ((tid >> 5) & 1)));
+        lab[r2 * CCL_TX + lx] = fg ? r2 * CCL_TX + lx : -1;
+    }
+    __syncthreads();
+    // unions inside the tile: the same reduced neighbour set as k_ccl_merge, rows as bit words
+    for (int r2 = tid >> 5; r2 < CCL_TY * CCL_TZ; r2 += 8) {
+        const int lx = tid & 31, ly = r2 % CCL_TY, lz = r2 / CCL_TY;
+        const unsigned int me = rowbits[r2];
+        if (!((me >> lx) & 1u)) continue;
+        const int i = r2 * CCL_TX + lx;
+        const bool left = lx > 0 && ((me >> (lx - 1)) & 1u);
+        if (lx + 1 < CCL_TX && ((me >> (lx + 1)) & 1u)) lds_union(lab, i, i + 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dz = r == 0 ? 0 : 1, dy = r == 0 ? 1 : r - 2;
+            const int zz = lz + dz, yy = ly + dy;
+            if (zz >= CCL_TZ || yy < 0 || yy >= CCL_TY) continue;
+            const int rr = zz * CCL_TY + yy;
+            const unsigned int w = rowbits[rr];
+            const bool m0 = lx > 0 && ((w >> (lx - 1)) & 1u), m1 = (w >> lx) & 1u, m2 = lx + 1 < CCL_TX && ((w >> (lx + 1)) & 1u);
+            const int row = rr * CCL_TX;
+            if (!left) {
+                if (m1) {
+                    lds_union(lab, i, row + lx);
+                } else {
+                    if (m0) lds_union(lab, i, row + lx - 1);
+                    if (m2) lds_union(lab, i, row + lx + 1);
+                }
+            } else if (m2 && !m1) {
+                lds_union(lab, i, row + lx + 1);
+            }
+        }
+    }
+    __syncthreads();
+    // global labels: the tile-local root's linear index in the volume; voxel counts of the local components (LDS atomics:
+    // the per-voxel global atomics of the one-level version were its second most expensive part)
+    int myroot[CCL_TILE / 256];
+#pragma unroll
+    for (int k = 0; k < CCL_TILE / 256; ++k) {
+        const int r2 = (tid >> 5) + 8 * k, lx = tid & 31;
+        myroot[k] = -1;
+        if ((rowbits[r2] >> lx) & 1u) myroot[k] = lds_find(lab, r2 * CCL_TX + lx);
+    }
+    __syncthreads();
+    unsigned int* cnt = (unsigned int*)lab;  // (a second 32 KiB array halved the occupancy: 2.1 -> 4.0 ms per 512^3 mask)
+#pragma unroll
+    for (int k = 0; k < CCL_TILE / 256; ++k) cnt[tid + 256 * k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CCL_TILE / 256; ++k) {
+        const int lx = tid & 31;
+        // one LDS atomic per run of equal roots in the row (a solid tile would otherwise put 8 192 atomics on one word)
+        const int prev = __shfl_up(myroot[k], 1);
+        const bool lead = lx == 0 || prev != myroot[k];
+        const unsigned int leads = (unsigned int)(__ballot(lead) >> (32 * ((tid >> 5) & 1)));  // this row's half of the wave
+        if (lead && myroot[k] >= 0) {
+            const unsigned int after = lx == 31 ? 0u : (leads >> (lx + 1));
+            const int len = after ? __ffs((int)after) : 32 - lx;
+            atomicAdd(&cnt[myroot[k]], (unsigned int)len);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CCL_TILE / 256; ++k) {
+        const int r2 = (tid >> 5) + 8 * k, lx = tid & 31, ly = r2 % CCL_TY, lz = r2 / CCL_TY;
+        const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+        if (x >= X || y >= Y || z >= Z) continue;
+        int out = -1;
+        if (myroot[k] >= 0) {
+            const int rt = myroot[k];
+            const int rx = rt % CCL_TX, rr = rt / CCL_TX;
+            out = (int)(((size_t)(z0 + rr / CCL_TY) * Y + (y0 + rr % CCL_TY)) * X + (x0 + rx));
+        }
+        const size_t gi = ((size_t)z * Y + y) * X + x;
+        L[gi] = out;
+        sizes[gi] = cnt[r2 * CCL_TX + lx];  // > 0 only at tile-local roots (every voxel is written: no memset of `sizes`)
+    }
+}
+
+// after the border unions: every voxel points at its global root; a tile-local root that is not the global root hands its count
+// over (one global atomic per tile-local component instead of one per voxel)
+__global__ __launch_bounds__(256) void k_ccl_resolve(size_t n, int* L, unsigned int* sizes, int* n_comp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int is_root = 0;
+    if (i < n) {
+        const int p0 = L[i];
+        if (p0 >= 0) {
+            int root = p0, p = L[root];
+            while (p != root) {
+                root = p;
+                p = L[root];
+            }
+            if (root != p0) L[i] = root;
+            if (root == (int)i) {
+                is_root = 1;
+            } else {
+                const unsigned int c = sizes[i];
+                if (c) {
+                    atomicAdd(&sizes[root], c);
+                    sizes[i] = 0;
+                }
+            }
+        }
+    }
+    const unsigned long long b = __ballot(is_root);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_comp, __popcll(b));
+}
+
+// unions across tile faces only: voxels on the faces x = 0 (its x - 1 neighbours in the later rows), x = TX-1, y = 0 (the
+// (dz, dy) = (1, -1) row), y = TY-1 and z = TZ-1 of their tile have forward neighbours in another tile
+__global__ __launch_bounds__(256) void k_ccl_border(const unsigned char* __restrict__ mask, int Z, int Y, int X, int* L) {
+    // grid (x blocks, y, z): no divisions
+    const int x = (int)blockIdx.x * 256 + (int)threadIdx.x, y = (int)blockIdx.y, z = (int)blockIdx.z;
+    if (x >= X) return;
+    const size_t i = ((size_t)z * Y + y) * X + x;
+    const int lx = x % CCL_TX, ly = y % CCL_TY, lz = z % CCL_TZ;
+    if (lx != 0 && lx != CCL_TX - 1 && ly != 0 && ly != CCL_TY - 1 && lz != CCL_TZ - 1) return;
+    if (!mask[i]) return;
+    if (lx == CCL_TX - 1 && x + 1 < X && mask[i + 1]) uf_union(L, (int)i, (int)(i + 1));
+    const bool left = x > 0 && mask[i - 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int dz = r == 0 ? 0 : 1, dy = r == 0 ? 1 : r - 2;
+        const int zz = z + dz, yy = y + dy;
+        if (zz >= Z || yy < 0 || yy >= Y) continue;
+        const bool row_other = (dz && lz == CCL_TZ - 1) || (dy == 1 && ly == CCL_TY - 1) || (dy == -1 && ly == 0);
+        const size_t row = ((size_t)zz * Y + yy) * X;
+        const bool m0 = x > 0 && mask[row + x - 1], m1 = mask[row + x] != 0, m2 = x + 1 < X && mask[row + x + 1];
+        // (a link inside the tile was made in LDS; x - 1 / x + 1 of the other row hang on its x voxel through that row's own links)
+        if (row_other) {
+            // the whole row lies in another tile.  As in k_ccl_merge: a foreground left neighbour (same face, so it runs this
+            // code too -- in this tile or the one to the left) has linked itself to x - 2, x - 1, x of that row already
+            if (!left) {
+                if (m1) {
+                    uf_union(L, (int)i, (int)(row + x));
+                } else {
+                    if (m0) uf_union(L, (int)i, (int)(row + x - 1));
+                    if (m2) uf_union(L, (int)i, (int)(row + x + 1));
+                }
+            } else if (m2 && !m1) {
+                uf_union(L, (int)i, (int)(row + x + 1));
+            }
+        } else if (!m1) {
+            if (m0 && lx == 0) uf_union(L, (int)i, (int)(row + x - 1));
+            if (m2 && lx == CCL_TX - 1) uf_union(L, (int)i, (int)(row + x + 1));
+        }
+    }
+}
+
 #define CCL_VPT 8
 __global__ __launch_bounds__(256) void k_ccl_compress(size_t n, int* L, unsigned int* sizes, int* n_comp) {
     // Each thread resolves CCL_VPT voxels (256 apart, so the loads stay coalesced) and run-length merges their roots; the wave
@@ -692,13 +894,23 @@ extern "C" int boa_ccl26(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int 
     int* d_count = nullptr;
     BOA_HIP_TRY(hipMalloc(&d_count, sizeof(int)));
     BOA_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
-    BOA_HIP_TRY(hipMemsetAsync(dev_sizes, 0, n * sizeof(uint32_t), c->stream));
+    static const bool flat = getenv("BOA_CCL_FLAT") != nullptr;  // the one-level version (A/B switch)
+    if (flat) BOA_HIP_TRY(hipMemsetAsync(dev_sizes, 0, n * sizeof(uint32_t), c->stream));
     unsigned grid = (unsigned)((n + 255) / 256);
     KernelTimer t(c, BOA_K_MORPH, 0, (double)n * 14.0);
-    hipLaunchKernelGGL(k_ccl_init, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, dev_roots);
-    hipLaunchKernelGGL(k_ccl_merge, dim3(grid), dim3(256), 0, c->stream, dev_mask, Z, Y, X, dev_roots);
-    hipLaunchKernelGGL(k_ccl_compress, dim3((unsigned)((n + 256 * CCL_VPT - 1) / (256 * CCL_VPT))), dim3(256), 0, c->stream, n, dev_roots,
-                       dev_sizes, d_count);
+    if (flat) {
+        hipLaunchKernelGGL(k_ccl_init, dim3(grid), dim3(256), 0, c->stream, dev_mask, n, dev_roots);
+        hipLaunchKernelGGL(k_ccl_merge, dim3(grid), dim3(256), 0, c->stream, dev_mask, Z, Y, X, dev_roots);
+        hipLaunchKernelGGL(k_ccl_compress, dim3((unsigned)((n + 256 * CCL_VPT - 1) / (256 * CCL_VPT))), dim3(256), 0, c->stream, n, dev_roots,
+                           dev_sizes, d_count);
+    } else {
+        const int tx = (X + CCL_TX - 1) / CCL_TX, ty = (Y + CCL_TY - 1) / CCL_TY, tz = (Z + CCL_TZ - 1) / CCL_TZ;
+        hipLaunchKernelGGL(k_ccl_local, dim3((unsigned)((size_t)tx * ty * tz)), dim3(256), 0, c->stream, dev_mask, Z, Y, X, tx, ty, dev_roots,
+                           dev_sizes);
+        hipLaunchKernelGGL(k_ccl_border, dim3((unsigned)((X + 255) / 256), (unsigned)Y, (unsigned)Z), dim3(256), 0, c->stream, dev_mask, Z, Y, X,
+                           dev_roots);
+        hipLaunchKernelGGL(k_ccl_resolve, dim3(grid), dim3(256), 0, c->stream, n, dev_roots, dev_sizes, d_count);
+    }
     t.stop();
     int cnt = 0;
     hipError_t e = hipMemcpyAsync(&cnt, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
@@ -712,9 +924,15 @@ extern "C" int boa_ccl26(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int 
 
 __global__ __launch_bounds__(256) void k_ccl_best(const unsigned int* __restrict__ sizes, size_t n,
                                                   unsigned long long* best) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // grid-stride, one atomic per wave of a few thousand (one per 64 voxels was 2 M atomics on one word: 1.8 ms per 512^3 volume)
     unsigned long long key = 0;
-    if (i < n && sizes[i]) key = ((unsigned long long)sizes[i] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned int sz = sizes[i];
+        if (sz) {
+            const unsigned long long k = ((unsigned long long)sz << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+            key = k > key ? k : key;
+        }
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         unsigned long long o = __shfl_xor(key, m);
@@ -742,7 +960,7 @@ extern "C" int boa_ccl_filter_largest(boa_ctx* c, const int32_t* dev_roots, cons
     BOA_HIP_TRY(hipMalloc(&d_best, sizeof(unsigned long long)));
     BOA_HIP_TRY(hipMemsetAsync(d_best, 0, sizeof(unsigned long long), c->stream));
     unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_ccl_best, dim3(grid), dim3(256), 0, c->stream, dev_sizes, n, d_best);
+    hipLaunchKernelGGL(k_ccl_best, dim3(std::min<unsigned>(grid, (unsigned)c->cu_count * 8)), dim3(256), 0, c->stream, dev_sizes, n, d_best);
     hipLaunchKernelGGL(k_ccl_apply_largest, dim3(grid), dim3(256), 0, c->stream, dev_roots, n, d_best, dev_seg,
                        fill_value);
     hipError_t e = hipStreamSynchronize(c->stream);

@@ -953,6 +953,7 @@ struct ConvTArgs {
     const float* bias;
     __half* out;
     float slope;
+    int dbg;  // BOA_CONVT_DBG ablation bits (results wrong by design): 1 no output stores, 2 no weight loads, 4 no input staging
 };
 
 // One wave = 32 consecutive (flattened) input voxels.  Per (tx, ty, cout chunk) it computes BOTH z taps (TZ = s2
@@ -969,23 +970,25 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     const int l31 = lane & 31;
     const int kh = lane >> 5;
     const int ncc = p.Cin / 16;
-    const size_t in_vox = (size_t)p.Di * p.Hi * p.Wi;
-    const size_t total = (size_t)p.N * in_vox;
+    // (32-bit index arithmetic: N * in_vox < 2^31, checked on the host -- the 64-bit divisions of the first version were
+    //  ~40 % of the kernel's instructions)
+    const unsigned in_vox = (unsigned)(p.Di * p.Hi * p.Wi);
+    const unsigned total = (unsigned)p.N * in_vox;
     constexpr int SLAB = 2 * 32 * TZ * 32;  // bytes: [2 planes][32 * TZ output voxels][16 halves]
     unsigned char* lds = smem + (size_t)wave * (ncc * 1024 + SLAB);  // [cc][khalf][32 voxels][8 halves] + slab
     unsigned char* slab = lds + ncc * 1024;
-    const size_t g0 = ((size_t)blockIdx.x * 4 + wave) * 32;  // first flattened (n, voxel) of this wave
-    const size_t g = g0 + l31;
+    const unsigned g0 = ((unsigned)blockIdx.x * 4 + wave) * 32;  // first flattened (n, voxel) of this wave
+    const unsigned g = g0 + l31;
     const bool valid = g < total;
-    const int n = valid ? (int)(g / in_vox) : 0;
-    const size_t vi = valid ? g % in_vox : 0;
+    const unsigned n = valid ? g / in_vox : 0;
+    const unsigned vi = valid ? g - n * in_vox : 0;
     // stage this wave's 32 voxels: lane (l31, kh) moves octet kh of every 16-channel chunk; loads batched by 4
     for (int c0 = 0; c0 < ncc; c0 += 4) {
         uint4 val[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int cc = min(c0 + b, ncc - 1);
-            val[b] = *(const uint4*)(p.src + (((size_t)n * ncc + cc) * in_vox + vi) * 16 + kh * 8);  // chunk-planar
+            val[b] = (p.dbg & 4) ? make_uint4(0, 0, 0, 0) : *(const uint4*)(p.src + (((size_t)n * ncc + cc) * in_vox + vi) * 16 + kh * 8);  // chunk-planar
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -1019,11 +1022,13 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     for (int k = 0; k < TZ; ++k) {
         const int ov = (lane + 64 * k) >> 1;
         const int j = ov / TZ, tz = ov % TZ;
-        const size_t gg = g0 + j;
+        const unsigned gg = g0 + j;
         ovalid[k] = gg < total;
-        const size_t nn = ovalid[k] ? gg / in_vox : 0;
-        const size_t v2 = ovalid[k] ? gg % in_vox : 0;
-        const int iz = (int)(v2 % p.Wi), iy = (int)((v2 / p.Wi) % p.Hi), ix = (int)(v2 / ((size_t)p.Wi * p.Hi));
+        const unsigned nn = ovalid[k] ? gg / in_vox : 0;
+        const unsigned v2 = ovalid[k] ? gg - nn * in_vox : 0;
+        const unsigned r2 = v2 / (unsigned)p.Wi;
+        const int iz = (int)(v2 - r2 * (unsigned)p.Wi);
+        const int ix = (int)(r2 / (unsigned)p.Hi), iy = (int)(r2 - (unsigned)ix * (unsigned)p.Hi);
         onn[k] = nn;
         ospat[k] = ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2 + tz);
     }
@@ -1041,8 +1046,10 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
 #pragma unroll
             for (int t = 0; t < TZ; ++t)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    a[t][b] = *(const f16x8*)(p.wpk + ((((size_t)(tap0 + t) * ncc + min(c0 + b, ncc - 1)) * 2 + kh) * p.Cout + co * 32 + l31) * 8);
+                for (int b = 0; b < 2; ++b) {
+                    a[t][b] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
+                    if (!(p.dbg & 2)) a[t][b] = *(const f16x8*)(p.wpk + ((((size_t)(tap0 + t) * ncc + min(c0 + b, ncc - 1)) * 2 + kh) * p.Cout + co * 32 + l31) * 8);
+                }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 if (c0 + b < ncc) {
@@ -1077,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
             for (int k = 0; k < TZ; ++k) {
                 const int piece = lane + 64 * k;
                 const uint4 d = *(const uint4*)(slab + pl * 32 * TZ * 32 + piece * 16);
-                if (ovalid[k])
+                if (ovalid[k] && !(p.dbg & 1))
                     *(uint4*)(p.out + ((onn[k] * (p.Cout / 16) + co * 2 + pl) * ovox + ospat[k] + toff) * 16 + 8 * (piece & 1)) = d;
             }
         __builtin_amdgcn_wave_barrier();
@@ -1091,13 +1098,17 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
     a.src = src.data; a.ss = src.ss; a.Cin = src.C; a.Cout = Cout; a.N = N;
     a.Di = din[0]; a.Hi = din[1]; a.Wi = din[2]; a.s0 = s[0]; a.s1 = s[1]; a.s2 = s[2];
     a.wpk = wpk; a.bias = bias; a.out = out; a.slope = slope;
+    static const int dbg = getenv("BOA_CONVT_DBG") ? atoi(getenv("BOA_CONVT_DBG")) : 0;
+    static const int gy_mult = getenv("BOA_CONVT_GY") ? atoi(getenv("BOA_CONVT_GY")) : 2;
+    a.dbg = dbg;
     size_t total = (size_t)N * din[0] * din[1] * din[2];
     int gx = (int)((total + 127) / 128);
     // split the (tap, cout-chunk) pairs over gridDim.y only as far as needed to fill the chip: every y-slice
     // re-stages the block's input voxels
     BOA_REQUIRE(s[2] == 1 || s[2] == 2, "convT: stride %d along the contiguous axis is not instantiated (1 or 2)", s[2]);
+    BOA_REQUIRE((double)total < 2147483648.0 - 256.0, "convT: %zu input voxels exceed the 32-bit index range", total);
     const int npairs = s[0] * s[1] * (Cout / 32);   // (tx, ty, cout chunk); a pair covers the s2 z taps
-    int gy = std::min(npairs, std::max(1, ceil_div(2 * ctx->cu_count, gx)));
+    int gy = std::min(npairs, std::max(1, ceil_div(gy_mult * ctx->cu_count, gx)));
     size_t lds = (size_t)4 * ((src.C / 16) * 1024 + 2 * 32 * s[2] * 32);
     BOA_REQUIRE(lds <= 160 * 1024, "convT: Cin=%d needs %zu bytes of LDS", src.C, lds);
     static bool once = (hipFuncSetAttribute((const void*)k_convt_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),

@@ -387,14 +387,24 @@ extern "C" int boa_copy3(boa_ctx* c, const void* dev_in, int in_dtype, long long
 // or [0, dim) when everything is zero.  host_bbox: int[6] = {lo0, hi0, lo1, hi1, lo2, hi2}.  Synchronous.
 template <typename T>
 __global__ __launch_bounds__(256) void k_nonzero_bbox(const T* __restrict__ in, int d0, int d1, int d2, int* __restrict__ bb) {
-    const size_t n = (size_t)d0 * d1 * d2;
+    // one wave per row of the contiguous axis: the (axis 0, axis 1) indices come from the row number once per row (the first
+    // version decomposed every non-zero voxel's linear index with 64-bit divisions: 1.2 ms per 512^3 mask, 115 GB/s)
     int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        if (in[i] != (T)0) {
-            const int o2 = (int)(i % d2), o1 = (int)((i / d2) % d1), o0 = (int)(i / ((size_t)d2 * d1));
+    const unsigned rows = (unsigned)d0 * (unsigned)d1;
+    const unsigned lane = threadIdx.x & 63, nw = gridDim.x * 4;
+    for (unsigned r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+        const T* p = in + (size_t)r * d2;
+        int lx = 1 << 30, hx = -1;
+        for (int x = (int)lane; x < d2; x += 64)
+            if (p[x] != (T)0) {
+                lx = min(lx, x);
+                hx = max(hx, x);
+            }
+        if (hx >= 0) {
+            const int o0 = (int)(r / (unsigned)d1), o1 = (int)(r - (unsigned)o0 * (unsigned)d1);
             lo[0] = min(lo[0], o0); hi[0] = max(hi[0], o0);
             lo[1] = min(lo[1], o1); hi[1] = max(hi[1], o1);
-            lo[2] = min(lo[2], o2); hi[2] = max(hi[2], o2);
+            lo[2] = min(lo[2], lx); hi[2] = max(hi[2], hx);
         }
     }
 #pragma unroll
@@ -420,7 +430,7 @@ extern "C" int boa_nonzero_bbox(boa_ctx* c, const void* dev_in, int dtype, const
     const int init[6] = {1 << 30, -1, 1 << 30, -1, 1 << 30, -1};
     BOA_HIP_TRY(hipMemcpyAsync(d_bb, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     const size_t n = (size_t)dims[0] * dims[1] * dims[2];
-    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 16);
+    const unsigned grid = (unsigned)std::min<size_t>(((size_t)dims[0] * dims[1] + 3) / 4, (size_t)c->cu_count * 32);
     c->prof_break = true;
     if (n) {
         switch (dtype) {

@@ -174,6 +174,40 @@ def test_ccl_and_region_postprocess_vs_oracle(ctx):
     assert (got == 255).sum() > 0
 
 
+@pytest.mark.parametrize("shape", [(33, 35, 70), (16, 16, 32), (17, 49, 33), (5, 3, 100), (48, 32, 64), (1, 1, 7)])
+def test_ccl26_roots_sizes_vs_scipy(ctx, shape):
+    """boa_ccl26 (tiles labelled in LDS, unions across tile faces in global memory): roots = smallest linear index of the
+    26-connected component, sizes[root] = its voxel count, for noise of several densities and blobs, on shapes that cut the
+    32 x 16 x 16 tiles raggedly."""
+    import ctypes as C
+    from scipy import ndimage
+    rng = np.random.default_rng(sum(shape))
+    n = int(np.prod(shape))
+    masks = [rng.random(shape) < p for p in (0.03, 0.15, 0.4, 0.75, 0.97)] + [_blobs(rng, shape, 25, max(2, min(shape) // 2 + 2)),
+                                                                            np.ones(shape, bool), np.zeros(shape, bool)]
+    d_roots, d_sizes = ctx.alloc(n * 4), ctx.alloc(n * 4)
+    for m in masks:
+        d_m = ctx.from_numpy(m.astype(np.uint8))
+        ncomp = C.c_int()
+        from boa_hip._lib import check
+        check(ctx.lib.boa_ccl26(ctx.h, d_m.vp, shape[0], shape[1], shape[2], d_roots.vp, d_sizes.vp, C.byref(ncomp)), "boa_ccl26")
+        roots = d_roots.download(shape, np.int32)
+        sizes = d_sizes.download((n,), np.uint32)
+        d_m.free()
+        lab, k = ndimage.label(m, structure=np.ones((3, 3, 3)))
+        assert ncomp.value == k
+        assert (roots[~m] == -1).all()
+        if k:
+            idx = np.arange(n).reshape(shape)
+            first = ndimage.minimum(idx, lab, index=np.arange(1, k + 1)).astype(np.int64)      # smallest index per component
+            np.testing.assert_array_equal(roots[m], first[lab[m] - 1])
+            cnt = np.bincount(lab[m] - 1, minlength=k)
+            np.testing.assert_array_equal(sizes[first], cnt)
+            assert int(sizes.sum()) == int(m.sum())
+    d_roots.free()
+    d_sizes.free()
+
+
 def _blobs(rng, shape, n_blobs, rmax):
     """random union of balls/holes: enough structure for nested contours, holes, small objects"""
     zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
