@@ -98,6 +98,8 @@ def compute_all_models(
     if unsupported:
         raise NotImplementedError(f"models {unsupported} are not implemented on the device")
     segmentation_folder.mkdir(parents=True, exist_ok=True)
+    if totalsegmentator_params.get("nr_thr_saving"):      # the reference's saving workers = deflate threads of nifti.save here
+        nifti.SAVE_THREADS = max(1, int(totalsegmentator_params["nr_thr_saving"]))
     ctx = get_context(totalsegmentator_params.get("device"))
     data, affine, hdr = nifti.load(ct_path)
     ct = _ct_array(data, hdr)

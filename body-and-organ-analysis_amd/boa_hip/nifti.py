@@ -10,6 +10,7 @@ UNPINNED vs nibabel's byte-level output; the header fields follow the standard).
 from __future__ import annotations
 
 import gzip
+import os
 import struct
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -161,9 +162,37 @@ def parse_label_xml(content: bytes) -> Dict[int, str]:
                                              content.decode("utf-8", "replace"))}
 
 
+SAVE_THREADS = int(os.environ.get("BOA_SAVE_THREADS", "0")) or min(8, os.cpu_count() or 1)   # nr_thr_saving of the reference
+_GZ_BLOCK = 4 << 20
+
+
+def write_gzip_members(f, payload, compresslevel: int = 1, threads: int = 1, block: int = _GZ_BLOCK):
+    """`payload` (bytes-like) as a gzip stream of independently compressed members (RFC 1952 section 2.2: a gzip file is a
+    series of members; gzip.open, zlib's gzread -- SimpleITK, nibabel -- and `gunzip` read them as one stream), the members
+    deflated in parallel: zlib releases the GIL, so a 512^3 label volume (134 MB) compresses on `threads` cores instead of
+    one (pigz's scheme without its shared dictionary; level 1 like nibabel's default, so the ratio loss is a fraction of a
+    percent).  The reference saves its volumes from `nr_thr_saving` worker processes instead (TS/nnunet.py:705-724)."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    mv = memoryview(payload).cast("B")
+
+    def member(lo):
+        c = zlib.compressobj(compresslevel, zlib.DEFLATED, 31)      # wbits 31: gzip header + crc32 + isize trailer
+        return c.compress(mv[lo:lo + block]) + c.flush()
+
+    starts = list(range(0, len(mv), block)) or [0]
+    if threads <= 1 or len(starts) == 1:
+        for lo in starts:
+            f.write(member(lo))
+        return
+    with ThreadPoolExecutor(max_workers=min(threads, len(starts))) as ex:
+        for part in ex.map(member, starts):
+            f.write(part)
+
+
 def save(path, data: np.ndarray, affine: np.ndarray, like: Optional[NiftiHeader] = None,
-         extensions: Optional[List[Tuple[int, bytes]]] = None, compresslevel: int = 1):
-    """Write `data` (file axis order).  `like`: header to copy (pixdim units, descrip, q/s-form codes ... as
+         extensions: Optional[List[Tuple[int, bytes]]] = None, compresslevel: int = 1, threads: Optional[int] = None):
+    """Write `data` (file axis order); `.gz` paths are deflated on `threads` cores (default SAVE_THREADS).  `like`: header to copy (pixdim units, descrip, q/s-form codes ... as
     `img_in_orig.header.copy()` keeps them); datatype/bitpix/dim/vox_offset and the affine fields are set from the
     arguments; scl_slope/inter are reset (label volumes are stored unscaled)."""
     data = np.asarray(data)
@@ -194,8 +223,12 @@ def save(path, data: np.ndarray, affine: np.ndarray, like: Optional[NiftiHeader]
     v[30] = float(352 + len(ext_blob))
     v[-1] = b"n+1\0"
     hdr = struct.pack(_HDR, *v)
-    with _open(path, "wb") if not str(path).endswith(".gz") else gzip.open(path, "wb", compresslevel=compresslevel) as f:
-        f.write(hdr)
-        f.write(bytes([1 if exts else 0, 0, 0, 0]))
-        f.write(ext_blob)
-        f.write(np.asfortranarray(data).tobytes(order="F"))
+    head = hdr + bytes([1 if exts else 0, 0, 0, 0]) + ext_blob
+    body = np.asfortranarray(data).reshape(-1, order="F")          # (a view when `data` is already F-ordered)
+    with open(path, "wb") as f:
+        if str(path).endswith(".gz"):
+            write_gzip_members(f, head, compresslevel, 1)
+            write_gzip_members(f, body, compresslevel, SAVE_THREADS if threads is None else int(threads))
+        else:
+            f.write(head)
+            f.write(body.tobytes())

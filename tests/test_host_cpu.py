@@ -272,3 +272,26 @@ def test_descriptive_statistics_equal_pandas_describe():
             for k, y in want[col].items():
                 x = m[col][k]
                 assert (x is None and y is None) or (type(x) is float and x == float(y)), (col, k, x, y)
+
+
+def test_nifti_parallel_gzip_members(tmp_path):
+    """`.nii.gz` written as independently deflated gzip members (nr_thr_saving cores): standard readers see one stream, the
+    bytes do not depend on the thread count, load() round-trips."""
+    import gzip
+    import subprocess
+    from boa_hip import nifti
+    rng = np.random.default_rng(5)
+    a = (rng.integers(0, 118, (160, 150, 230)) * (rng.random((160, 150, 230)) < 0.25)).astype(np.uint8)     # 5.5 MB: 2 members
+    aff = np.array([[-1.5, 0, 0, 10], [0, -1.5, 0, 20], [0, 0, 3.0, -5], [0, 0, 0, 1]], dtype=np.float64)
+    p1, p4 = tmp_path / "t1.nii.gz", tmp_path / "t4.nii.gz"
+    nifti.save(p1, a, aff, threads=1, extensions=[(0, nifti.label_xml({1: "one", 2: "two"}))])
+    nifti.save(p4, a, aff, threads=4, extensions=[(0, nifti.label_xml({1: "one", 2: "two"}))])
+    assert p1.read_bytes() == p4.read_bytes()
+    raw = gzip.open(p4, "rb").read()                                   # Python's reader: all members, one stream
+    assert len(raw) == int(np.frombuffer(raw[108:112], "<f4")[0]) + a.size
+    out = subprocess.run(["gunzip", "-c", str(p4)], capture_output=True)
+    if out.returncode == 0:
+        assert out.stdout == raw
+    b, baff, hdr = nifti.load(p4)
+    assert np.array_equal(a, b) and np.allclose(aff, baff)
+    assert nifti.parse_label_xml(hdr.extensions[0][1]) == {1: "one", 2: "two"}
