@@ -28,6 +28,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -280,17 +281,26 @@ def main():
         # compute_measurements' view: SimpleITK (z,y,x) arrays of the file (BOA/compute/measurements.py:257-258)
         c_zyx = d_in.transpose((2, 1, 0)).contiguous(np.int16, force_copy=True)
         s_zyx = d_total.transpose((2, 1, 0)).contiguous(force_copy=True)
-        meas, d_mask = M.total_measurements(ctx, None, None, label_map, (1.5, 1.5, 1.5), cnr_adjustment=True, d_ct=c_zyx.buf,
-                                            d_lab=s_zyx.buf, shape=c_zyx.shape, mask_on_device=True)
+        # device passes now; the per-label order statistics (pure numpy on the downloaded histogram) on a worker thread under
+        # the BCA nets' kernels -- joined before the step ends, so every step still delivers its complete tables
+        fin, d_mask = M.total_measurements(ctx, None, None, label_map, (1.5, 1.5, 1.5), cnr_adjustment=True, d_ct=c_zyx.buf,
+                                           d_lab=s_zyx.buf, shape=c_zyx.shape, mask_on_device=True, defer_host=pipe is not None)
         d_mask.free()
         c_zyx.free()
         s_zyx.free()
         ts_ = stage("total measurements", ts_)
         res = None
         if pipe is not None:
+            box = {}
+            th = threading.Thread(target=lambda: box.update(meas=fin()))
+            th.start()
             res = pipe.run_resident(d_in, affine, d_total)
             outs += [res["body_parts"], res["body_regions"], res["tissues"]]
+            th.join()
+            meas = box["meas"]
             ts_ = stage("bca", ts_)
+        else:
+            meas = fin
         host = [a.download() for a in outs] if download else None
         chk = None
         if download:

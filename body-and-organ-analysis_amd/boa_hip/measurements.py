@@ -216,9 +216,12 @@ def cnr_adjusted_region_metrics(ctx: Context, d_ct: DeviceBuffer, d_lab: DeviceB
 
 def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Optional[np.ndarray], label_map: Dict[str, int],
                        spacing, cnr_adjustment: bool = True, model_name: str = "total", d_ct: Optional[DeviceBuffer] = None,
-                       d_lab: Optional[DeviceBuffer] = None, shape=None, mask_on_device: bool = False, shard=None):
+                       d_lab: Optional[DeviceBuffer] = None, shape=None, mask_on_device: bool = False, shard=None,
+                       defer_host: bool = False):
     """compute_measurements (:244-343) for models == ["total"] on (z,y,x) arrays.  Returns (measurements dict, ct_pfav
-    mask).  Resident inputs: pass `d_ct` (int16) / `d_lab` (uint8) + `shape` instead of the host arrays (not freed here);
+    mask).  `defer_host=True`: the device passes run now, the ~120 per-label order statistics (pure numpy on the downloaded
+    histogram) are returned as a function `finish() -> measurements dict` in place of the dict, so that a caller can run them
+    on a worker thread while the device works on the next stage (bench.py: under the BCA nets).  Resident inputs: pass `d_ct` (int16) / `d_lab` (uint8) + `shape` instead of the host arrays (not freed here);
     `mask_on_device=True` returns the mask as a DeviceBuffer (caller frees).
 
     `shard` = (agg_shard.AggComm, (a, b)): the arrays are this rank's z-slab of the volume INCLUDING a halo of
@@ -266,7 +269,6 @@ def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Option
         binary_erode(ctx, d_m, d_e, d_t, shape)
         st_auto = _masked_stats(ctx, d_ct, d_e, n)
         am, asd = (st_auto["mean"], st_auto["std"]) if st_auto else (None, None)
-        seg = _metrics_from_hist(hist, label_map, am, asd, spacing)
         # pulmonary fat (ct_pfav, :151-200): the fat window of a label (union) is a bin range of its histogram rows
         lo, hi = ADIPOSE_TISSUE[0] - HU_MIN, ADIPOSE_TISSUE[1] - HU_MIN
 
@@ -276,12 +278,16 @@ def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Option
                 h += hist[label_map[nm]][lo:hi + 1]
             return _metrics(stats_from_hist(h, ADIPOSE_TISSUE[0]), ml, am, asd)
 
-        pf = {}
-        for nm in LUNG_MASKS:
-            pf["ct_pfav_" + nm] = fat_metrics([nm])
-        for side in ("left", "right"):
-            pf[f"ct_pfav_lobe_{side}"] = fat_metrics([nm for nm in LUNG_MASKS if nm.endswith(side)])
-        pf["ct_pfav_lungs"] = fat_metrics(LUNG_MASKS)
+        def host_tables():
+            seg = _metrics_from_hist(hist, label_map, am, asd, spacing)
+            pf = {}
+            for nm in LUNG_MASKS:
+                pf["ct_pfav_" + nm] = fat_metrics([nm])
+            for side in ("left", "right"):
+                pf[f"ct_pfav_lobe_{side}"] = fat_metrics([nm for nm in LUNG_MASKS if nm.endswith(side)])
+            pf["ct_pfav_lungs"] = fat_metrics(LUNG_MASKS)
+            return {**seg, **pf}
+
         label_hu_mask(ctx, d_ct, d_lab, [label_map[nm] for nm in LUNG_MASKS], 1, n, d_m)
         if mask_on_device:
             keep_mask = ctx.alloc(n)
@@ -290,7 +296,6 @@ def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Option
             fat_mask = keep_mask
         else:
             fat_mask = d_m.download(shape, np.uint8)
-        meas["segmentations"][model_name] = {**seg, **pf}
         if cnr_adjustment and model_name in CNR_ADJUSTED_REGIONS:
             if am is not None and asd is not None:
                 adj = {}
@@ -310,7 +315,14 @@ def total_measurements(ctx: Context, ct: Optional[np.ndarray], total_seg: Option
         meas["info"]["autochthon_mean"] = am
         meas["info"]["autochthon_std"] = asd
         keep_mask = None
-        return meas, fat_mask
+
+        def finish():
+            out = {"segmentations": {model_name: host_tables()}, "info": meas["info"]}      # key order of the reference's dict
+            if "cnr_adjusted" in meas:
+                out["cnr_adjusted"] = meas["cnr_adjusted"]
+            return out
+
+        return (finish if defer_host else finish()), fat_mask
     finally:
         for b in ((d_ct, d_lab) if own else ()) + (d_m, d_e, d_t) + ((keep_mask,) if keep_mask is not None else ()):
             b.free()
