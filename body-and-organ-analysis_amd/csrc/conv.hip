@@ -948,12 +948,12 @@ int launch_norm_finalize(boa_ctx* ctx, float* partials, int nblk, int N, int C, 
 struct ConvTArgs {
     const __half* src;
     const float* ss;
+    const unsigned* ss16;  // packed fp16 (scale, shift) pairs of the input's deferred norm (preferred), or NULL
     int Cin, Cout, N, Di, Hi, Wi, s0, s1, s2;
     const __half* wpk;  // [tap][Cin/16][2][Cout][8]
     const float* bias;
     __half* out;
     float slope;
-    int dbg;  // BOA_CONVT_DBG ablation bits (results wrong by design): 1 no output stores, 2 no weight loads, 4 no input staging
 };
 
 // One wave = 32 consecutive (flattened) input voxels.  Per (tx, ty, cout chunk) it computes BOTH z taps (TZ = s2
@@ -961,6 +961,36 @@ struct ConvTArgs {
 // one 16-cout plane is one run of 2 KiB (TZ = 2) of consecutive bytes.  The D fragments go through a per-wave LDS slab
 // [2 planes][32 TZ voxels][16 couts] and leave as 16-byte pieces, lane L taking pieces L, L + 64, ...: every store
 // instruction writes 1 KiB of consecutive bytes (the one-tap-per-pass form wrote 32-byte pieces 64 bytes apart).
+typedef _Float16 ct_h2 __attribute__((ext_vector_type(2)));
+
+// deferred InstanceNorm + LeakyReLU on 8 channels in packed fp16 (the same one-rounding evaluation as k_conv_ws's producers):
+// w = 4 x {packed scales, packed shifts} of the four channel pairs
+__device__ __forceinline__ uint4 convt_norm_act8_pk(uint4 raw, const uint4& w0, const uint4& w1, unsigned slope2) {
+    union {
+        uint4 u;
+        ct_h2 v[4];
+    } x;
+    union {
+        unsigned u;
+        ct_h2 v;
+    } s, t, sl;
+    const unsigned w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    x.u = raw;
+    sl.u = slope2;
+    ct_h2 y[4], z[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s.u = w[2 * i];
+        t.u = w[2 * i + 1];
+        y[i] = __builtin_elementwise_fma(x.v[i], s.v, t.v);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = y[i] * sl.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x.v[i] = __builtin_elementwise_max(y[i], z[i]);
+    return x.u;
+}
+
 template <int TZ>
 __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -971,7 +1001,8 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     const int kh = lane >> 5;
     const int ncc = p.Cin / 16;
     // (32-bit index arithmetic: N * in_vox < 2^31, checked on the host -- the 64-bit divisions of the first version were
-    //  ~40 % of the kernel's instructions)
+    //  ~40 % of the kernel's instructions; the kernel is instruction-bound: with every memory access switched off it still
+    //  took half of its time)
     const unsigned in_vox = (unsigned)(p.Di * p.Hi * p.Wi);
     const unsigned total = (unsigned)p.N * in_vox;
     constexpr int SLAB = 2 * 32 * TZ * 32;  // bytes: [2 planes][32 * TZ output voxels][16 halves]
@@ -983,40 +1014,55 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     const unsigned n = valid ? g / in_vox : 0;
     const unsigned vi = valid ? g - n * in_vox : 0;
     // stage this wave's 32 voxels: lane (l31, kh) moves octet kh of every 16-channel chunk; loads batched by 4
-    for (int c0 = 0; c0 < ncc; c0 += 4) {
-        uint4 val[4];
+    {
+        union {
+            unsigned u;
+            ct_h2 v;
+        } sl2;
+        sl2.v = ct_h2{(_Float16)p.slope, (_Float16)p.slope};
+        const __half* src_l = p.src + ((size_t)n * ncc * in_vox + vi) * 16 + kh * 8;   // + cc * in_vox * 16 per chunk
+        const unsigned* ss16_l = p.ss16 ? p.ss16 + ((size_t)n * p.Cin + kh * 8) : nullptr;  // + cc * 16 words per chunk
+        for (int c0 = 0; c0 < ncc; c0 += 4) {
+            uint4 val[4], w0[4], w1[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int cc = min(c0 + b, ncc - 1);
-            val[b] = (p.dbg & 4) ? make_uint4(0, 0, 0, 0) : *(const uint4*)(p.src + (((size_t)n * ncc + cc) * in_vox + vi) * 16 + kh * 8);  // chunk-planar
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int cc = min(c0 + b, ncc - 1);
-            uint4 o = val[b];
-            if (p.ss) {
-                float sc[8], sh[8];
-                const float* ss = p.ss + ((size_t)n * p.Cin + cc * 16 + kh * 8) * 2;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    sc[j] = ss[2 * j];
-                    sh[j] = ss[2 * j + 1];
+            for (int b = 0; b < 4; ++b) {
+                const int cc = min(c0 + b, ncc - 1);
+                val[b] = *(const uint4*)(src_l + (size_t)cc * in_vox * 16);  // chunk-planar
+                if (ss16_l) {
+                    w0[b] = *(const uint4*)(ss16_l + cc * 16);
+                    w1[b] = *(const uint4*)(ss16_l + cc * 16 + 4);
                 }
-                o = norm_act8(o, sc, sh, p.slope);
             }
-            if (!valid) o = make_uint4(0, 0, 0, 0);
-            *(uint4*)(lds + ((cc * 2 + kh) * 32 + l31) * 16) = o;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int cc = min(c0 + b, ncc - 1);
+                uint4 o = val[b];
+                if (ss16_l) {
+                    o = convt_norm_act8_pk(o, w0[b], w1[b], sl2.u);
+                } else if (p.ss) {  // (callers without the packed table: fp32 evaluation)
+                    float sc[8], sh[8];
+                    const float* ss = p.ss + ((size_t)n * p.Cin + cc * 16 + kh * 8) * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        sc[j] = ss[2 * j];
+                        sh[j] = ss[2 * j + 1];
+                    }
+                    o = norm_act8(o, sc, sh, p.slope);
+                }
+                if (!valid) o = make_uint4(0, 0, 0, 0);
+                *(uint4*)(lds + ((cc * 2 + kh) * 32 + l31) * 16) = o;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const int Do = p.Di * p.s0, Ho = p.Hi * p.s1, Wo = p.Wi * p.s2;
-    const size_t ovox = (size_t)Do * Ho * Wo;
+    const int Ho = p.Hi * p.s1, Wo = p.Wi * p.s2;
+    const size_t ovox = (size_t)(p.Di * p.s0) * Ho * Wo;
     const int nco = p.Cout / 32;
     const int npairs = p.s0 * p.s1 * nco;  // (tx, ty, cout chunk); every pair covers the TZ z taps
     // store side: the slab of one plane holds 32 * TZ output voxels = 64 * TZ pieces of 16 bytes; this lane takes pieces
-    // lane + 64 k (k < TZ) of each plane: output voxel ov = piece / 2 -> input voxel j = ov / TZ, z tap ov % TZ
-    size_t ospat[TZ];
-    size_t onn[TZ];
+    // lane + 64 k (k < TZ) of each plane: output voxel ov = piece / 2 -> input voxel j = ov / TZ, z tap ov % TZ.
+    // optr[k]: this lane's piece in plane 0 of the sample at tap (0, 0); a pass adds ((co * 2 + pl) * ovox + toff) * 32 bytes
+    unsigned char* optr[TZ];
     bool ovalid[TZ];
 #pragma unroll
     for (int k = 0; k < TZ; ++k) {
@@ -1029,63 +1075,81 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
         const unsigned r2 = v2 / (unsigned)p.Wi;
         const int iz = (int)(v2 - r2 * (unsigned)p.Wi);
         const int ix = (int)(r2 / (unsigned)p.Hi), iy = (int)(r2 - (unsigned)ix * (unsigned)p.Hi);
-        onn[k] = nn;
-        ospat[k] = ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2 + tz);
+        const size_t ospat = ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2 + tz);
+        optr[k] = (unsigned char*)p.out + ((size_t)nn * (p.Cout / 16) * ovox + ospat) * 32 + 16 * (lane & 1);
     }
+    // weights: wave-uniform part of the address per (tap, chunk, cout chunk) + this lane's (kh, cout) offset
+    const unsigned char* wbase = (const unsigned char*)p.wpk;
+    const unsigned wlane = ((unsigned)kh * (unsigned)p.Cout + (unsigned)l31) * 16u;
+    const unsigned wstep_cc = 2u * (unsigned)p.Cout * 16u;  // bytes per (tap, chunk)
+    const unsigned char* bfrag = lds + (kh * 32 + l31) * 16;  // + cc * 1024
+    int bias_co = -1;
+    f32x16 biasv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) biasv[i] = 0.f;
     for (int pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
         const int txy = pr / nco, co = pr - txy * nco;
         const int ty = txy % p.s1, tx = txy / p.s1;
-        f32x16 acc[TZ];
+        if (co != bias_co) {  // this lane's 16 biases of the cout chunk (entry 4 gq + e <-> cout 8 gq + 4 kh + e)
+            bias_co = co;
 #pragma unroll
-        for (int t = 0; t < TZ; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        const int tap0 = (tx * p.s1 + ty) * p.s2;
-        for (int c0 = 0; c0 < ncc; c0 += 2) {
-            f16x8 a[TZ][2];
-#pragma unroll
-            for (int t = 0; t < TZ; ++t)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    a[t][b] = f16x8{1, 1, 1, 1, 1, 1, 1, 1};
-                    if (!(p.dbg & 2)) a[t][b] = *(const f16x8*)(p.wpk + ((((size_t)(tap0 + t) * ncc + min(c0 + b, ncc - 1)) * 2 + kh) * p.Cout + co * 32 + l31) * 8);
-                }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                if (c0 + b < ncc) {
-                    const f16x8 bf = *(const f16x8*)(lds + (((c0 + b) * 2 + kh) * 32 + l31) * 16);
-#pragma unroll
-                    for (int t = 0; t < TZ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][b], bf, acc[t], 0, 0, 0);
-                }
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 bq = *(const float4*)(p.bias + co * 32 + 8 * gq + 4 * kh);
+                biasv[gq * 4 + 0] = bq.x; biasv[gq * 4 + 1] = bq.y; biasv[gq * 4 + 2] = bq.z; biasv[gq * 4 + 3] = bq.w;
             }
         }
-        // + bias, fp16, into the slab: lane (voxel l31, kh) holds couts 8 gq + 4 kh + e -> plane gq / 2, offset 8 (gq % 2) + 4 kh
+        f32x16 acc[TZ];
+        const int tap0 = (tx * p.s1 + ty) * p.s2;
+        const unsigned char* wpass = wbase + ((size_t)tap0 * ncc * wstep_cc + (size_t)co * 32 * 16);  // uniform
+        // groups of 4 chunks: the group's TZ x 4 weight fragments are loaded as one batch (the thin deep layers wait on L2 for
+        // them: 8 loads in flight per wave), then 4 x TZ MFMAs.  The very first MFMA takes an inline-zero C operand instead
+        // of zeroed accumulators.
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        auto group = [&](int c0, bool first) {
+            f16x8 a[TZ][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int t = 0; t < TZ; ++t)
+                    a[t][b] = *(const f16x8*)(wpass + (size_t)(t * ncc + min(c0 + b, ncc - 1)) * wstep_cc + wlane);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b == 0 || c0 + b < ncc) {  // (wave-uniform)
+                    const f16x8 bf = *(const f16x8*)(bfrag + (c0 + b) * 1024);
+#pragma unroll
+                    for (int t = 0; t < TZ; ++t)
+                        acc[t] = (first && b == 0) ? __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][b], bf, zero, 0, 0, 0)
+                                                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][b], bf, acc[t], 0, 0, 0);
+                }
+            }
+        };
+        group(0, true);
+        for (int c0 = 4; c0 < ncc; c0 += 4) group(c0, false);
+        // fp16, into the slab: lane (voxel l31, kh) holds couts 8 gq + 4 kh + e -> plane gq / 2, offset 8 (gq % 2) + 4 kh
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            const float4 bq = *(const float4*)(p.bias + co * 32 + 8 * gq + 4 * kh);
 #pragma unroll
             for (int t = 0; t < TZ; ++t) {
                 union {
                     uint2 u;
                     __half h[4];
                 } pk;
-                pk.h[0] = __float2half_rn(acc[t][gq * 4 + 0] + bq.x);
-                pk.h[1] = __float2half_rn(acc[t][gq * 4 + 1] + bq.y);
-                pk.h[2] = __float2half_rn(acc[t][gq * 4 + 2] + bq.z);
-                pk.h[3] = __float2half_rn(acc[t][gq * 4 + 3] + bq.w);
+                pk.h[0] = __float2half_rn(acc[t][gq * 4 + 0] + biasv[gq * 4 + 0]);
+                pk.h[1] = __float2half_rn(acc[t][gq * 4 + 1] + biasv[gq * 4 + 1]);
+                pk.h[2] = __float2half_rn(acc[t][gq * 4 + 2] + biasv[gq * 4 + 2]);
+                pk.h[3] = __float2half_rn(acc[t][gq * 4 + 3] + biasv[gq * 4 + 3]);
                 *(uint2*)(slab + ((gq >> 1) * 32 * TZ + l31 * TZ + t) * 32 + (8 * (gq & 1) + 4 * kh) * 2) = pk.u;
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const size_t toff = ((size_t)tx * Ho + ty) * Wo;
+        const size_t poff = ((size_t)(co * 2) * ovox + ((size_t)tx * Ho + ty) * Wo) * 32;  // uniform; plane pl adds ovox * 32
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int k = 0; k < TZ; ++k) {
                 const int piece = lane + 64 * k;
                 const uint4 d = *(const uint4*)(slab + pl * 32 * TZ * 32 + piece * 16);
-                if (ovalid[k] && !(p.dbg & 1))
-                    *(uint4*)(p.out + ((onn[k] * (p.Cout / 16) + co * 2 + pl) * ovox + ospat[k] + toff) * 16 + 8 * (piece & 1)) = d;
+                if (ovalid[k]) *(uint4*)(optr[k] + poff + (size_t)pl * ovox * 32) = d;
             }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1095,12 +1159,10 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
                       const __half* wpk, const float* bias, float slope, __half* out) {
     BOA_REQUIRE(src.C % 16 == 0 && Cout % 32 == 0, "convT: channels %d -> %d unsupported", src.C, Cout);
     ConvTArgs a;
-    a.src = src.data; a.ss = src.ss; a.Cin = src.C; a.Cout = Cout; a.N = N;
+    a.src = src.data; a.ss = src.ss; a.ss16 = src.ss16; a.Cin = src.C; a.Cout = Cout; a.N = N;
     a.Di = din[0]; a.Hi = din[1]; a.Wi = din[2]; a.s0 = s[0]; a.s1 = s[1]; a.s2 = s[2];
     a.wpk = wpk; a.bias = bias; a.out = out; a.slope = slope;
-    static const int dbg = getenv("BOA_CONVT_DBG") ? atoi(getenv("BOA_CONVT_DBG")) : 0;
-    static const int gy_mult = getenv("BOA_CONVT_GY") ? atoi(getenv("BOA_CONVT_GY")) : 2;
-    a.dbg = dbg;
+    const int gy_mult = 2;  // (8 and 32 measured slower: every y-slice re-stages the block's input voxels)
     size_t total = (size_t)N * din[0] * din[1] * din[2];
     int gx = (int)((total + 127) / 128);
     // split the (tap, cout-chunk) pairs over gridDim.y only as far as needed to fill the chip: every y-slice
