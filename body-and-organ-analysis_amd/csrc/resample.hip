@@ -59,6 +59,93 @@ __global__ __launch_bounds__(64) void k_spline_filter_axis(double* __restrict__ 
     for (int i = n - 2; i >= 0; --i) p[i * st] = z * (p[(size_t)(i + 1) * st] - p[i * st]);
 }
 
+// The same filter for lines along the CONTIGUOUS axis (element stride 1): one thread per line again, but every lane moves its
+// line in 64-byte pieces (8 doubles = one full cache line per access) and runs the recursions on registers.  With one 8-byte
+// access per step (above) neighbouring lanes touch addresses a whole line apart, every 64-byte line is fetched up to eight
+// times and each step waits for memory: 13 ms for a 536^3 volume against ~2 ms for the other two axes.  The arithmetic is the
+// same sequence of fp64 operations (the scaled value p[i] * gain is recomputed where the in-place version re-read it: the same
+// double), so the results are bit-identical.
+__global__ __launch_bounds__(64) void k_spline_filter_contig(double* __restrict__ c, int n, int n1, size_t st1, int n2, size_t st2,
+                                                             SplineConsts k) {
+    const size_t line = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (line >= (size_t)n1 * n2) return;
+    double* p = c + (line / n2) * st1 + (line % n2) * st2;
+    const double z = k.z, gain = k.gain, z_n = k.z_n;
+    const int nc = n / 8;  // whole 8-element pieces
+    // ---- causal initialisation: acc = p0 + z_n p[n-1] + sum_{i>=1} z^i (p[i] + z_n p[n-1-i]), all p scaled by gain
+    const double c0 = p[0] * gain;
+    double acc = c0 + z_n * (p[n - 1] * gain);
+    double z_i = z;
+    for (int cb = 0; cb < nc; ++cb) {
+        double f[8], b[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] = p[8 * cb + m];
+        const int b0 = n - 8 * cb - 8;  // b[m] = p[b0 + m] <-> i = 8 cb + 7 - m
+#pragma unroll
+        for (int m = 0; m < 8; ++m) b[m] = p[b0 + m];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int i = 8 * cb + m;
+            if (i >= 1) {
+                acc += z_i * (f[m] * gain + z_n * (b[7 - m] * gain));
+                z_i *= z;
+            }
+        }
+    }
+    for (int i = max(8 * nc, 1); i < n; ++i) {
+        acc += z_i * (p[i] * gain + z_n * (p[n - 1 - i] * gain));
+        z_i *= z;
+    }
+    acc *= k.init_scale;
+    acc += c0;
+    // ---- causal pass: p[0] = acc, p[i] = gain p[i] + z p[i-1]
+    double prev = acc;
+    for (int cb = 0; cb < nc; ++cb) {
+        double f[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] = p[8 * cb + m];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (8 * cb + m >= 1) {
+                double s = f[m] * gain;
+                s += z * prev;
+                prev = s;
+            }
+            f[m] = prev;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) p[8 * cb + m] = f[m];
+    }
+    for (int i = 8 * nc; i < n; ++i) {
+        if (i >= 1) {
+            double s = p[i] * gain;
+            s += z * prev;
+            prev = s;
+        }
+        p[i] = prev;
+    }
+    // ---- anticausal pass: p[n-1] *= tail_scale, p[i] = z (p[i+1] - p[i])
+    double nxt = p[n - 1] * k.tail_scale;
+    p[n - 1] = nxt;
+    int i = n - 2;
+    for (; i >= 0 && ((i + 1) & 7) != 0; --i) {  // down to an 8-aligned piece boundary
+        nxt = z * (nxt - p[i]);
+        p[i] = nxt;
+    }
+    for (; i >= 7; i -= 8) {  // pieces [i - 7, i]
+        double f[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] = p[i - 7 + m];
+#pragma unroll
+        for (int m = 7; m >= 0; --m) {
+            nxt = z * (nxt - f[m]);
+            f[m] = nxt;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) p[i - 7 + m] = f[m];
+    }
+}
+
 __device__ __forceinline__ void cubic_weights(double cc, int* start, double w[4]) {
     const double fl = floor(cc);
     const double x = cc - fl;
@@ -155,8 +242,8 @@ extern "C" int boa_resample_cubic(boa_ctx* c, const void* dev_in, int in_dtype, 
                        (size_t)PY * PZ, PY, (size_t)PZ, PZ, (size_t)1, spline_consts(PX));
     hipLaunchKernelGGL(k_spline_filter_axis, dim3((unsigned)(((size_t)PX * PZ + 63) / 64)), dim3(64), 0, c->stream, coef, PY,
                        (size_t)PZ, PX, (size_t)PY * PZ, PZ, (size_t)1, spline_consts(PY));
-    hipLaunchKernelGGL(k_spline_filter_axis, dim3((unsigned)(((size_t)PX * PY + 63) / 64)), dim3(64), 0, c->stream, coef, PZ,
-                       (size_t)1, PX, (size_t)PY * PZ, PY, (size_t)PZ, spline_consts(PZ));
+    hipLaunchKernelGGL(k_spline_filter_contig, dim3((unsigned)(((size_t)PX * PY + 63) / 64)), dim3(64), 0, c->stream, coef, PZ, PX,
+                       (size_t)PY * PZ, PY, (size_t)PZ, spline_consts(PZ));
     const size_t on = (size_t)out_dims[0] * out_dims[1] * out_dims[2];
     hipLaunchKernelGGL(k_zoom_cubic, dim3((unsigned)((on + 255) / 256)), dim3(256), 0, c->stream, coef, X, Y, Z, out_dims[0],
                        out_dims[1], out_dims[2], zoom_factor(X, out_dims[0]), zoom_factor(Y, out_dims[1]),
@@ -421,8 +508,8 @@ extern "C" int boa_resize_skimage_f32(boa_ctx* c, const float* dev_in, const int
         hipLaunchKernelGGL(k_spline_filter_axis, dim3((unsigned)(((size_t)ra.P[0] * ra.P[2] + 63) / 64)), dim3(64), 0, c->stream, coef, ra.P[1],
                            s1, ra.P[0], s0, ra.P[2], s2, spline_consts(ra.P[1]));
     if (ra.act[2])
-        hipLaunchKernelGGL(k_spline_filter_axis, dim3((unsigned)(((size_t)ra.P[0] * ra.P[1] + 63) / 64)), dim3(64), 0, c->stream, coef, ra.P[2],
-                           s2, ra.P[0], s0, ra.P[1], s1, spline_consts(ra.P[2]));
+        hipLaunchKernelGGL(k_spline_filter_contig, dim3((unsigned)(((size_t)ra.P[0] * ra.P[1] + 63) / 64)), dim3(64), 0, c->stream, coef,
+                           ra.P[2], ra.P[0], s0, ra.P[1], s1, spline_consts(ra.P[2]));
     const size_t on = (size_t)out_dims[0] * out_dims[1] * out_dims[2];
     hipLaunchKernelGGL(k_resize_cubic_f32, dim3((unsigned)((on + 255) / 256)), dim3(256), 0, c->stream, coef, ra, mm, dev_out);
     t.stop();
