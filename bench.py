@@ -47,7 +47,7 @@ PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_512.json")
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, nargs="+", default=[512])
     ap.add_argument("--batch", type=int, default=8, help="tiles per conv-stack launch")
@@ -333,8 +333,11 @@ def main():
     ctx.prof_enable(not args.no_prof)
     barrier()
     t_start = time.perf_counter()
+    step_s = []
     for _ in range(args.steps):
-        meas, bca_js, _ = step(d_ct)
+        t_s = time.perf_counter()
+        meas, bca_js, _ = step(d_ct)     # (a step ends with the download of its last table: it has completed on the device)
+        step_s.append(time.perf_counter() - t_s)
     barrier()
     elapsed = time.perf_counter() - t_start
     ctx.prof_enable(False)
@@ -353,6 +356,15 @@ def main():
             print(f"bench.py: {ranks_seen} ranks answered the all-reduce, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(2)
 
+    total_only = None
+    if rank == 0 and args.models == "total+bca" and args.gpus == 1 and not args.no_h2h:
+        # the `total` half alone (configs[1] as round 1 reported it), outside the timed region: 2 volumes
+        ctx.sync()
+        tb = time.perf_counter()
+        for _ in range(2):
+            total_task.predict_image(d_ct, affine, return_device=True).free()
+        ctx.sync()
+        total_only = {"volumes_per_s": 2.0 / (time.perf_counter() - tb), "steps": 2, "tile_forwards_per_volume": 625}
     h2h = None
     if rank == 0 and not args.no_h2h and args.gpus == 1:
         # PCIe-inclusive: upload the CT, download `total` + the three BCA label volumes (tables are host dicts already)
@@ -411,6 +423,8 @@ def main():
                                "ms": prof[k]["ms"], "launches": prof[k]["launches"]}
                            for k in ("head_accum", "finalize_argmax", "convT_mfma", "conv_first") if prof[k]["launches"]},
             "kernel_variants": counters,
+            "median_ms_per_step": float(np.median(step_s)) * 1e3,
+            "total_only": total_only,
             "host_to_host": h2h,
             "tables": {"total_labels_present": int(sum(1 for v in meas["segmentations"]["total"].values() if v.get("present"))) if meas else None,
                        "bca_aggregated_groups": len(bca_js.get("aggregated", {})) if bca_js else None},
