@@ -331,9 +331,10 @@ def postprocess_region_segmentation_device(ctx: Context, d_seg: DeviceBuffer, sh
     def run(mode, vals):
         v = (C.c_int * 3)(*vals)
         check(ctx.lib.boa_label_select(ctx.h, d_seg.vp, n, mode, v, d_mask.vp))
-        check(ctx.lib.boa_ccl26(ctx.h, d_mask.vp, shape[0], shape[1], shape[2], d_roots.vp, d_sizes.vp, C.byref(ncomp)))
-        if ncomp.value > 1:
-            check(ctx.lib.boa_ccl_filter_largest(ctx.h, d_roots.vp, d_sizes.vp, n, d_seg.vp, 255))
+        # (no component count back to the host: boa_ccl_filter_largest is a no-op for <= 1 component, and the chain stays
+        #  free of host round trips)
+        check(ctx.lib.boa_ccl26(ctx.h, d_mask.vp, shape[0], shape[1], shape[2], d_roots.vp, d_sizes.vp, None))
+        check(ctx.lib.boa_ccl_filter_largest(ctx.h, d_roots.vp, d_sizes.vp, n, d_seg.vp, 255))
 
     try:
         run(1, (0, 0, 0))
@@ -466,12 +467,12 @@ def postprocess_part_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shap
             check(ctx.lib.boa_label_select(ctx.h, d_seg.vp, n, 0, v, d_mask.vp))
             _fill_holes_2d_cropped(ctx, d_mask, shape, d_roots, d_tmp, d_box, d_fill)
             # small foreground objects
-            check(ctx.lib.boa_ccl26(ctx.h, d_fill.vp, Z, Y, X, d_roots.vp, d_sizes.vp, C.byref(ncomp)))
+            check(ctx.lib.boa_ccl26(ctx.h, d_fill.vp, Z, Y, X, d_roots.vp, d_sizes.vp, None))
             check(ctx.lib.boa_ccl_remove_small(ctx.h, d_roots.vp, d_sizes.vp, n, threshold - 1, d_fill.vp))
             # small holes: the same on the inverted mask
             zero = (C.c_int * 3)(0, 0, 0)
             check(ctx.lib.boa_label_select(ctx.h, d_fill.vp, n, 0, zero, d_mask.vp))       # d_mask = ~filled
-            check(ctx.lib.boa_ccl26(ctx.h, d_mask.vp, Z, Y, X, d_roots.vp, d_sizes.vp, C.byref(ncomp)))
+            check(ctx.lib.boa_ccl26(ctx.h, d_mask.vp, Z, Y, X, d_roots.vp, d_sizes.vp, None))
             check(ctx.lib.boa_ccl_remove_small(ctx.h, d_roots.vp, d_sizes.vp, n, threshold - 1, d_mask.vp))
             check(ctx.lib.boa_mask_assign(ctx.h, d_mask.vp, n, 1, int(label), d_out.vp))   # out[~d_mask] = label
         return d_out

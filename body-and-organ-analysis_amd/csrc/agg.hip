@@ -891,8 +891,10 @@ extern "C" int boa_ccl26(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int 
     BOA_REQUIRE(c && dev_mask && dev_roots && dev_sizes && Z > 0 && Y > 0 && X > 0, "boa_ccl26: bad argument");
     const size_t n = (size_t)Z * Y * X;
     BOA_REQUIRE(n < (1ull << 31), "boa_ccl26: volume too large for int32 indices");
+    // the component counter: a pooled 4-byte block; without host_n_components nothing is copied back and the call does not
+    // synchronise (the BCA post-processing chains 16 of these per volume)
     int* d_count = nullptr;
-    BOA_HIP_TRY(hipMalloc(&d_count, sizeof(int)));
+    BOA_TRY(boa_malloc(c, sizeof(int), (void**)&d_count));
     BOA_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
     static const bool flat = getenv("BOA_CCL_FLAT") != nullptr;  // the one-level version (A/B switch)
     if (flat) BOA_HIP_TRY(hipMemsetAsync(dev_sizes, 0, n * sizeof(uint32_t), c->stream));
@@ -912,13 +914,15 @@ extern "C" int boa_ccl26(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int 
         hipLaunchKernelGGL(k_ccl_resolve, dim3(grid), dim3(256), 0, c->stream, n, dev_roots, dev_sizes, d_count);
     }
     t.stop();
-    int cnt = 0;
-    hipError_t e = hipMemcpyAsync(&cnt, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_count);
+    hipError_t e = hipGetLastError();
+    if (host_n_components && e == hipSuccess) {
+        int cnt = 0;
+        e = hipMemcpyAsync(&cnt, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        *host_n_components = cnt;
+    }
+    boa_free(c, d_count);  // (stream-ordered: the block is reused only by work queued after the kernels above)
     BOA_HIP_TRY(e);
-    BOA_HIP_TRY(hipGetLastError());
-    if (host_n_components) *host_n_components = cnt;
     return BOA_OK;
 }
 
@@ -957,16 +961,15 @@ extern "C" int boa_ccl_filter_largest(boa_ctx* c, const int32_t* dev_roots, cons
     BOA_REQUIRE(c && dev_roots && dev_sizes && dev_seg, "boa_ccl_filter_largest: NULL argument");
     if (n == 0) return BOA_OK;
     unsigned long long* d_best = nullptr;
-    BOA_HIP_TRY(hipMalloc(&d_best, sizeof(unsigned long long)));
+    BOA_TRY(boa_malloc(c, sizeof(unsigned long long), (void**)&d_best));   // (pooled: no synchronisation around the two kernels)
     BOA_HIP_TRY(hipMemsetAsync(d_best, 0, sizeof(unsigned long long), c->stream));
     unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_ccl_best, dim3(std::min<unsigned>(grid, (unsigned)c->cu_count * 8)), dim3(256), 0, c->stream, dev_sizes, n, d_best);
     hipLaunchKernelGGL(k_ccl_apply_largest, dim3(grid), dim3(256), 0, c->stream, dev_roots, n, d_best, dev_seg,
                        fill_value);
-    hipError_t e = hipStreamSynchronize(c->stream);
-    hipFree(d_best);
+    hipError_t e = hipGetLastError();
+    boa_free(c, d_best);
     BOA_HIP_TRY(e);
-    BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
 }
 
