@@ -356,6 +356,16 @@ def main():
             print(f"bench.py: {ranks_seen} ranks answered the all-reduce, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(2)
 
+    # what the matrix cores of this very GPU sustain with no memory traffic at all (outside the timed region, ~50 ms): the part
+    # is power-limited under matrix load and the clock it holds depends on the operand bits
+    attainable = None
+    if rank == 0:
+        try:
+            attainable = {"pure_mfma_constant_operands_TFLOPs": ctx.mfma_peak(False), "pure_mfma_random_operands_TFLOPs": ctx.mfma_peak(True),
+                          "note": "v_mfma_f32_32x32x16_f16 only, one wave per SIMD, 4 accumulator chains, no LDS / memory traffic; "
+                                  "synthetic weights and a noise phantom are random-operand data"}
+        except Exception as e:  # diagnostics only
+            attainable = {"error": f"{type(e).__name__}: {e}"}
     total_only = None
     if rank == 0 and args.models == "total+bca" and args.gpus == 1 and not args.no_h2h:
         # the `total` half alone (configs[1] as round 1 reported it), outside the timed region: 2 volumes
@@ -413,7 +423,10 @@ def main():
                          "launches": conv["launches"], "avg_launch_ms": conv_ms / max(conv["launches"], 1),
                          "flops_per_launch": conv["flops"] / max(conv["launches"], 1),
                          "bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
-                         "share_of_kernel_time": conv_ms / max(total_ms, 1e-9)},
+                         "share_of_kernel_time": conv_ms / max(total_ms, 1e-9),
+                         "attainable": attainable,
+                         "frac_of_attainable_random_operands": (achieved / attainable["pure_mfma_random_operands_TFLOPs"]
+                                                                if attainable and "error" not in attainable else None)},
             "end_to_end_tflops": flops_per_volume * n_vol / elapsed / 1e12,
             # the HBM-bound stages of the same run (algorithmic bytes / event time against 8 TB/s): BASELINE.json's "% HBM roofline"
             "hbm_stages": {k: {"achieved_GBps": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6,

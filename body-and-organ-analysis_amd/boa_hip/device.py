@@ -106,6 +106,13 @@ class Context:
         self._children = weakref.WeakSet()  # objects holding device state (predictors) closed before the context
         _LIVE.add(self)
 
+    def mfma_peak(self, random_operands: bool = True, iters: int = 20000) -> float:
+        """TFLOP/s a pure v_mfma_f32_32x32x16_f16 loop sustains on this GPU (no memory traffic): the attainable ceiling of the
+        matrix cores under power, near-constant or random operand bits (`boa_mfma_peak`)."""
+        out = C.c_double()
+        check(self.lib.boa_mfma_peak(self.h, 1 if random_operands else 0, int(iters), C.byref(out)), "boa_mfma_peak")
+        return float(out.value)
+
     def register(self, obj):
         self._children.add(obj)
 

@@ -11,7 +11,7 @@ OUT=${TMPDIR:-/tmp}/boa_asan
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -I$ROOT/include -I$SRC -Wno-pass-failed -Wno-unused-value -Wno-option-ignored -fsanitize=address -fno-omit-frame-pointer"
 pids=""
-for f in api seg conv conv_ws net net_f32 agg resample morph; do
+for f in api seg conv conv_ws net net_f32 agg resample morph diag; do
   /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OUT/$f.o &
   pids="$pids $!"
 done
