@@ -106,7 +106,7 @@ class Context:
         self._children = weakref.WeakSet()  # objects holding device state (predictors) closed before the context
         _LIVE.add(self)
 
-    def mfma_peak(self, random_operands: bool = True, iters: int = 20000) -> float:
+    def mfma_peak(self, random_operands: bool = True, iters: int = 40000) -> float:
         """TFLOP/s a pure v_mfma_f32_32x32x16_f16 loop sustains on this GPU (no memory traffic): the attainable ceiling of the
         matrix cores under power, near-constant or random operand bits (`boa_mfma_peak`)."""
         out = C.c_double()

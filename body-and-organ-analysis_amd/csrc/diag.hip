@@ -52,7 +52,7 @@ extern "C" int boa_mfma_peak(boa_ctx* c, int random_operands, int iters, double*
         else
             hipLaunchKernelGGL(k_mfma_peak<false>, dim3(blocks), dim3(threads), 0, c->stream, d, n);
     };
-    launch(iters);  // settle the clock
+    for (int w = 0; w < 4; ++w) launch(iters);  // let the power management settle (tens of milliseconds) before timing
     hipEventRecord(e0, c->stream);
     launch(iters);
     hipEventRecord(e1, c->stream);

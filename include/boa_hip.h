@@ -57,8 +57,8 @@ int boa_free(boa_ctx* ctx, void* dev);
 int boa_trim(boa_ctx* ctx);
 /* Diagnostics (not on the data path): the rate a pure v_mfma_f32_32x32x16_f16 loop sustains on this GPU -- no memory, no LDS,
  * one wave per SIMD with 4 independent accumulator chains -- with near-constant operands (random_operands = 0) or operands whose
- * bits differ per lane and element (1).  The part is power-limited under matrix load: the second figure (~1.5 PFLOP/s measured,
- * against 2.3 for the first and 2.5 on the data sheet) is the ceiling a conv on real activations can be priced against. */
+ * bits differ per lane and element (1).  The part is power-limited under matrix load: the second figure (1.5-1.7 PFLOP/s measured,
+ * against 2.3-2.5 for the first and 2.5 on the data sheet) is the ceiling a conv on real activations can be priced against. */
 int boa_mfma_peak(boa_ctx* ctx, int random_operands, int iters, double* tflops_out);
 int boa_memset(boa_ctx* ctx, void* dev, int value, size_t bytes);
 int boa_h2d(boa_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);   /* synchronous */
