@@ -488,13 +488,42 @@ def g13_nnunet_resampling():
     save_npz("g13_nnunet_resampling.npz", **out)
 
 
+def g14_overview():
+    """BCA/report/plots/check.py create_equidistant_overview (five slices: HU window + colour overlay at 25 % opacity) with the
+    reference's own apply_hu_window / blend_overlay (BCA/report/plots/overlay.py).  SimpleITK is absent: its two calls here are
+    `GetArrayViewFromImage`, which returns the (z,y,x) array of the image -- the harness hands the arrays over directly."""
+    import SimpleITK as sitk  # the stub
+    from body_composition_analysis.report.plots import check
+    sitk.GetArrayViewFromImage = lambda a: a
+    check.sitk.GetArrayViewFromImage = lambda a: a
+    rng = np.random.default_rng(14)
+    out = {}
+    for i, shape in enumerate([(11, 20, 24), (2, 9, 7), (37, 16, 16)]):
+        img = rng.integers(-1100, 1600, size=shape).astype(np.int16)
+        segs, cmaps = [], []
+        for k, nlab in enumerate((5, 12)):
+            seg = (rng.integers(0, nlab, size=shape) * (rng.random(shape) < 0.6)).astype(np.uint8)
+            cmap = {l: tuple(int(v) for v in rng.integers(0, 256, 3)) for l in range(nlab)}
+            cmap[0] = (0, 0, 0)
+            segs.append(seg)
+            cmaps.append(np.array([cmap[l] for l in range(nlab)], dtype=np.uint8))
+        res = check.create_equidistant_overview(img, [(s, [tuple(c) for c in cm]) for s, cm in zip(segs, cmaps)])
+        out[f"c{i}_img"] = img
+        for k in range(2):
+            out[f"c{i}_seg{k}"] = segs[k]
+            out[f"c{i}_cmap{k}"] = cmaps[k]
+        out[f"c{i}_names"] = np.array([r[0] for r in res])
+        out[f"c{i}_out"] = np.stack([np.stack(r[1:]) for r in res])      # [5 slices][2 segmentations][Y][X][3] float64
+    save_npz("g14_overview.npz", **out)
+
+
 if __name__ == "__main__":
     ct = load_example_ct()
     print("example ct", ct.shape, ct.dtype, ct.min(), ct.max())
     only = sys.argv[1:]
     fns = dict(g1=g1_steps, g2=g2_gaussian, g3=g3_sliding_window, g3b=g3b_fold_ensemble, g4=lambda: g4_ctnorm(ct),
                g5=lambda: g5_resample(ct), g67=g67_argmax_merge, g10=g10_config, g9=g9_measurements, g8=g8_bca,
-               g11=g11_measurement_label_maps, g12=g12_cropping, g13=g13_nnunet_resampling)
+               g11=g11_measurement_label_maps, g12=g12_cropping, g13=g13_nnunet_resampling, g14=g14_overview)
     for k, f in fns.items():
         if not only or k in only:
             f()

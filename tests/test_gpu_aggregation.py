@@ -336,3 +336,34 @@ def test_tissue_projections_match_numpy(ctx):
         m = tissues == v
         np.testing.assert_array_equal(cor[t], m.sum(axis=1))
         np.testing.assert_array_equal(sag[t], m.sum(axis=2))
+
+
+def test_overview_and_l3_axes_on_resident_volumes(ctx):
+    """report.create_equidistant_overview / major_minor_axis with the volumes resident on the device: the five slices and the
+    middle L3 slice are gathered on the device; results equal golden G14 / the oracle."""
+    from boa_hip import report
+    from boa_hip.devarray import DevArray
+    from oracle import report as orep
+    z = np.load(os.path.join(GOLDEN, "g14_overview.npz"))
+    for i in range(3):
+        d_img = DevArray.from_numpy(ctx, z[f"c{i}_img"])
+        d_segs = [(DevArray.from_numpy(ctx, z[f"c{i}_seg{k}"]), z[f"c{i}_cmap{k}"]) for k in range(2)]
+        got = report.create_equidistant_overview(d_img, d_segs)
+        for s_i, row in enumerate(got):
+            for k in range(2):
+                np.testing.assert_array_equal(row[1 + k], z[f"c{i}_out"][s_i, k])
+        d_img.free()
+        for d, _ in d_segs:
+            d.free()
+    # L3 axes: an elliptic body, vertebra L3 (label 27 here) on slices 9..14
+    zz, yy, xx = np.mgrid[:24, :96, :128]
+    body = (((xx - 64) / 50.0) ** 2 + ((yy - 48) / 30.0) ** 2 <= 1.0).astype(np.uint8)
+    total = np.zeros(body.shape, np.uint8)
+    total[9:15, 40:56, 56:72] = 27
+    want = orep.major_minor_axis(total == 27, body == 1, (0.8, 0.8))
+    d_t, d_b = DevArray.from_numpy(ctx, total), DevArray.from_numpy(ctx, body)
+    got = report.major_minor_axis(ctx, d_t, d_b, 27, (0.8, 0.8))
+    assert got == want and abs(got[0] - 100 * 0.8) <= 2.0 and abs(got[1] - 60 * 0.8) <= 2.0, (got, want)
+    assert report.major_minor_axis(ctx, d_t, d_b, 99, (0.8, 0.8)) == (None, None)
+    d_t.free()
+    d_b.free()

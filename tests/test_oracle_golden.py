@@ -236,3 +236,39 @@ def test_skimage_resize_restatement_matches_scipy_grid_mode():
         d = rng.standard_normal(shp) * 50
         for order in (1, 3):
             np.testing.assert_array_equal(nnr.skimage_resize_explicit(d, osh, order), nnr.skimage_resize(d, osh, order))
+
+
+def test_g14_equidistant_overview():
+    """create_equidistant_overview (check.py:10-36) as the reference computed it: oracle and the product's host path, exact."""
+    from boa_hip import report
+    from oracle import report as orep
+    z = np.load(os.path.join(GOLDEN, "g14_overview.npz"))
+    for i in range(3):
+        img = z[f"c{i}_img"]
+        segs = [(z[f"c{i}_seg{k}"], z[f"c{i}_cmap{k}"]) for k in range(2)]
+        want = z[f"c{i}_out"]
+        for impl in (orep.create_equidistant_overview, report.create_equidistant_overview):
+            got = impl(img, segs)
+            assert [r[0] for r in got] == list(z[f"c{i}_names"])
+            for s_i, row in enumerate(got):
+                for k in range(2):
+                    assert row[1 + k].dtype == np.float64
+                    np.testing.assert_array_equal(row[1 + k], want[s_i, k])
+
+
+def test_find_axes_on_an_ellipse():
+    """geometry.find_axes restated (ConvexHull + farthest points as the reference; minor end points without cv2): an axis-aligned
+    and a rotated ellipse with known axes, within 2 pixels."""
+    from boa_hip import report
+    from oracle import report as orep
+    yy, xx = np.mgrid[:160, :200]
+    for ang, a, b in ((0.0, 70.0, 40.0), (0.5, 60.0, 30.0)):
+        c, s_ = np.cos(ang), np.sin(ang)
+        u, v = (xx - 100) * c + (yy - 80) * s_, -(xx - 100) * s_ + (yy - 80) * c
+        m = (u / a) ** 2 + (v / b) ** 2 <= 1.0
+        for impl in (orep.find_axes, report.find_axes):
+            p1, p2, q1, q2 = impl(m)
+            major = np.hypot(p1[0] - p2[0], p1[1] - p2[1])
+            minor = np.hypot(q1[0] - q2[0], q1[1] - q2[1])
+            assert abs(major - 2 * a) <= 2.5 and abs(minor - 2 * b) <= 2.5, (ang, major, minor)
+        assert orep.find_axes(m) == report.find_axes(m)
