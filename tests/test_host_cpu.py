@@ -106,7 +106,8 @@ def test_every_product_module_imports():
               "boa_hip.synthetic", "boa_hip.label_maps", "boa_hip.bca", "boa_hip.measurements", "boa_hip.compute.config",
               "boa_hip.compute.constants", "boa_hip.compute.util", "boa_hip.totalseg", "boa_hip.task", "boa_hip.pipeline",
               "boa_hip.resample", "boa_hip.orientation", "boa_hip.distributed", "boa_hip.devarray", "boa_hip.nifti",
-              "boa_hip.model_store", "boa_hip.compute.inference", "boa_hip.compute.measurements"):
+              "boa_hip.model_store", "boa_hip.compute.inference", "boa_hip.compute.measurements", "boa_hip.report",
+              "boa_hip.agg_shard", "boa_hip.nnunet_resample", "boa_hip.tile_shard"):
         importlib.import_module(m)
 
 
