@@ -80,7 +80,7 @@ class BcaPipelineHip:
     """parts_model / regions_model: (ModelConfig, [weight blob per fold])."""
 
     def __init__(self, ctx: Context, parts_model: Tuple[ModelConfig, Sequence[np.ndarray]],
-                 regions_model: Tuple[ModelConfig, Sequence[np.ndarray]], fast_bca: bool = False, max_batch: int = 8):
+                 regions_model: Tuple[ModelConfig, Sequence[np.ndarray]], fast_bca: bool = False, max_batch: int = 16):
         self.ctx = ctx
         self.tasks: Dict[str, SegmentationTask] = {}
         for name, model in (("body_parts", parts_model), ("body_regions", regions_model)):

@@ -74,7 +74,7 @@ class SegmentationTask:
 
     def __init__(self, ctx: Context, task_name: str, models: Sequence[Tuple[int, ModelConfig, Sequence[np.ndarray]]],
                  resample: Optional[float] = None, resample_only_thickness: bool = False, multimodel: Optional[bool] = None,
-                 max_batch: int = 8, part_luts: Optional[Dict[int, np.ndarray]] = None, precision: Optional[str] = None):
+                 max_batch: int = 16, part_luts: Optional[Dict[int, np.ndarray]] = None, precision: Optional[str] = None):
         self.ctx = ctx
         self.task_name = task_name
         self.resample = None if resample is None else float(resample)
@@ -367,7 +367,7 @@ def remove_outside_of_mask(ctx: Context, seg: np.ndarray, mask: np.ndarray, addo
 
 
 def run_cascade_task(ctx: Context, task: str, data: np.ndarray, affine: np.ndarray, rough_models, task_models,
-                     crop_names: Sequence[str], crop_addon=(3, 3, 3), max_batch: int = 8, rough_resample: float = 6.0,
+                     crop_names: Sequence[str], crop_addon=(3, 3, 3), max_batch: int = 16, rough_resample: float = 6.0,
                      remove_outside: Optional[Sequence[str]] = None, remove_outside_dilation: Optional[float] = None) -> np.ndarray:
     """Crop-cascade task of `--models all` (TS/python_api.py:670-757): a rough `total` segmentation at 6 mm (single model
     Dataset298; 3 mm / Dataset297 with robust_crop: `rough_resample`), labels = the `total` map -> crop mask = union of the

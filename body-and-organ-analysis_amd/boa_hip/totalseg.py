@@ -24,7 +24,7 @@ class TotalSegmentatorHip(SegmentationTask):
     """Holds one HipPredictor per part model; `predict(ct_xyz, spacing)` returns the merged `total` label volume."""
 
     def __init__(self, ctx: Context, models: Sequence[Tuple[int, ModelConfig, Sequence[np.ndarray]]],
-                 step_size: float = 0.8, max_batch: int = 8, resample: float = 1.5, precision=None):
+                 step_size: float = 0.8, max_batch: int = 16, resample: float = 1.5, precision=None):
         super().__init__(ctx, "total", models, resample=resample, multimodel=True, max_batch=max_batch, precision=precision)
         if abs(step_size - self.step_size) > 1e-12:   # explicit override (the reference derives it, TS/nnunet.py:507-514)
             self.step_size = float(step_size)
