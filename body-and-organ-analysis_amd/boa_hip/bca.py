@@ -326,7 +326,6 @@ def postprocess_region_segmentation_device(ctx: Context, d_seg: DeviceBuffer, sh
     d_mask = ctx.alloc(n)
     d_roots = ctx.alloc(n * 4)
     d_sizes = ctx.alloc(n * 4)
-    ncomp = C.c_int()
 
     def run(mode, vals):
         v = (C.c_int * 3)(*vals)
@@ -459,7 +458,6 @@ def postprocess_part_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shap
     d_out = ctx.zeros(n)
     d_mask, d_fill, d_tmp, d_box = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
     d_roots, d_sizes = ctx.alloc(n * 4), ctx.alloc(n * 4)
-    ncomp = C.c_int()
     try:
         labels = np.flatnonzero(slice_label_presence(ctx, d_seg, shape).any(axis=0))
         for label in labels[labels > 0]:
