@@ -444,10 +444,11 @@ __global__ __launch_bounds__(256) void k_gather_patches(const float* __restrict_
                                                         int P1, int P2, int pad0, int pad1, int pad2, int PX, int PY, int PZ,
                                                         int flip, float* __restrict__ out) {
     const int n = blockIdx.z, ci = blockIdx.y;
-    const size_t pvol = (size_t)PX * PY * PZ;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned pvol = (unsigned)(PX * PY * PZ);  // (a padded tile is far below 2^31 voxels: 32-bit index divisions)
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= pvol) return;
-    const int z = (int)(i % PZ), y = (int)((i / PZ) % PY), x = (int)(i / ((size_t)PZ * PY));
+    const unsigned r = i / (unsigned)PZ;
+    const int z = (int)(i - r * (unsigned)PZ), x = (int)(r / (unsigned)PY), y = (int)(r - (unsigned)x * (unsigned)PY);
     const int px = x - pad0, py = y - pad1, pz = z - pad2;  // patch coordinates
     float v = 0.f;
     if (px >= 0 && px < P0 && py >= 0 && py < P1 && pz >= 0 && pz < P2) {
