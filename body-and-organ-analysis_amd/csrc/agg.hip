@@ -504,9 +504,8 @@ __global__ __launch_bounds__(256) void k_erode_axis(const unsigned char* __restr
     const size_t n = (size_t)Z * Y * X;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int x = (int)(i % X);
-    const int y = (int)((i / X) % Y);
-    const int z = (int)(i / ((size_t)X * Y));
+    int x, y, z;
+    idx3(i, Y, X, z, y, x);
     const int pos = axis == 0 ? z : (axis == 1 ? y : x);
     const int len = axis == 0 ? Z : (axis == 1 ? Y : X);
     const size_t st = axis == 0 ? (size_t)Y * X : (axis == 1 ? (size_t)X : 1);

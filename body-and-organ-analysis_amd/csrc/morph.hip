@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256) void k_copy3(const TI* __restrict__ in, long l
     const size_t n = (size_t)d0 * d1 * d2;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int o2 = (int)(i % d2), o1 = (int)((i / d2) % d1), o0 = (int)(i / ((size_t)d2 * d1));
+    int o0, o1, o2;
+    idx3(i, d1, d2, o0, o1, o2);
     const TI v = in[in_off + o0 * s0 + o1 * s1 + o2 * s2];
     out[out_off + o0 * t0 + o1 * t1 + o2 * t2] = (TO)v;  // float -> int conversions truncate like numpy astype
 }

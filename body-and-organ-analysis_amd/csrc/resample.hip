@@ -22,7 +22,9 @@ __global__ __launch_bounds__(256) void k_pad_edge_f64(const T* __restrict__ in, 
     const size_t n = (size_t)PX * PY * PZ;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    int z = (int)(i % PZ) - NPAD, y = (int)((i / PZ) % PY) - NPAD, x = (int)(i / ((size_t)PZ * PY)) - NPAD;
+    int x, y, z;
+    idx3(i, PY, PZ, x, y, z);
+    x -= NPAD; y -= NPAD; z -= NPAD;
     x = min(max(x, 0), X - 1);
     y = min(max(y, 0), Y - 1);
     z = min(max(z, 0), Z - 1);
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(256) void k_zoom_cubic(const double* __restrict__ c
     const size_t n = (size_t)OX * OY * OZ;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int oz = (int)(i % OZ), oy = (int)((i / OZ) % OY), ox = (int)(i / ((size_t)OZ * OY));
+    int ox, oy, oz;
+    idx3(i, OY, OZ, ox, oy, oz);
     const int PY = Y + 2 * NPAD, PZ = Z + 2 * NPAD;
     double wx[4], wy[4], wz[4];
     int sx, sy, sz;
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(256) void k_zoom_nearest_u8(const unsigned char* __
     const size_t n = (size_t)OX * OY * OZ;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int oz = (int)(i % OZ), oy = (int)((i / OZ) % OY), ox = (int)(i / ((size_t)OZ * OY));
+    int ox, oy, oz;
+    idx3(i, OY, OZ, ox, oy, oz);
     const int ix = min(max((int)floor((double)ox * zx + 0.5), 0), X - 1);
     const int iy = min(max((int)floor((double)oy * zy + 0.5), 0), Y - 1);
     const int iz = min(max((int)floor((double)oz * zz_ + 0.5), 0), Z - 1);
@@ -322,7 +326,9 @@ __global__ __launch_bounds__(256) void k_pad_edge_axes_f64(const float* __restri
     const size_t n = (size_t)PX * PY * PZ;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    int z = (int)(i % PZ) - pz, y = (int)((i / PZ) % PY) - py, x = (int)(i / ((size_t)PZ * PY)) - px;
+    int x, y, z;
+    idx3(i, PY, PZ, x, y, z);
+    x -= px; y -= py; z -= pz;
     x = min(max(x, 0), X - 1);
     y = min(max(y, 0), Y - 1);
     z = min(max(z, 0), Z - 1);
@@ -347,7 +353,8 @@ __global__ __launch_bounds__(256) void k_resize_cubic_f32(const double* __restri
     const size_t n = (size_t)a.O[0] * a.O[1] * a.O[2];
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int o[3] = {(int)(i / ((size_t)a.O[2] * a.O[1])), (int)((i / a.O[2]) % a.O[1]), (int)(i % a.O[2])};
+    int o[3];
+    idx3(i, a.O[1], a.O[2], o[0], o[1], o[2]);
     double w[3][4];
     int st[3], nt[3];
 #pragma unroll
@@ -400,7 +407,8 @@ __global__ __launch_bounds__(256) void k_resize_logits_argmax(LogitsResizeArgs a
     const size_t n = (size_t)a.O[0] * a.O[1] * a.O[2];
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int o[3] = {(int)(i / ((size_t)a.O[2] * a.O[1])), (int)((i / a.O[2]) % a.O[1]), (int)(i % a.O[2])};
+    int o[3];
+    idx3(i, a.O[1], a.O[2], o[0], o[1], o[2]);
     double w[3][2];
     int i0[3], i1[3], nt[3];
 #pragma unroll
