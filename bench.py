@@ -402,7 +402,9 @@ def main():
         log(f"  sum of event-timed kernel classes {total_ms:.1f} ms of {elapsed * 1e3:.1f} ms wall; kernel variants {counters}")
         n_vol = (1 if shared else args.gpus) * args.steps
         res = {
-            "metric": "CT volumes/sec (512^3 @1.5 mm, total+bca) on MI355X" if with_bca else "CT volumes/sec (512^3 @1.5 mm, total) on MI355X",
+            # (BASELINE.json's metric at the default --size 512; other sizes are development runs and say so)
+            "metric": "CT volumes/sec (%s @1.5 mm, %s) on MI355X" % ("512^3" if list(shape) == [512, 512, 512] else "x".join(str(v) for v in shape),
+                                                                     "total+bca" if with_bca else "total"),
             "value": n_vol / elapsed, "unit": "volumes/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "strong" if shared else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
