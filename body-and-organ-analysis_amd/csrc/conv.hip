@@ -634,6 +634,12 @@ struct FirstMfmaArgs {
     int nslots;
     int t0, t1, t2;  // block tiles per axis
     int vw;          // virtual workgroups per sample
+    // fused tile gather (vol != NULL): the halo is read straight out of the resident volume -- tile origin, pad_nd_image zeros,
+    // conv padding, tile overhang and the test-time flip resolved per element -- instead of from the dense `padded` copy that
+    // k_gather_patches made (one kernel and a 4.3 B / voxel round trip less per batch)
+    const float* vol;
+    const int* origins;  // [N][3]
+    int V0, V1, V2, o0, o1, o2, flip;
 };
 
 __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
@@ -723,6 +729,28 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
         const int tz = sp % p.t2;
         sp /= p.t2;
         const int ty = sp % p.t1, tx = sp / p.t1;
+        if (p.vol) {
+            // patch coordinates of the halo origin (conv padding 1) and the tile's position in the volume
+            const int bx = tx * MF0 - 1, by = ty * MF1 - 1, bz = tz * MF2 - 1;
+            const int ox = p.origins[q.n * 3 + 0] - p.o0, oy = p.origins[q.n * 3 + 1] - p.o1, oz = p.origins[q.n * 3 + 2] - p.o2;
+#pragma unroll
+            for (int j = 0; j < NPRE; ++j) {
+                const int i = min(tid + 256 * j, HV - 1);
+                const int z = i % H2, r = i / H2, y = r % H1, x = r / H1;
+                const int px = bx + x, py = by + y, pz = bz + z;
+                float v = 0.f;
+                if ((unsigned)px < (unsigned)p.P0 && (unsigned)py < (unsigned)p.P1 && (unsigned)pz < (unsigned)p.P2) {
+                    // test-time mirroring (predict_from_raw_data.py:541-557): the network sees torch.flip(tile, axes)
+                    const int qx = (p.flip & 1) ? p.P0 - 1 - px : px, qy = (p.flip & 2) ? p.P1 - 1 - py : py,
+                              qz = (p.flip & 4) ? p.P2 - 1 - pz : pz;
+                    const int vx = ox + qx, vy = oy + qy, vz = oz + qz;
+                    if ((unsigned)vx < (unsigned)p.V0 && (unsigned)vy < (unsigned)p.V1 && (unsigned)vz < (unsigned)p.V2)
+                        v = p.vol[((size_t)vx * p.V1 + vy) * p.V2 + vz];
+                }
+                pre[j] = v;
+            }
+            return;
+        }
         const float* src = p.padded + (size_t)q.n * pvol + ((size_t)(tx * MF0) * p.PY + ty * MF1) * p.PZ + tz * MF2;
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) {
@@ -847,6 +875,9 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
     const size_t pvol = (size_t)PD[0] * PD[1] * PD[2];
     const double vox = (double)N * P[0] * P[1] * P[2];
     KernelTimer tm(ctx, BOA_K_CONV_FIRST, 2.0 * vox * k[0] * k[1] * k[2] * Cin * Cout, vox * (4.0 * Cin + 2.0 * Cout));
+    static const bool fuse_gather = !(getenv("BOA_FIRST_GATHER") && atoi(getenv("BOA_FIRST_GATHER")) == 1);  // 1: separate gather kernel
+    const bool fused = fuse_gather && first_mfma_ok(Cin, P, k, Cout);
+    if (!fused)
     hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)((pvol + 255) / 256), Cin, N), dim3(256), 0, ctx->stream, volume,
                        dev_origins, V[0], V[1], V[2], vol_off ? vol_off[0] : 0, vol_off ? vol_off[1] : 0,
                        vol_off ? vol_off[2] : 0, Cin, P[0], P[1], P[2], (k[0] - 1) / 2, (k[1] - 1) / 2, (k[2] - 1) / 2, PD[0],
@@ -856,6 +887,9 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
     if (first_mfma_ok(Cin, P, k, Cout)) {
         FirstMfmaArgs m;
         m.padded = padded_scratch; m.PX = PD[0]; m.PY = PD[1]; m.PZ = PD[2];
+        m.vol = fused ? volume : nullptr; m.origins = dev_origins; m.flip = flip_mask;
+        m.V0 = V[0]; m.V1 = V[1]; m.V2 = V[2];
+        m.o0 = vol_off ? vol_off[0] : 0; m.o1 = vol_off ? vol_off[1] : 0; m.o2 = vol_off ? vol_off[2] : 0;
         m.N = N; m.P0 = P[0]; m.P1 = P[1]; m.P2 = P[2];
         m.w = w; m.bias = bias; m.out = out; m.partials = partials; m.nslots = nblk_tab;
         m.t0 = P[0] / MF0; m.t1 = P[1] / MF1; m.t2 = P[2] / MF2;
