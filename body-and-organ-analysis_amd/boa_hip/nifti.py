@@ -72,9 +72,12 @@ def best_affine(h: NiftiHeader) -> np.ndarray:
         return aff
     if h.qform_code > 0:
         return _qform(h)
-    aff = np.diag([h.pixdim[1], h.pixdim[2], h.pixdim[3], 1.0]).astype(np.float64)
+    # neither code set: nibabel's base affine (shape_zoom_affine with the Analyze / NIfTI default x_flip=True):
+    # diag(-zx, zy, zz) with the volume centre at the world origin
+    zooms = np.array([-h.pixdim[1], h.pixdim[2], h.pixdim[3]], dtype=np.float64)
+    aff = np.diag([zooms[0], zooms[1], zooms[2], 1.0])
     shape = np.array(h.dim[1:4], dtype=np.float64)
-    aff[:3, 3] = -(shape - 1) / 2.0 * np.array(h.pixdim[1:4])
+    aff[:3, 3] = -(shape - 1) / 2.0 * zooms
     return aff
 
 

@@ -517,13 +517,103 @@ def g14_overview():
     save_npz("g14_overview.npz", **out)
 
 
+# ---------------------------------------------------------------------------------------------- G15
+def _nifti_expect(raw: bytes, endian="<"):
+    """Independent field-by-field parse of a NIfTI-1 blob (offsets of the NIfTI-1.1 standard's header table) and the
+    affine / scaled data nibabel's `load(...).affine` / `.get_fdata()` documents: sform when sform_code > 0, else the
+    quaternion form when qform_code > 0; data * scl_slope + scl_inter unless slope is 0 / (1, 0)."""
+    e = endian
+    dim = struct.unpack(e + "8h", raw[40:56])
+    datatype, bitpix = struct.unpack(e + "hh", raw[70:74])
+    pixdim = struct.unpack(e + "8f", raw[76:108])
+    vox_offset, slope, inter = struct.unpack(e + "3f", raw[108:120])
+    qform_code, sform_code = struct.unpack(e + "hh", raw[252:256])
+    qb, qc, qd, qx, qy, qz = struct.unpack(e + "6f", raw[256:280])
+    srow = struct.unpack(e + "12f", raw[280:328])
+    if sform_code > 0:
+        aff = [list(srow[0:4]), list(srow[4:8]), list(srow[8:12]), [0.0, 0.0, 0.0, 1.0]]
+    elif qform_code > 0:
+        qa = max(0.0, 1.0 - (qb * qb + qc * qc + qd * qd)) ** 0.5
+        R = [[qa * qa + qb * qb - qc * qc - qd * qd, 2 * qb * qc - 2 * qa * qd, 2 * qb * qd + 2 * qa * qc],
+             [2 * qb * qc + 2 * qa * qd, qa * qa + qc * qc - qb * qb - qd * qd, 2 * qc * qd - 2 * qa * qb],
+             [2 * qb * qd - 2 * qa * qc, 2 * qc * qd + 2 * qa * qb, qa * qa + qd * qd - qc * qc - qb * qb]]
+        qfac = -1.0 if pixdim[0] < 0 else 1.0
+        z = [pixdim[1], pixdim[2], pixdim[3] * qfac]
+        aff = [[R[i][j] * z[j] for j in range(3)] + [(qx, qy, qz)[i]] for i in range(3)] + [[0.0, 0.0, 0.0, 1.0]]
+    else:
+        aff = None
+    np_dt = {2: "u1", 4: "i2", 8: "i4", 16: "f4", 64: "f8"}[datatype]
+    n = dim[1] * dim[2] * dim[3]
+    a = np.frombuffer(raw, dtype=e + np_dt, count=n, offset=int(vox_offset)).reshape(dim[3], dim[2], dim[1]).transpose(2, 1, 0)
+    a = np.ascontiguousarray(a).astype(np_dt)     # (x, y, z) = file axis order, native byte order
+    f = a.astype(np.float64)
+    if np.isfinite(slope) and slope != 0 and not (slope == 1.0 and inter == 0.0):
+        f = f * np.float64(slope) + np.float64(inter)
+    return {"shape": list(dim[1:4]), "datatype": datatype, "bitpix": bitpix, "zooms": list(pixdim[1:4]), "qform_code": qform_code,
+            "sform_code": sform_code, "affine": aff, "scl_slope": slope, "scl_inter": inter,
+            "voxels_sha256": hashlib.sha256(a.tobytes()).hexdigest(), "voxel_sum": int(a.astype(np.int64).sum()),
+            "voxel_min": float(a.min()), "voxel_max": float(a.max()),
+            "fdata_sum": float(f.sum()), "fdata_at": {"0,0,0": float(f[0, 0, 0]), "60,50,15": float(f[60, 50, 15]), "121,100,29": float(f[121, 100, 29])}}
+
+
+def nifti_variants(raw: bytes):
+    """Byte-patched variants of a NIfTI-1 blob (same patches applied by tests/test_host_cpu.py): name -> (blob, endian)."""
+    out = {"orig": (raw, "<")}
+    b = bytearray(raw)                                  # qform only: sform_code 0, a 90-degree-about-z quaternion, qfac -1
+    b[252:256] = struct.pack("<hh", 1, 0)
+    b[76:80] = struct.pack("<f", -1.0)
+    b[256:280] = struct.pack("<6f", 0.0, 0.0, 0.70710678, 10.5, -20.25, 7.0)
+    out["qform_only"] = (bytes(b), "<")
+    b = bytearray(raw)                                  # neither code set: nibabel falls back to the pixdim / centre affine
+    b[252:256] = struct.pack("<hh", 0, 0)
+    out["no_form"] = (bytes(b), "<")
+    b = bytearray(raw)                                  # rescale slope / intercept (get_fdata applies them)
+    b[112:120] = struct.pack("<ff", 2.0, -1024.0)
+    out["scaled"] = (bytes(b), "<")
+    # big-endian copy of the whole file (header fields and voxels byte-swapped)
+    hdr_fmt = "i10s18sihcB8h3f4h8f3fhBB4f2i80s24s2h3f3f12f16s4s"
+    v = struct.unpack("<" + hdr_fmt, raw[:348])
+    dim = v[7:15]
+    n = dim[1] * dim[2] * dim[3]
+    off = int(v[30])
+    vox = np.frombuffer(raw, dtype="<i2", count=n, offset=off).astype(">i2").tobytes()
+    out["big_endian"] = (struct.pack(">" + hdr_fmt, *v) + raw[348:off] + vox, ">")
+    return out
+
+
+def g15_nifti():
+    """The reference's own test volumes (NN/tests/example_data/*.nii.gz: data files, committed as fixtures) and what
+    NN/imageio/nibabel_reader_writer.py:38-99 gets from nibabel for them (shape, zooms, affine, dtype, voxels), restated field by
+    field from the NIfTI-1 standard -- nibabel itself is absent from the image (PARITY UNPINNED vs nibabel's code, pinned vs the
+    standard and vs files this repo did not write)."""
+    import shutil
+    src = os.path.join(H.EXT, "nnunetv2", "tests", "example_data")
+    exp = {}
+    for name in ("example_ct_sm.nii.gz", "example_ct_sm_T300_output.nii.gz"):
+        shutil.copyfile(os.path.join(src, name), os.path.join(HERE, "ref_" + name))
+        os.chmod(os.path.join(HERE, "ref_" + name), 0o644)
+        raw = gzip.open(os.path.join(src, name), "rb").read()
+        exp[name] = {"orig": _nifti_expect(raw)}
+        if name == "example_ct_sm.nii.gz":
+            for k, (blob, en) in nifti_variants(raw).items():
+                exp[name][k] = _nifti_expect(blob, en)
+            sh = exp[name]["no_form"]["shape"]
+            # nibabel's fallback (Nifti1Header.get_base_affine -> shape_zoom_affine(shape, zooms, x_flip=True), published
+            # behaviour): diag(-zx, zy, zz), origin at the volume centre
+            z = exp[name]["no_form"]["zooms"]
+            z = [-z[0], z[1], z[2]]
+            exp[name]["no_form"]["affine"] = [[z[0], 0, 0, -(sh[0] - 1) / 2.0 * z[0]], [0, z[1], 0, -(sh[1] - 1) / 2.0 * z[1]],
+                                              [0, 0, z[2], -(sh[2] - 1) / 2.0 * z[2]], [0, 0, 0, 1.0]]
+    save_json("g15_nifti.json", exp)
+
+
 if __name__ == "__main__":
     ct = load_example_ct()
     print("example ct", ct.shape, ct.dtype, ct.min(), ct.max())
     only = sys.argv[1:]
     fns = dict(g1=g1_steps, g2=g2_gaussian, g3=g3_sliding_window, g3b=g3b_fold_ensemble, g4=lambda: g4_ctnorm(ct),
                g5=lambda: g5_resample(ct), g67=g67_argmax_merge, g10=g10_config, g9=g9_measurements, g8=g8_bca,
-               g11=g11_measurement_label_maps, g12=g12_cropping, g13=g13_nnunet_resampling, g14=g14_overview)
+               g11=g11_measurement_label_maps, g12=g12_cropping, g13=g13_nnunet_resampling, g14=g14_overview, g15=g15_nifti)
     for k, f in fns.items():
         if not only or k in only:
             f()

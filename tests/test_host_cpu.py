@@ -197,6 +197,68 @@ def test_nifti_roundtrip_and_label_extension(tmp_path):
     assert int(h2.vox_offset) % 16 == 0
 
 
+def test_nifti_reader_on_foreign_files(tmp_path):
+    """nifti.load on files this repo did NOT write: the reference's own test volumes (NN/tests/example_data, committed as data
+    fixtures tests/golden/ref_*.nii.gz) and byte-patched variants (qform only with qfac -1, no form code, scl_slope / scl_inter,
+    big-endian) against golden G15 -- an independent field-by-field parse by tests/golden/make_golden.py.  What the reference gets
+    from nibabel for them: NN/imageio/nibabel_reader_writer.py:38-99 (shape, affine, zooms, dtype, get_fdata)."""
+    import gzip
+    import hashlib
+    import json
+    import sys
+    from boa_hip import nifti
+    sys.path.insert(0, GOLDEN)
+    exp_all = json.load(open(os.path.join(GOLDEN, "g15_nifti.json")))
+
+    def check(path, exp):
+        data, aff, h = nifti.load(path)
+        assert list(data.shape) == exp["shape"] and list(h.get_data_shape()) == exp["shape"]
+        assert h.datatype == exp["datatype"] and data.dtype.itemsize * 8 == exp["bitpix"]
+        assert data.dtype.isnative
+        np.testing.assert_array_equal(np.asarray(h.get_zooms(), dtype=np.float64), np.asarray(exp["zooms"]))
+        assert (h.qform_code, h.sform_code) == (exp["qform_code"], exp["sform_code"])
+        np.testing.assert_allclose(aff, np.asarray(exp["affine"], dtype=np.float64), rtol=0, atol=1e-12)
+        assert hashlib.sha256(np.ascontiguousarray(data).tobytes()).hexdigest() == exp["voxels_sha256"]
+        assert int(data.astype(np.int64).sum()) == exp["voxel_sum"]
+        assert float(data.min()) == exp["voxel_min"] and float(data.max()) == exp["voxel_max"]
+        f = nifti.fdata(data, h)
+        assert f.dtype == np.float64 and float(f.sum()) == exp["fdata_sum"]
+        for k, v in exp["fdata_at"].items():
+            assert float(f[tuple(int(i) for i in k.split(","))]) == v
+        assert nifti.is_scaled(h) == (exp["scl_slope"] not in (0.0, 1.0) or exp["scl_inter"] != 0.0)
+
+    for name, cases in exp_all.items():
+        check(os.path.join(GOLDEN, "ref_" + name), cases["orig"])
+    # the variants: same byte patches as the generator (offsets of the NIfTI-1 header table)
+    import struct
+    name = "example_ct_sm.nii.gz"
+    raw = gzip.open(os.path.join(GOLDEN, "ref_" + name), "rb").read()
+    patched = {}
+    b = bytearray(raw)
+    b[252:256] = struct.pack("<hh", 1, 0)
+    b[76:80] = struct.pack("<f", -1.0)
+    b[256:280] = struct.pack("<6f", 0.0, 0.0, 0.70710678, 10.5, -20.25, 7.0)
+    patched["qform_only"] = bytes(b)
+    b = bytearray(raw)
+    b[252:256] = struct.pack("<hh", 0, 0)
+    patched["no_form"] = bytes(b)
+    b = bytearray(raw)
+    b[112:120] = struct.pack("<ff", 2.0, -1024.0)
+    patched["scaled"] = bytes(b)
+    hdr_fmt = "i10s18sihcB8h3f4h8f3fhBB4f2i80s24s2h3f3f12f16s4s"
+    v = struct.unpack("<" + hdr_fmt, raw[:348])
+    n, off = v[8] * v[9] * v[10], int(v[30])
+    patched["big_endian"] = struct.pack(">" + hdr_fmt, *v) + raw[348:off] + np.frombuffer(raw, "<i2", n, off).astype(">i2").tobytes()
+    for k, blob in patched.items():
+        pth = tmp_path / (k + (".nii.gz" if k != "scaled" else ".nii"))
+        with (gzip.open(pth, "wb") if str(pth).endswith(".gz") else open(pth, "wb")) as fh:
+            fh.write(blob)
+        check(pth, exp_all[name][k])
+    # and the drop-in reader keeps the CT what the reference's pipeline sees: int16 HU with the identity scaling
+    data, aff, h = nifti.load(os.path.join(GOLDEN, "ref_" + name))
+    assert data.dtype == np.int16 and not nifti.is_scaled(h)
+
+
 def test_model_store_folder_contract(tmp_path):
     from boa_hip import model_store, plans
     pj, dj = plans.synthetic_plans(patch=(16, 16, 16), features=(8, 16), num_classes=3)
