@@ -24,7 +24,7 @@ struct ConvGeom {
 
 // tile configuration chosen on the host (see choose_conv_tile)
 struct ConvTile {
-    int variant;     // 0: k_conv_mfma (256 threads, 2 blocks/CU); 1: k_conv_ws (producer/consumer waves, persistent)
+    int variant;     // 0: k_conv_mfma (256 threads, 2 blocks/CU); 1: k_conv_ws (producer/consumer waves, persistent); 2: k_conv_ns
     int R;           // M-tiles (32 output voxels each) per (consumer) wave; block tile = 4R M-tiles
     int w[3];        // wave M-tile shape, product 32
     int b[3];        // M-tiles per block along each axis, product 4R
@@ -93,6 +93,7 @@ struct ConvArgs {
     __half* out;
     float* partials;
     float slope;
+    int ncy;                    // k_conv_ws / k_conv_ns: cout groups per spatial tile (Cout / 32 resp. ceil(Cout / 128))
     int cy_fast;                // k_conv_ws: cout chunk is the fastest tile index (halo reuse, 2-chunk inputs)
     int nslots;                 // k_conv_ws: statistics slots per (n, cout) in `partials`
     int vw;                     // k_conv_ws: virtual workgroups per sample (<= nslots / 4)
@@ -117,6 +118,11 @@ __device__ __forceinline__ uint4 norm_act8(uint4 raw, const float* sc, const flo
 }
 
 int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double flops, double bytes);
+// k_conv_ns (conv_ns.hip): consumer waves split the cout axis, weights straight from L2 (stride-2 / deep 3x3x3 layers)
+bool conv_ns_applicable(const ConvGeom& g);
+void conv_ns_tile(const ConvGeom& g, ConvTile* t);
+int conv_ns_ncy(int Cout);
+int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double flops, double bytes);
 
 // ---- fp32 "exact" mode (net_f32.hip): channels-last fp32 activations, weights [tap][Cin][Cout] fp32 -------------------
 int launch_conv_f32(boa_ctx* ctx, const float* src0, const float* ss0, int C0, const float* src1, const float* ss1, int C1, int N,

@@ -84,6 +84,10 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
     double best_cost = 1e30;
     bool found = false;
     const int force = conv_variant_override();
+    if (force < 0 && conv_ns_applicable(g)) {  // N-split kernel (conv_ns.hip): stride-2 and deep layers, fixed tile shape
+        conv_ns_tile(g, out);
+        return true;
+    }
     // wave M-tile shapes: 32 voxels = w0 x w1 x w2 (powers of two), contiguous axis as long as possible first
     // (second pass: extents so small that no wave tile fits without overhang -- e.g. a last axis of 2 -- take any shape; the
     // kernels mask the overhang)
@@ -173,6 +177,7 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
 // number of per-(n, cout) partial-statistics entries the conv kernel writes
 int conv_nblk(const ConvTile& t, int cu_count, int Cout) {
     const int spatial = t.tiles[0] * t.tiles[1] * t.tiles[2];
+    if (t.variant == 2) return conv_ws_nslots(spatial * conv_ns_ncy(Cout), cu_count);
     return t.variant == 1 ? conv_ws_nslots(spatial * (Cout / 32), cu_count) : spatial;
 }
 
@@ -396,6 +401,7 @@ int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const Con
     const double vox = (double)g.N * g.Do * g.Ho * g.Wo;
     const double flops = 2.0 * vox * taps * (s0.C + s1.C) * g.Cout;
     const double bytes = 2.0 * ((double)g.N * g.Di * g.Hi * g.Wi * (s0.C + s1.C) + vox * g.Cout);
+    if (t.variant == 2) return launch_conv_ns(ctx, a, t, flops, bytes);
     if (t.variant == 1) return launch_conv_ws(ctx, a, t, flops, bytes);
     ctx->counters[BOA_CNT_CONV_SIMPLE]++;
     KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);

@@ -1,0 +1,468 @@
+// k_conv_ns: wave-specialised persistent implicit-GEMM 3x3x3 conv whose consumer waves split the COUT axis (gfx950).
+//
+// k_conv_ws (conv_ws.hip) gives each of its four consumer waves its own voxels and ONE 32-cout chunk per staged halo: a layer
+// with Cout = 128 ... 320 stages every input halo Cout / 32 times and streams the chunk's weights through LDS for every tile.
+// That is the right trade for the full-resolution 32-channel layers and the wrong one for the stride-2 and deep layers
+// (profiles/r02_per_layer.txt: 150-400 TFLOP/s, producer / L2 bound).  Here
+//   * the block's output tile is 4 x-planes of 4 x 8 voxels (M-tile = one plane = 32 voxels) and all four consumer waves work
+//     on the SAME voxels with DIFFERENT cout chunks (cout group = 4 chunks = 128 couts per staged halo);
+//   * a wave's weight (A) fragments are therefore private to it: they go straight from global / L2 into registers (scalar
+//     base + lane offset, a ring of three (dy, dz) tap groups, prefetched two groups = 24 MFMAs ahead, across chunk and tile
+//     boundaries) -- no weight staging, no LDS space, no LDS reads for weights;
+//   * the input (B) fragments come from the LDS halo with reuse along x: per (dy, dz) group the wave reads the S * 3 + 3 input
+//     planes once and feeds 12 MFMAs (stride 1: plane j serves the outputs r = j - dx; stride 2: the planes 2 r + dx), 0.5 /
+//     0.75 KiB of LDS reads per MFMA;
+//   * producers (waves 4-7), tile sequence / virtual workgroups / run tables, deferred InstanceNorm in the staging, bias as the
+//     first MFMA's C operand, register-transpose epilogue and batch-invariant statistics are k_conv_ws's (conv_ws_dev.h).
+// tools/consumer_ns.hip is the isolated consumer loop (1.4-1.6 PFLOP/s with random operands, weights up to 5 MB from L2).
+// Instantiated for 3x3x3 kernels with stride 1 or 2 on all axes; everything else stays on k_conv_ws.
+#include <stdlib.h>
+
+#include "conv.h"
+
+#include "conv_ws_dev.h"
+
+// One 16-channel chunk: acc[r] += sum over the 27 taps.  b0p: LDS address of this lane's voxel in plane 0 of the wave's
+// M-tiles, this lane's k-half plane (halo extents are compile-time: every fragment read has an immediate offset); wb: the
+// packed weights (wave-uniform base); vcur / vnext: this lane's byte offset of (chunk, tap 0) of this and of the following
+// chunk for the wave's cout chunk (always valid: the last chunk of the last tile prefetches a dummy); gs: bytes per tap.
+// The accumulators enter a tile's first chunk holding the bias.
+template <int S, int RM>
+__device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16 (&acc)[RM], f16x8 (&a)[3][3],
+                                                const WS_GLOBAL unsigned char* wb, unsigned vcur, unsigned vnext, unsigned gs) {
+    constexpr int NB = S * (RM - 1) + 3;
+    constexpr int H1 = 3 * S + 3, H2 = 7 * S + 3;
+    f16x8 b[NB];
+    auto fetch_a = [&](unsigned vchunk, int g, int slot) {  // group g = dy * 3 + dz: taps g + 9 dx
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            unsigned vo = __umul24((unsigned)(g + 9 * dx), gs) + vchunk;
+            asm volatile("" : "+v"(vo));  // keep the 32 -> 64 bit extension in this block: scalar-base load form
+            a[slot][dx] = *(const WS_GLOBAL f16x8*)(wb + vo);
+        }
+    };
+#pragma unroll
+    for (int jj = 0; jj < NB; ++jj) b[jj] = *(const f16x8*)(b0p + (jj * H1 * H2) * 16);
+    __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        const int slot = g % 3;
+        if (g + 2 < 9)
+            fetch_a(vcur, g + 2, (g + 2) % 3);
+        else
+            fetch_a(vnext, g + 2 - 9, (g + 2) % 3);
+        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) {
+            int cnt = 0;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int rr = jj - dx;
+                if (rr < 0 || rr % S != 0 || rr / S >= RM) continue;
+                const int r = rr / S;
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[slot][dx], b[jj], acc[r], 0, 0, 0);
+                ++cnt;
+            }
+            if (cnt == 1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            else if (cnt == 2)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            else if (cnt == 3)
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            if (g + 1 < 9) {
+                const int gn = g + 1, dy = gn / 3, dz = gn % 3;
+                b[jj] = *(const f16x8*)(b0p + ((jj * H1 + dy) * H2 + dz) * 16);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    }
+}
+
+// S: conv stride (all axes); WN: consumer waves along the cout axis (cout group = WN chunks), 4 / WN wave rows along x;
+// RM: M-tiles (x-planes of 4 x 8 output voxels) per wave.  Block tile = (4 / WN) * RM planes.
+template <int S, int WN, int RM>
+__global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int l31 = lane & 31;
+    const int kh = lane >> 5;
+    const int HV = p.h0 * p.h1 * p.h2;
+    const int plane = ws_plane_bytes(HV);
+    const int ncc = (p.C0 + p.C1) / 16;
+    const int buf_bytes = 2 * plane;  // LDS: [halo buf 0][halo buf 1], each two k-octet planes
+    unsigned char* bufs = smem;
+
+    int my_tiles = 0;
+    for (int v = (int)blockIdx.x; v < p.N * p.vw; v += (int)gridDim.x) my_tiles += p.runs[(v % p.vw) * 8];
+    const int my_chunks = my_tiles * ncc;
+    for (int i = tid; i < p.Cout; i += WS_THREADS) ((float*)(smem + 2 * buf_bytes))[i] = p.bias[i];  // (ordered by the first barrier)
+
+    if (producer) {
+        // ---- producer waves: as in k_conv_ws without the weight staging (chunk g + 1 committed while the consumers work on
+        // chunk g, its global loads issued one barrier interval earlier)
+        const int q = tid - 256;
+        const ProdConst pc = prod_const(p, q, HV);
+        TileSeq pseq;
+        pseq.n = pseq.left = pseq.j = 0;
+        TileCoord& ptc = pseq.tc;
+        ptc.n = ptc.cy = ptc.ox0 = ptc.oy0 = ptc.oz0 = ptc.sp = 0;
+        ProdItems items;
+#pragma unroll
+        for (int j = 0; j < WS_MAXV; ++j) items.gi[j] = 0;
+        items.ok = 0;
+        ChunkRegs rg;
+#pragma unroll
+        for (int j = 0; j < WS_MAXV; ++j) rg.d[j] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rg.ssw[j] = 0;
+        rg.ok = rg.live = 0;
+        rg.has_ss = 0;
+        rg.skip_halo = 0;
+        int pcc = 0;
+        const bool live = !(dbg & 2);
+        if (live && my_chunks > 0) {
+            seq_first(p, pseq);
+            prod_setup(p, ptc, pc, items);
+            prod_issue(p, ptc, items, pc.in_halo, 0, false, q, dbg, rg);
+            if (++pcc == ncc) pcc = 0;
+        }
+        for (int g = -1; g < my_chunks; ++g) {
+            if (live && g + 1 < my_chunks) {
+                unsigned char* nxt = bufs + ((g + 1) & 1) * buf_bytes;
+                const bool do_issue = g + 2 < my_chunks;
+                if (do_issue && pcc == 0) {  // (before the commit: see k_conv_ws)
+                    seq_next(p, pseq);
+                    prod_setup(p, ptc, pc, items);
+                }
+                prod_commit(p, rg, nxt, q, HV, plane, dbg);
+                if (do_issue) {
+                    prod_issue(p, ptc, items, pc.in_halo, pcc, false, q, dbg, rg);
+                    if (++pcc == ncc) pcc = 0;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- consumer waves --------------------------------------------------------------------------------
+    if (!(dbg & 1024)) __builtin_amdgcn_s_setprio(3);
+    int tr_n = 0;
+    // debug timeline (BOA_WS_TRACE): consumer wave 0 of block 0; codes 1 tile start, 2 before the first chunk, 3 chunk done, 4 barrier passed
+#define NS_STAMP(code)                                                                                                   \
+    do {                                                                                                                 \
+        if (p.trace && blockIdx.x == 0 && wave == 0 && lane == 0 && tr_n < WS_TRACE_SLOTS) {                              \
+            p.trace[tr_n] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
+            ++tr_n;                                                                                                      \
+        }                                                                                                                \
+    } while (0)
+    constexpr int WM = 4 / WN;
+    const int cw = wave & 3;
+    const int wn = cw % WN, wm = cw / WN;
+    const int ly = l31 >> 3, lz = l31 & 7;
+    const int nchunks_out = p.Cout / 32;
+    // this lane's voxel in plane 0 of the wave's M-tiles, its k-half plane
+    constexpr int H1 = 3 * S + 3, H2 = 7 * S + 3;  // halo extents along y, z (host: conv_ns_tile)
+    const int hoff = (((S * (wm * RM)) * H1 + S * ly) * H2 + S * lz) * 16 + kh * plane;
+    const int srel0 = ly * p.Wo + lz;
+    const size_t out_vox = (size_t)p.Do * p.Ho * p.Wo;
+    const int nslots = p.nslots;
+    int slot = 0;
+    // InstanceNorm partial sums in the D-fragment layout (see k_conv_ws)
+    float st_s[16], st_q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
+    int st_n = -1, st_ch = 0;
+    auto flush_stats = [&]() {
+        if (st_n < 0) return;
+#define NS_HALVE(M, HALF)                                                                                \
+    {                                                                                                    \
+        const bool up = (l31 & (M)) != 0;                                                                \
+        _Pragma("unroll") for (int i = 0; i < (HALF); ++i) {                                             \
+            const float ks = up ? st_s[i + (HALF)] : st_s[i], gs_ = up ? st_s[i] : st_s[i + (HALF)];     \
+            const float kq = up ? st_q[i + (HALF)] : st_q[i], gq_ = up ? st_q[i] : st_q[i + (HALF)];     \
+            st_s[i] = ks + __shfl_xor(gs_, (M));                                                         \
+            st_q[i] = kq + __shfl_xor(gq_, (M));                                                         \
+        }                                                                                                \
+    }
+        NS_HALVE(1, 8)
+        NS_HALVE(2, 4)
+        NS_HALVE(4, 2)
+        NS_HALVE(8, 1)
+#undef NS_HALVE
+        st_s[0] += __shfl_xor(st_s[0], 16);
+        st_q[0] += __shfl_xor(st_q[0], 16);
+        if (l31 < 16) {
+            const int i = ((l31 & 1) << 3) | ((l31 & 2) << 1) | ((l31 & 4) >> 1) | ((l31 & 8) >> 3);
+            const int row = st_ch * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
+            float* pp = p.partials + (((size_t)st_n * p.Cout + row) * 2) * nslots + slot;
+            pp[0] = st_s[0];
+            pp[nslots] = st_q[0];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st_s[i] = st_q[i] = 0.f;
+    };
+
+    f32x16 acc[RM];
+    auto epilogue = [&](const TileCoord& tc, int ch) {
+        st_n = tc.n;  // (the caller flushed when the sample / cout chunk / run changed)
+        st_ch = ch;
+        const int cout0 = ch * 32;
+        const bool full = tc.ox0 + WM * RM <= p.Do && tc.oy0 + 4 <= p.Ho && tc.oz0 + 8 <= p.Wo;
+        const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + (((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * 16;
+        const unsigned olane = ((unsigned)kh * (unsigned)out_vox + (unsigned)srel0) * 32u;
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            const int mx = wm * RM + r;  // wave-uniform plane within the block tile
+            const int mrel = mx * p.Ho * p.Wo;
+            bool ok = true;
+            if (!full) ok = tc.ox0 + mx < p.Do && tc.oy0 + ly < p.Ho && tc.oz0 + lz < p.Wo;
+            const float dm = ok ? 1.f : 0.f;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[r][i];
+            // packed fp32 (v_pk_add_f32 / v_pk_fma_f32: two entries per instruction; same operations and order per entry)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f2_t vm = f2_t{v[2 * i], v[2 * i + 1]};
+                if (!full) vm = vm * f2_t{dm, dm};
+                f2_t s2 = f2_t{st_s[2 * i], st_s[2 * i + 1]}, q2 = f2_t{st_q[2 * i], st_q[2 * i + 1]};
+                s2 = s2 + vm;
+                q2 = __builtin_elementwise_fma(vm, vm, q2);
+                st_s[2 * i] = s2.x; st_s[2 * i + 1] = s2.y;
+                st_q[2 * i] = q2.x; st_q[2 * i + 1] = q2.y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned w[8];
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float lo4[4], hi4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[pr * 4 + e]), __float_as_uint(v[(pr + 2) * 4 + e]), false, false);
+                    lo4[e] = __uint_as_float(sw[0]);
+                    hi4[e] = __uint_as_float(sw[1]);
+                }
+                w[pr * 4 + 0] = cvt_pk_h2(lo4[0], lo4[1]);
+                w[pr * 4 + 1] = cvt_pk_h2(lo4[2], lo4[3]);
+                w[pr * 4 + 2] = cvt_pk_h2(hi4[0], hi4[1]);
+                w[pr * 4 + 3] = cvt_pk_h2(hi4[2], hi4[3]);
+            }
+            if (ok && !(dbg & 4)) {
+                WS_GLOBAL unsigned char* dst = sgpr_ptr(p.out + (obase + (size_t)mrel * 16));
+                unsigned ol = olane;
+                asm volatile("" : "+v"(ol));
+                *(WS_GLOBAL u32x4_t*)(dst + ol) = u32x4_t{w[0], w[1], w[2], w[3]};
+                *(WS_GLOBAL u32x4_t*)(dst + ol + 16) = u32x4_t{w[4], w[5], w[6], w[7]};
+            }
+        }
+    };
+
+    // weights: wpk [(cc * 27 + tap) * 2 + kh][Cout][8 halves]; a wave's fragment of (cc, tap, cout chunk ch): lane (kh, l31)
+    // reads 16 bytes at ((cc * 27 + tap) * 2 * Cout + kh * Cout + ch * 32 + l31) * 16
+    const unsigned gs = 32u * (unsigned)p.Cout;  // bytes per tap
+    const unsigned voff = ((unsigned)kh * (unsigned)p.Cout + (unsigned)l31) * 16u;
+    auto woff = [&](int cc, int ch) -> unsigned { return voff + (unsigned)cc * 27u * gs + (unsigned)ch * 512u; };
+    f16x8 a[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[i][j][e] = (_Float16)0.f;
+    auto prime = [&](unsigned vchunk) {  // groups 0 and 1 of a chunk into ring slots 0 and 1
+        const WS_GLOBAL unsigned char* wb = sgpr_ptr(p.wpk);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                unsigned vo = __umul24((unsigned)(g + 9 * dx), gs) + vchunk;
+                asm volatile("" : "+v"(vo));
+                a[g][dx] = *(const WS_GLOBAL f16x8*)(wb + vo);
+            }
+    };
+
+    TileSeq cseq;
+    cseq.n = cseq.left = cseq.j = 0;
+    cseq.tc.n = cseq.tc.cy = cseq.tc.ox0 = cseq.tc.oy0 = cseq.tc.oz0 = cseq.tc.sp = 0;
+    // cout group of the tile after the current one (the weight ring is prefetched across tile boundaries): within a run the
+    // group advances when the spatial index wraps (spatial tiles are the fastest index), a new run reads its table entry
+    const int nsp = p.t0 * p.t1 * p.t2;
+    auto peek_next_cy = [&]() -> int {
+        if (cseq.left > 1) return cseq.tc.sp == nsp - 1 ? (cseq.tc.cy + 1 == p.ncy ? 0 : cseq.tc.cy + 1) : cseq.tc.cy;
+        int j = cseq.j + p.vstep_j;
+        if (j >= p.vw) j -= p.vw;
+        return p.runs[j * 8 + 1];
+    };
+    bool ring_valid = false;
+    TileCoord done_tc = cseq.tc;
+    int done_ch = 0;
+    bool done_active = false;
+    __syncthreads();  // chunk 0 and the bias table staged
+    for (int k = 0; k < my_tiles + 1; ++k) {
+        const bool more = k < my_tiles;
+        bool new_run = true;
+        NS_STAMP(1);
+        if (k == 0) {
+            if (more) seq_first(p, cseq);
+        } else if (more)
+            new_run = seq_next(p, cseq);
+        const bool have_next = k + 1 < my_tiles;
+        const TileCoord& tc = cseq.tc;
+        const int ch = tc.cy * WN + wn;
+        if (k > 0 && done_active && !(dbg & 8)) epilogue(done_tc, done_ch);  // deferred: the previous tile's
+        // ONE flush site: the accumulated partial sums go to their slot when the next tile belongs to another virtual
+        // workgroup, sample or cout chunk, and at the end
+        if (k > 0 && (!more || new_run || tc.n != st_n || ch != st_ch)) {
+            flush_stats();
+            st_n = -1;
+        }
+        if (!more) break;
+        if (new_run) slot = cseq.j * 4 + cw;
+        const bool active = ch < nchunks_out;
+        // the chunk the ring is prefetched for after this tile: the next tile's (clamped to a valid chunk when this wave idles there)
+        int ch_next = have_next ? peek_next_cy() * WN + wn : ch;
+        const bool next_active = have_next && ch_next < nchunks_out;
+        if (ch_next >= nchunks_out) ch_next = nchunks_out - 1;
+        if (active) {
+            // the accumulators start at the bias: this lane's 16 biases of the cout chunk in the D-fragment layout (entry 4 gq + e
+            // <-> cout 8 gq + 4 kh + e) from the LDS copy (no bias add in the epilogue, no bias registers across the tile)
+            const float* lb = (const float*)(smem + 2 * buf_bytes) + ch * 32 + 4 * kh;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4_t bv = *(const f32x4_t*)(lb + 8 * gq);
+#pragma unroll
+                for (int r = 0; r < RM; ++r) {
+                    acc[r][gq * 4 + 0] = bv[0]; acc[r][gq * 4 + 1] = bv[1]; acc[r][gq * 4 + 2] = bv[2]; acc[r][gq * 4 + 3] = bv[3];
+                }
+            }
+            if (!ring_valid) prime(woff(0, ch));
+        }
+        NS_STAMP(2);
+        for (int cc = 0; cc < ncc; ++cc) {
+            const int g = k * ncc + cc;
+            if (active) {
+                const unsigned char* cur = bufs + (g & 1) * buf_bytes;
+                int ho = hoff;
+                asm volatile("" : "+v"(ho));
+                const WS_GLOBAL unsigned char* wb = sgpr_ptr(p.wpk);
+                const unsigned vcur = woff(cc, ch);
+                const unsigned vnext = cc + 1 < ncc ? woff(cc + 1, ch) : woff(0, ch_next);
+                consume_chunk_x<S, RM>(cur + ho, acc, a, wb, vcur, vnext, gs);
+            }
+            NS_STAMP(3);
+            __syncthreads();
+            NS_STAMP(4);
+        }
+        ring_valid = active && next_active;
+        done_tc.n = __builtin_amdgcn_readfirstlane(tc.n);
+        done_tc.cy = __builtin_amdgcn_readfirstlane(tc.cy);
+        done_tc.sp = __builtin_amdgcn_readfirstlane(tc.sp);
+        done_tc.ox0 = __builtin_amdgcn_readfirstlane(tc.ox0);
+        done_tc.oy0 = __builtin_amdgcn_readfirstlane(tc.oy0);
+        done_tc.oz0 = __builtin_amdgcn_readfirstlane(tc.oz0);
+        done_ch = __builtin_amdgcn_readfirstlane(ch);
+        done_active = active;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+const int* ws_run_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, int vw);
+int conv_ws_vw(int tiles_per_sample, int cu_count);
+
+static size_t ns_plane_host(int HV) { return ((size_t)(HV + WS_PROD / 2 - 1) / (WS_PROD / 2)) * (WS_PROD / 2) * 16 + 64; }
+
+// The layers k_conv_ns takes (a function of the layer geometry only): 3x3x3 kernels with stride 2 on all axes, at least two cout
+// chunks and an output of at least 8^3 voxels -- measured per layer against k_conv_ws on the `total` geometry (8 tiles): 32 -> 64
+// @128^3, 64 -> 128 @64^3 453 -> 194 us, 128 -> 256 @32^3 224 -> 96 us, 256 -> 320 @16^3 114 -> 81 us.  The stride-1 layers with
+// Cout >= 128 run at par with k_conv_ws (the epilogue of four M-tiles per 128-voxel tile costs what the fourfold halo reuse
+// gains) and the 8^3 / 4^3 layers are latency-bound either way; BOA_NS_ALL=1 sends them here as well (experiments).
+bool conv_ns_applicable(const ConvGeom& g) {
+    static const bool off = getenv("BOA_NO_NS") != nullptr;
+    static const bool all = getenv("BOA_NS_ALL") != nullptr;
+    if (off) return false;
+    const bool k333 = g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3;
+    const bool s1 = g.s[0] == 1 && g.s[1] == 1 && g.s[2] == 1, s2 = g.s[0] == 2 && g.s[1] == 2 && g.s[2] == 2;
+    if (!k333 || g.Cout % 32 != 0) return false;
+    if (all) return (s1 || s2) && g.Cout >= 128 && g.Do >= 2 && g.Ho >= 2 && g.Wo >= 4;
+    return s2 && g.Cout >= 64 && g.Do >= 8 && g.Ho >= 8 && g.Wo >= 8;
+}
+
+// consumer waves along the cout axis: four when the layer has four or more cout chunks, else two (Cout = 64 / 96)
+static int ns_wn(int Cout) { return Cout >= 128 ? 4 : 2; }
+
+void conv_ns_tile(const ConvGeom& g, ConvTile* t) {
+    t->variant = 2;
+    t->R = 4;
+    t->w[0] = 1; t->w[1] = 4; t->w[2] = 8;
+    t->b[0] = 4; t->b[1] = 1; t->b[2] = 1;
+    const int ext[3] = {4, 4, 8};
+    const int dims[3] = {g.Do, g.Ho, g.Wo};
+    size_t HV = 1;
+    for (int d = 0; d < 3; ++d) {
+        t->h[d] = (ext[d] - 1) * g.s[d] + 3;
+        t->tiles[d] = (dims[d] + ext[d] - 1) / ext[d];
+        HV *= (size_t)t->h[d];
+    }
+    t->lds_bytes = 4 * ns_plane_host((int)HV) + (size_t)g.Cout * sizeof(float);  // two halo buffers + the bias table
+}
+
+int conv_ns_ncy(int Cout) { return (Cout / 32 + ns_wn(Cout) - 1) / ns_wn(Cout); }
+
+template <int S, int WN, int RM>
+static void launch_ns(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int grid) {
+    static bool once = (hipFuncSetAttribute((const void*)k_conv_ns<S, WN, RM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL((k_conv_ns<S, WN, RM>), dim3(grid), dim3(WS_THREADS), t.lds_bytes, ctx->stream, a,
+                       getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0);
+}
+
+int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes) {
+    ConvArgs a = a_in;
+    a.ncy = conv_ns_ncy(a.Cout);
+    const int total = t.tiles[0] * t.tiles[1] * t.tiles[2] * a.ncy;  // tiles of one sample
+    const int vw = conv_ws_vw(total, ctx->cu_count);
+    const int grid = (int)std::min<long long>((long long)vw * a.N, ctx->cu_count);
+    BOA_REQUIRE((double)a.Di * a.Hi * a.Wi <= 16777216.0, "conv_ns: more than 2^24 input voxels per sample (24-bit offset multiply)");
+    BOA_REQUIRE((double)a.Di * a.Hi * a.Wi * std::max(a.C0, a.C1) * 2.0 < 4294967296.0,
+                "conv_ns: one sample of the input exceeds 4 GiB (32-bit voxel offsets)");
+    BOA_REQUIRE(2 * t.h[0] * t.h[1] * t.h[2] <= WS_PROD * WS_MAXV, "conv_ns: halo too large");
+    static const bool want_trace = getenv("BOA_WS_TRACE") != nullptr;
+    a.trace = nullptr;
+    if (want_trace) {
+        hipMalloc(&a.trace, WS_TRACE_SLOTS * 8);
+        hipMemsetAsync(a.trace, 0, WS_TRACE_SLOTS * 8, ctx->stream);
+    }
+    a.nslots = 4 * vw;
+    a.vw = vw;
+    a.vstep_n = grid / vw;
+    a.vstep_j = grid % vw;
+    a.cy_fast = 0;
+    a.runs = ws_run_table(ctx, a, total, vw);
+    BOA_REQUIRE(a.runs != nullptr, "conv_ns: could not allocate the run table");
+    KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);
+    ctx->counters[BOA_CNT_CONV_WS]++;
+    if (ns_wn(a.Cout) == 2) {
+        BOA_REQUIRE(a.s0 == 2, "conv_ns: the two-chunk cout group is instantiated for stride 2 only");
+        launch_ns<2, 2, 2>(ctx, a, t, grid);
+    } else if (a.s0 == 1)
+        launch_ns<1, 4, 4>(ctx, a, t, grid);
+    else
+        launch_ns<2, 4, 4>(ctx, a, t, grid);
+    tm.stop();
+    if (want_trace && a.trace) {
+        static unsigned long long host[WS_TRACE_SLOTS];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpy(host, a.trace, sizeof(host), hipMemcpyDeviceToHost);
+        hipFree(a.trace);
+        fprintf(stderr, "[ns-trace] Cin=%d Cout=%d in=%d s=%d:", a.C0 + a.C1, a.Cout, a.Di, a.s0);
+        for (int i = 1; i < 80 && host[i]; ++i)
+            fprintf(stderr, " %d:%llu", (int)(host[i] >> 56), (host[i] & 0x00ffffffffffffffull) - (host[i - 1] & 0x00ffffffffffffffull));
+        fprintf(stderr, "\n");
+    }
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
