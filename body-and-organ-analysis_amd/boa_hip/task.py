@@ -368,20 +368,21 @@ def remove_outside_of_mask(ctx: Context, seg: np.ndarray, mask: np.ndarray, addo
 
 def run_cascade_task(ctx: Context, task: str, data: np.ndarray, affine: np.ndarray, rough_models, task_models,
                      crop_names: Sequence[str], crop_addon=(3, 3, 3), max_batch: int = 16, rough_resample: float = 6.0,
-                     remove_outside: Optional[Sequence[str]] = None, remove_outside_dilation: Optional[float] = None) -> np.ndarray:
+                     remove_outside: Optional[Sequence[str]] = None, remove_outside_dilation: Optional[float] = None,
+                     precision: Optional[str] = None) -> np.ndarray:
     """Crop-cascade task of `--models all` (TS/python_api.py:670-757): a rough `total` segmentation at 6 mm (single model
     Dataset298; 3 mm / Dataset297 with robust_crop: `rough_resample`), labels = the `total` map -> crop mask = union of the
     `crop_names` structures -> the task's own model at native resolution on the cropped image -> labels on the input grid
     -> optionally cleared outside the dilated union of the `remove_outside` structures (TS/nnunet.py:711-716).
     rough_models / task_models: [(task_id, ModelConfig, [weight blob per fold])] as `model_store.load_task_models` gives."""
-    rough = SegmentationTask(ctx, "total", rough_models, resample=rough_resample, multimodel=False, max_batch=max_batch)
+    rough = SegmentationTask(ctx, "total", rough_models, resample=rough_resample, multimodel=False, max_batch=max_batch, precision=precision)
     try:
         organ_seg = rough.predict_image(data, affine)
     finally:
         rough.close()
     inv = label_maps.CLASS_MAP_TOTAL_INV
     crop_mask = np.isin(organ_seg, [inv[n] for n in crop_names]).astype(np.uint8)
-    t = SegmentationTask(ctx, task, task_models, resample=None, multimodel=False, max_batch=max_batch)
+    t = SegmentationTask(ctx, task, task_models, resample=None, multimodel=False, max_batch=max_batch, precision=precision)
     try:
         seg = t.predict_image(data, affine, crop_mask=crop_mask, crop_addon=crop_addon)
     finally:

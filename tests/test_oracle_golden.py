@@ -180,12 +180,15 @@ def test_g12_cropping_helpers():
     """TS get_bbox_from_mask / crop_to_bbox and nnU-Net's create_nonzero_mask, executed from the reference (G12): the
     oracle's `nonzero_bbox` and the product's host helpers (`task.get_bbox_from_mask`, `task.nonzero_bbox`) agree."""
     from boa_hip import task
+    from oracle import cascade as ocas
     z = _npz("g12_cropping.npz")
     n_c, n_n = (int(v) for v in z["n_cases"])
     for i in range(n_c):
         m, ov, addon = z[f"c{i}_mask"], int(z[f"c{i}_outside"]), [int(v) for v in z[f"c{i}_addon"]]
         bbox = task.get_bbox_from_mask(m, outside_value=ov, addon=addon)
         assert bbox == z[f"c{i}_bbox"].tolist(), i
+        assert ocas.get_bbox_from_mask(m, outside_value=ov, addon=addon) == bbox, i        # the cascade oracle's restatement
+        np.testing.assert_array_equal(ocas.undo_crop(z[f"c{i}_crop"], m.shape, bbox)[tuple(slice(a, b) for a, b in bbox)], z[f"c{i}_crop"])
         sl = tuple(slice(a, b) for a, b in bbox)
         np.testing.assert_array_equal(z[f"c{i}_img"][sl], z[f"c{i}_crop"])
     for j in range(n_n):
