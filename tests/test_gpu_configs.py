@@ -55,7 +55,7 @@ def test_config0_total_fast_128_dropin_vs_oracle(tmp_path, monkeypatch):
     want = opipe.predict_image(ct, (1.5, 1.5, 1.5), [omodel], None, "total", 3.0, multimodel=False)
     agree = float((got == want).mean())
     print("configs[0] total_fast 128^3 label agreement with the oracle pipeline", agree, "labels", len(np.unique(got)))
-    assert agree >= 0.99            # 118 classes of a random-weight fp16 net; every other step is exact
+    assert agree >= 0.993   # measured 0.9964;           # 118 classes of a random-weight fp16 net; every other step is exact
     # the same call in exact mode ($BOA_NET_PRECISION=fp32: the reference's CPU arithmetic): identical label file
     monkeypatch.setenv("BOA_NET_PRECISION", "fp32")
     out32 = tmp_path / "seg32"

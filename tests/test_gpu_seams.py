@@ -257,8 +257,8 @@ def _small_net(patch=(32, 32, 32), features=(32, 64, 128), classes=5, seed=0, ke
      [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2]]),
 ])
 def test_network_forward_vs_oracle(ctx, patch, features, kernels, strides):
-    """Whole PlainConvUNet tile forward (fp16 MFMA) vs the torch-CPU fp32 oracle.  Tolerance: max abs logit error
-    <= 3 % of the logit range and argmax agreement >= 98 % (random weights make near-ties common)."""
+    """Whole PlainConvUNet tile forward (fp16 MFMA) vs the torch-CPU fp32 oracle.  Bars = measured on MI355X +
+    margin: max abs logit error <= 0.5 % of the logit range, argmax agreement >= 99.6 % (random weights make near-ties common)."""
     from boa_hip.predictor import HipPredictor
     from oracle.network import network_fn_from_module
     geom, blob, net = _small_net(patch, features, 5, 0, kernels, strides)
@@ -276,8 +276,8 @@ def test_network_forward_vs_oracle(ctx, patch, features, kernels, strides):
         err = float(np.abs(got[i] - ref).max())
         agree = float((got[i].argmax(0) == ref.argmax(0)).mean())
         print(f"tile {i}: max|err|={err:.4g} range={rng_:.4g} argmax agreement={agree:.5f}")
-        assert err <= 0.03 * rng_, (err, rng_)
-        assert agree >= 0.98
+        assert err <= 0.005 * rng_, (err, rng_)     # measured 1.3e-3 .. 2.2e-3 of the range
+        assert agree >= 0.996                         # measured 0.9981 .. 0.9992
     p.close()
 
 
@@ -307,8 +307,8 @@ def test_sliding_window_end_to_end(ctx):
         print("max|err| over all voxels incl. quantised corners:", float(np.abs(g32 - r32).max()))
         agree = float((seg == ref.argmax(0)).mean())
         print(f"{shape} step {step}: max|err|={err:.4g} range={rng_:.4g} label agreement={agree:.5f}")
-        assert err <= 0.03 * rng_
-        assert agree >= 0.98
+        assert err <= 0.003 * rng_                    # measured 8.2e-4 .. 8.8e-4 of the range
+        assert agree >= 0.998                         # measured 0.99957 / 0.99968
         # on-device argmax is exactly the argmax of the on-device fp16 logits
         np.testing.assert_array_equal(seg, got.argmax(0).astype(np.uint8))
         p.close()
@@ -317,7 +317,7 @@ def test_sliding_window_end_to_end(ctx):
 def test_total_pipeline_vs_oracle(ctx):
     """`total` array pipeline (5 part models, crop_to_nonzero, CTNormalization, step 0.8, argmax, part merge) vs
     the oracle pipeline with torch-CPU fp32 networks.  A zero slab forces a non-trivial crop.  Label agreement
-    >= 97 % (five random-weight fp16 nets; every other step is exact)."""
+    >= 99.6 % (five random-weight fp16 nets; every other step is exact)."""
     import torch
     from boa_hip import label_maps, plans, totalseg
     from oracle import pipeline as opipe
@@ -345,4 +345,4 @@ def test_total_pipeline_vs_oracle(ctx):
     assert (got[:3] == 0).all() and (got[:, :, -5:] == 0).all()  # outside the crop box
     agree = float((got == want).mean())
     print("total pipeline label agreement", agree, "labels present", len(np.unique(got)))
-    assert agree >= 0.97
+    assert agree >= 0.996      # measured 0.9985 (five random-weight fp16 nets; every other step is exact)

@@ -66,7 +66,7 @@ def test_total_resampled_lps_input(ctx):
     assert got.shape == ct_lps.shape and got.dtype == np.uint8
     agree = float((got[::-1, ::-1, :] == want_ras).mean())
     print("total (resampled, LPS) agreement", agree, "labels", len(np.unique(got)))
-    assert agree >= 0.97
+    assert agree >= 0.996      # measured 0.9984
 
 
 def test_force_split_matches_oracle(ctx):
@@ -85,7 +85,7 @@ def test_force_split_matches_oracle(ctx):
     t.close()
     agree = float((got == want).mean())
     print("force_split agreement", agree, "split vs unsplit", float((got == nosplit).mean()))
-    assert agree >= 0.97
+    assert agree >= 0.997      # measured 0.9993
 
 
 def test_bca_nets_thickness_resampling_5_folds(ctx):
@@ -104,7 +104,7 @@ def test_bca_nets_thickness_resampling_5_folds(ctx):
     assert got.shape == ct.shape
     agree = float((got == want).mean())
     print("BCA 5-fold thickness-resampled agreement", agree)
-    assert agree >= 0.97
+    assert agree >= 0.996      # measured 0.9985
 
 
 def test_bca_pipeline_vs_oracle_composition(ctx):
@@ -187,4 +187,4 @@ def test_crop_mask_and_permuted_axes(ctx):
     assert (got[outside] == 0).all() and bbox[0] == [4, 32]
     agree = float((got == want).mean())
     print("crop + permuted axes agreement", agree)
-    assert agree >= 0.97
+    assert agree >= 0.998      # measured 0.9997
