@@ -78,8 +78,8 @@ def _bca_models(folds):
 
 
 def test_config2_total_bca_512x512x768(ctx):
-    """configs[2]: whole-body 512x512x768 @1.5 mm, `total` (1 000 tile forwards) + `bca` (fast_bca: one fold per net at 5 mm
-    slices -- the 5-fold arithmetic is covered at small size) + total measurements on one GPU.  Properties: two runs agree
+    """configs[2]: whole-body 512x512x768 @1.5 mm, `total` (1 000 tile forwards) + `bca` with the FIVE folds per net the config
+    names (2 x 5 x 147 tiles at 5 mm slices, step 0.5) + total measurements on one GPU.  Properties: two runs agree
     bit for bit (labels and tables), every table is consistent with the label volumes it summarises."""
     from boa_hip import label_maps, synthetic
     from boa_hip import measurements as M
@@ -90,8 +90,8 @@ def test_config2_total_bca_512x512x768(ctx):
     ct = synthetic.ct_phantom(shape, seed=3)
     aff = np.diag([-1.5, -1.5, 1.5, 1.0])
     ts = TotalSegmentatorHip(ctx, [(tid, cfg, [blob]) for tid, cfg, blob, _ in synthetic.total_part_models()])
-    bm = _bca_models(1)
-    pipe = BcaPipelineHip(ctx, bm["body_parts"], bm["body_regions"], fast_bca=True)
+    bm = _bca_models(5)
+    pipe = BcaPipelineHip(ctx, bm["body_parts"], bm["body_regions"], fast_bca=False)
     runs = []
     for _ in range(2):
         total = ts.predict(ct, affine=aff)
@@ -154,3 +154,74 @@ def test_config4_triple_split_512x512x1024(ctx):
     ts.close()
     dst, src = comb[1]
     np.testing.assert_array_equal(seg[:, :, dst], mid[:, :, src])
+
+
+
+def test_config4_models_all_512x512x1024(tmp_path, monkeypatch):
+    """configs[4]: `--models all` (BOA/compute/constants: total + bca + lung_vessels + cerebral_bleed + hip_implant +
+    pleural_pericard_effusion + liver_vessels) on one 512x512x1024 @1.5 mm CT through the file-level drop-in
+    (`compute_all_models`), synthetic model folders with the documented 128^3 six-stage geometry for `total` / BCA and small nets for
+    the rough 6 mm model and the cascade tasks.  Property test (no CPU reference at this size): every output of the folder contract
+    exists with the input's grid, labels stay inside the task's class map, the stats dict is the reference's, the triple z-split is
+    taken (268 M voxels), tables are consistent with the volumes, and a cascade result is zero outside its crop box."""
+    import json
+    from boa_hip import label_maps, model_store, nifti, plans, synthetic
+    from boa_hip.compute.constants import ALL_MODELS
+    from boa_hip.compute.inference import compute_all_models
+    root = str(tmp_path / "results")
+    for (tid, cfg, blob, (pj, dj, sd)), k in zip(synthetic.total_part_models(), range(5)):
+        model_store.write_model_folder(root, tid, f"TotalSegmentator_part{k + 1}", "nnUNetTrainerNoMirroring", pj, dj, [sd])
+    small = dict(patch=(64, 64, 64), features=(32, 64, 128))
+    specs = [(298, 118, "TotalSegmentator_6mm", "nnUNetTrainer_4000epochs_NoMirroring", (6.0, 6.0, 6.0), 1)]
+    for name in ("lung_vessels", "cerebral_bleed", "hip_implant", "pleural_pericard_effusion", "liver_vessels"):
+        info = model_store.TASKS[name]
+        specs.append((info["task_id"][0], max(label_maps.class_map(name)) + 1, name, info["trainer"], (1.5, 1.5, 1.5),
+                      2 if info["folds"] is None else 1))
+    for tid, nc, name, trainer, sp, nfolds in specs:
+        pj, dj = plans.synthetic_plans(num_classes=nc, spacing=sp, **small)
+        geom = plans.model_config_from_plans(pj, dj).geometry
+        model_store.write_model_folder(root, tid, name, trainer, pj, dj, [plans.synthetic_state_dict(geom, seed=tid + f) for f in range(nfolds)])
+    for tid, nc, name, trainer in ((543, 7, "BCA_body_parts", "nnUNetTrainer_1500epochs_NoMirroring"), (542, 12, "BCA_inference", "nnUNetTrainerNoMirroring")):
+        pj, dj = plans.synthetic_plans(num_classes=nc, spacing=(5.0, 1.5, 1.5))
+        geom = plans.model_config_from_plans(pj, dj).geometry
+        model_store.write_model_folder(root, tid, name, trainer, pj, dj, [plans.synthetic_state_dict(geom, seed=tid + f) for f in range(5)])
+    monkeypatch.setenv("nnUNet_results", root)
+    shape = (512, 512, 1024)
+    ct = synthetic.ct_phantom(shape, seed=44)
+    aff = np.diag([-1.5, -1.5, 1.5, 1.0])
+    ct_path = tmp_path / "ct.nii.gz"
+    nifti.save(ct_path, ct, aff, threads=8)
+    out = tmp_path / "seg"
+    params = {"preview": False, "fast": False, "ml": True, "nr_thr_resamp": 1, "nr_thr_saving": 8, "quiet": True, "verbose": False,
+              "device": "gpu", "license_number": None}
+    models = sorted(ALL_MODELS - {"body_parts", "body_regions"})          # `bca` runs both BCA nets
+    stats = compute_all_models(ct_path, out, models, params, fast_bca=False,
+                               bca_params={"median_filtering": False, "examined_body_region": None, "save_pdf": False, "theme": "light"})
+    assert stats == {"num_voxels": 512 * 512 * 1024, "num_slices": 1024, "num_slices_resampled": 1024}
+    nvox = int(np.prod(shape))
+    for name in ("total", "lung_vessels", "cerebral_bleed", "hip_implant", "pleural_pericard_effusion", "liver_vessels", "body_parts",
+                 "body_regions", "tissues"):
+        seg, saff, hdr = nifti.load(out / f"{name}.nii.gz")
+        assert seg.shape == shape and seg.dtype == np.uint8, name
+        np.testing.assert_allclose(saff, aff)
+        labs = np.flatnonzero(np.bincount(seg.ravel(), minlength=256))
+        if name in model_store.CASCADE_MODELS:      # labels are the network's class indices: within the task's class map range
+            assert set(labs.tolist()) <= set(range(max(label_maps.class_map(name)) + 1)), (name, labs)
+        if name == "total":
+            assert len(labs) > 40 and hdr.extensions and nifti.parse_label_xml(hdr.extensions[0][1]) == label_maps.CLASS_MAP_TOTAL
+            counts = np.bincount(seg.ravel(), minlength=256)
+        del seg
+    with open(out / "total-measurements.json") as f:
+        tm = json.load(f)
+    ml = 1.5 ** 3 / 1000.0
+    lm = label_maps.measurement_label_map("total")
+    for nm, lab in list(lm.items())[:30]:
+        e = tm["segmentations"]["total"][nm]
+        assert e["present"] == bool(counts[lab])
+        if counts[lab]:
+            assert abs(e["volume_ml"] - counts[lab] * ml) <= 1e-9 * counts[lab] * ml
+    with open(out / "bca-measurements.json") as f:
+        bj = json.load(f)
+    assert len(bj["slices"]) == 1024 and "aggregated" in bj
+    assert (out / "ct_pfav.nii.gz").is_file()
+    assert nvox > 512 * 512 * 900            # the size that triggers the triple z-split of `total` (TS/nnunet.py:489-505)
