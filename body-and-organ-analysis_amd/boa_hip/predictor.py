@@ -194,9 +194,7 @@ class HipPredictor:
         grid (nnU-Net's own resampling, export_prediction.py:25-33): the fold-mean logits are resampled with order 1 to
         `out_dims` and reduced to labels there (`boa_resize_logits_argmax`); labels_out is then uint8 [*out_dims]."""
         if shard is not None and shard.comm.world > 1:
-            if resample_to is not None:
-                raise NotImplementedError("tile sharding together with nnU-Net's plan-spacing resampling")
-            return self._predict_segmentation_sharded(dvol, V, labels_out, lut, merge, work, shard)
+            return self._predict_segmentation_sharded(dvol, V, labels_out, lut, merge, work, shard, resample_to)
         PV, below = sw.pad_amounts(V, self.geom.patch_size)
         origins = sw.get_sliding_window_origins(PV, self.geom.patch_size, self.tile_step_size)
         C_ = self.geom.num_classes
@@ -247,7 +245,7 @@ class HipPredictor:
             for b in work.values():
                 b.free()
 
-    def _predict_segmentation_sharded(self, dvol, V, labels_out, lut, merge, work, shard):
+    def _predict_segmentation_sharded(self, dvol, V, labels_out, lut, merge, work, shard, resample_to=None):
         from . import tile_shard as ts
         PV, below = sw.pad_amounts(V, self.geom.patch_size)
         origins = sw.get_sliding_window_origins(PV, self.geom.patch_size, self.tile_step_size)
@@ -277,6 +275,8 @@ class HipPredictor:
             lut_arr = np.zeros(256, dtype=np.uint8)
             lut_arr[:len(lut)] = lut
         crop = any(b != 0 for b in below) or list(PV) != list(V)
+        direct = resample_to is None
+        lo = hi = 0
         for f in range(nf):
             self._ensure_net(f)
             eng = ts.HipShardEngine(self, shard.comm, dvol, V, PV, below, origins, acc, nacc)
@@ -285,19 +285,31 @@ class HipPredictor:
             finally:
                 eng.close()
             last = f == nf - 1
+            # (resampled path: keep the normalised fold-mean logits of the owned planes -- in `acc` for one fold, in `fold` otherwise)
             check(self.lib.boa_finalize_labels_planes(
                 self.ctx.h, acc.vp, nacc.vp, C_, int3(PV), fold.vp if fold else None, 0 if f == 0 else 1,
-                nf if (last and fold) else 0, 0, lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None,
-                0, part.vp if last else None, int3(below) if crop else None, int3(V) if crop else None, flag.vp, lo, hi),
+                nf if (last and fold) else 0, 0 if (direct or fold) else 1, lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None,
+                0, part.vp if (last and direct) else None, int3(below) if crop else None, int3(V) if crop else None, flag.vp, lo, hi),
                 "boa_finalize_labels_planes")
         bad = int(flag.download((1,), np.int32)[0])
-        ts.all_reduce_labels(self.ctx, shard.comm, part, nv)
         import torch
+        if direct:
+            ts.all_reduce_labels(self.ctx, shard.comm, part, nv)
+        else:
+            # nnU-Net resamples the logits (order 1) before the argmax: every rank needs all planes -> sum the plane-disjoint logits
+            # over the ranks, then the same fused resize + argmax as on one GPU (identical labels on every rank)
+            out_dims, slice_axis = resample_to
+            logits = fold if fold else acc
+            ts.all_reduce_logit_planes(self.ctx, shard.comm, logits, C_, PV, lo, hi)
         t = torch.tensor([bad], dtype=torch.int32, device=shard.comm.device)
         shard.comm.all_reduce_sum(t)
         if int(t.item()):
             raise RuntimeError("Encountered inf in predicted array. Aborting...")
-        if merge:
+        if not direct:
+            check(self.lib.boa_resize_logits_argmax(self.ctx.h, logits.vp, C_, int3(PV), int3(below), int3(V), int3(out_dims), int(slice_axis),
+                                                    lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None, 1 if merge else 0,
+                                                    labels_out.vp), "boa_resize_logits_argmax")
+        elif merge:
             check(self.lib.boa_label_overlay(self.ctx.h, part.vp, nv, labels_out.vp), "boa_label_overlay")
         else:
             one, st = (C.c_int * 3)(1, 1, nv), (C.c_longlong * 3)(0, 0, 1)

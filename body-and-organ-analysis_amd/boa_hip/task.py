@@ -89,8 +89,11 @@ class SegmentationTask:
         for task_id, cfg, blobs in models:
             if cfg.normalization_schemes[0] != "CTNormalization":
                 raise ValueError(f"Dataset{task_id}: only CTNormalization is supported on device")
-            if list(cfg.transpose_forward) != [0, 1, 2]:
-                raise NotImplementedError("plans with a non-identity transpose_forward")
+            tf, tb = [int(v) for v in cfg.transpose_forward], [int(v) for v in cfg.transpose_backward]
+            if sorted(tf) != [0, 1, 2] or [tf[i] for i in tb] != [0, 1, 2]:
+                raise ValueError(f"Dataset{task_id}: transpose_forward {tf} / transpose_backward {tb} are not inverse permutations")
+            if self.parts and tf != [int(v) for v in self.parts[0][1].transpose_forward]:
+                raise NotImplementedError("models of one task with different transpose_forward")
             p = HipPredictor(ctx, cfg.geometry, tile_step_size=self.step_size, max_batch=max_batch, precision=precision)
             p.set_parameters(list(blobs))
             if self.multimodel:
@@ -129,32 +132,36 @@ class SegmentationTask:
             vol = self._work["vol"] = ctx.alloc(n * 4)
         d_labels.zero()
         if self.model_shard is not None and self.model_shard.world > 1 and self.multimodel:
-            if spacing_zyx is not None and any(nr.compute_new_shape(shape, spacing_zyx, cfg.spacing) != list(shape) for _, cfg, _, _ in self.parts):
-                raise NotImplementedError("model sharding together with nnU-Net's plan-spacing resampling")
-            return self._predict_zyx_model_sharded(d_ct, shape, d_labels, in_dtype, vol, n)
-        for task_id, cfg, p, lut in self.parts:
-            ip = cfg.intensity_properties["0"]
-            # every model normalises with its own plans' intensity properties (default_preprocessor.py:336-348)
-            check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, in_dtype, vol.vp, n, ip["mean"], ip["std"],
-                                           ip["percentile_00_5"], ip["percentile_99_5"]), "boa_ct_normalize")
-            new_shape = list(shape) if spacing_zyx is None else nr.compute_new_shape(shape, spacing_zyx, cfg.spacing)
-            if new_shape == list(shape):      # resample_data_or_seg returns its input unchanged (default_resampling.py:194-196)
-                p.predict_segmentation_device(vol, list(shape), d_labels, lut=lut, merge=self.multimodel, work=self._work,
-                                              shard=self.shard)
-                continue
-            # normalise BEFORE resampling (default_preprocessor.py:82-84), order 3 in; order 1 back, then argmax
-            ax_in = nr.slice_axis_for(nr.checked_kwargs(cfg.extra, "data"), spacing_zyx, cfg.spacing)
-            ax_out = nr.slice_axis_for(nr.checked_kwargs(cfg.extra, "probabilities"), cfg.spacing, spacing_zyx)
-            vol_r = ctx.alloc(int(np.prod(new_shape)) * 4)
-            try:
-                check(ctx.lib.boa_resize_skimage_f32(ctx.h, vol.vp, int3(shape), vol_r.vp, int3(new_shape), 3, ax_in),
-                      "boa_resize_skimage_f32")
-                p.predict_segmentation_device(vol_r, new_shape, d_labels, lut=lut, merge=self.multimodel, work=self._work,
-                                              shard=self.shard, resample_to=(list(shape), ax_out))
-            finally:
-                vol_r.free()
+            return self._predict_zyx_model_sharded(d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx)
+        for k in range(len(self.parts)):
+            self._run_model(k, d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx, merge=self.multimodel, shard=self.shard)
 
-    def _predict_zyx_model_sharded(self, d_ct, shape, d_labels, in_dtype, vol, n):
+    def _run_model(self, k, d_ct, shape, d_out, in_dtype, vol, n, spacing_zyx, merge, shard):
+        """One model of the task on the resident array: CTNormalization with the model's own intensity properties
+        (default_preprocessor.py:336-348), nnU-Net's resampling to the plans' spacing when it differs from the array's, sliding
+        window, labels written (merge=False) or merged (merge=True) into `d_out`."""
+        ctx = self.ctx
+        task_id, cfg, p, lut = self.parts[k]
+        ip = cfg.intensity_properties["0"]
+        check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, in_dtype, vol.vp, n, ip["mean"], ip["std"],
+                                       ip["percentile_00_5"], ip["percentile_99_5"]), "boa_ct_normalize")
+        new_shape = list(shape) if spacing_zyx is None else nr.compute_new_shape(shape, spacing_zyx, cfg.spacing)
+        if new_shape == list(shape):      # resample_data_or_seg returns its input unchanged (default_resampling.py:194-196)
+            p.predict_segmentation_device(vol, list(shape), d_out, lut=lut, merge=merge, work=self._work, shard=shard)
+            return
+        # normalise BEFORE resampling (default_preprocessor.py:82-84), order 3 in; order 1 back, then argmax
+        ax_in = nr.slice_axis_for(nr.checked_kwargs(cfg.extra, "data"), spacing_zyx, cfg.spacing)
+        ax_out = nr.slice_axis_for(nr.checked_kwargs(cfg.extra, "probabilities"), cfg.spacing, spacing_zyx)
+        vol_r = ctx.alloc(int(np.prod(new_shape)) * 4)
+        try:
+            check(ctx.lib.boa_resize_skimage_f32(ctx.h, vol.vp, int3(shape), vol_r.vp, int3(new_shape), 3, ax_in),
+                  "boa_resize_skimage_f32")
+            p.predict_segmentation_device(vol_r, new_shape, d_out, lut=lut, merge=merge, work=self._work,
+                                          shard=shard, resample_to=(list(shape), ax_out))
+        finally:
+            vol_r.free()
+
+    def _predict_zyx_model_sharded(self, d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx=None):
         from . import tile_shard as ts
         ctx, comm = self.ctx, self.model_shard
         part = self._work.get("part")
@@ -162,13 +169,10 @@ class SegmentationTask:
             if part is not None:
                 part.free()
             part = self._work["part"] = ctx.alloc(n)
-        for k, (task_id, cfg, p, lut) in enumerate(self.parts):
+        for k in range(len(self.parts)):
             check(ctx.lib.boa_memset(ctx.h, part.vp, 0, n), "boa_memset")
-            if k % comm.world == comm.rank:
-                ip = cfg.intensity_properties["0"]
-                check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, in_dtype, vol.vp, n, ip["mean"], ip["std"],
-                                               ip["percentile_00_5"], ip["percentile_99_5"]), "boa_ct_normalize")
-                p.predict_segmentation_device(vol, list(shape), part, lut=lut, merge=False, work=self._work)
+            if k % comm.world == comm.rank:   # exactly the one-GPU computation of this model (incl. its plan-spacing resampling)
+                self._run_model(k, d_ct, shape, part, in_dtype, vol, n, spacing_zyx, merge=False, shard=None)
             # the owner's label volume reaches every rank (sum over disjoint supports), then the reference's merge in part
             # order: `seg_combined[seg == jdx] = class_map_inv[name]` (TS/nnunet.py:553-556)
             ts.all_reduce_labels(ctx, comm, part, n)
@@ -184,21 +188,34 @@ class SegmentationTask:
         want = dt if dt in (np.dtype(np.int16), np.dtype(np.int32)) else np.dtype(np.float32)
         code = {np.dtype(np.int16): 0, np.dtype(np.float32): 1, np.dtype(np.int32): 2}[want]
         zyx = part_xyz.transpose((2, 1, 0)).contiguous(want, force_copy=False)
-        bbox = zyx.nonzero_bbox()
-        full = all(b == [0, n] for b, n in zip(bbox, zyx.shape))
-        crop = zyx if full else zyx.box(bbox).contiguous()
+        # plans' transpose_forward (default_preprocessor.py:57-60: data.transpose([0, *[i + 1 for i in transpose_forward]]) before
+        # cropping / resampling; export_prediction.py:56-58 transposes the segmentation back): a device view + one copy
+        tf = [int(v) for v in self.parts[0][1].transpose_forward]
+        ident = tf == [0, 1, 2]
+        work = zyx if ident else zyx.transpose(tuple(tf)).contiguous(want, force_copy=True)
+        sp_t = None if spacing_zyx is None else [spacing_zyx[i] for i in tf]
+        bbox_t = work.nonzero_bbox()
+        full = all(b == [0, n] for b, n in zip(bbox_t, work.shape))
+        crop = work if full else work.box(bbox_t).contiguous()
         d_lab = DevArray.empty(self.ctx, crop.shape, np.uint8)
         try:
-            self.predict_zyx_device(crop.buf, crop.shape, d_lab.buf, in_dtype=code, spacing_zyx=spacing_zyx)
+            self.predict_zyx_device(crop.buf, crop.shape, d_lab.buf, in_dtype=code, spacing_zyx=sp_t)
+            # back to (z, y, x): axis i of the transposed array is axis tf[i] of the original
+            bbox = [None, None, None]
+            for i in range(3):
+                bbox[tf[i]] = bbox_t[i]
+            lab_zyx = d_lab if ident else d_lab.transpose(tuple(int(v) for v in self.parts[0][1].transpose_backward))
             k0, k1 = max(bbox[0][0], src_lo), min(bbox[0][1], src_hi)
             if k0 < k1:
-                src = d_lab.slice(0, k0 - bbox[0][0], k1 - bbox[0][0]).transpose((2, 1, 0))
+                src = lab_zyx.slice(0, k0 - bbox[0][0], k1 - bbox[0][0]).transpose((2, 1, 0))
                 dst = dst_xyz.slice(2, k0 - src_lo, k1 - src_lo).slice(1, bbox[1][0], bbox[1][1]).slice(0, bbox[2][0], bbox[2][1])
                 src.copy_to(dst)
         finally:
             d_lab.free()
-            if crop is not zyx:
+            if crop is not work:
                 crop.free()
+            if work is not zyx:
+                work.free()
             if zyx.buf is not part_xyz.buf:
                 zyx.free()
 

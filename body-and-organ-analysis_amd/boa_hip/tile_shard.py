@@ -326,6 +326,39 @@ def all_reduce_labels(ctx, comm: ShardComm, buf, n: int):
         buf.upload(t.numpy())
 
 
+def all_reduce_logit_planes(ctx, comm: ShardComm, buf, C_: int, PV, lo: int, hi: int):
+    """`buf`: fp16 logits [C][PV0][PV1][PV2] of which this rank holds the planes [lo, hi) of axis 0 (its share of a tile-sharded
+    sliding window after the normalisation).  The other planes are cleared and the buffers summed over the ranks (disjoint
+    supports: x + 0 is exact in fp16), so every rank ends with the complete logits -- needed when nnU-Net resamples the logits
+    before the argmax (export_prediction.py:25-33), which reads across plane ownership."""
+    import torch
+    if comm.world == 1:
+        return
+    plane = int(PV[1]) * int(PV[2])
+    vox = int(PV[0]) * plane
+    for c in range(C_):
+        base = buf.ptr + 2 * c * vox
+        if lo > 0:
+            check(ctx.lib.boa_memset(ctx.h, C.c_void_p(base), 0, 2 * lo * plane), "boa_memset")
+        if hi < PV[0]:
+            check(ctx.lib.boa_memset(ctx.h, C.c_void_p(base + 2 * hi * plane), 0, 2 * (int(PV[0]) - hi) * plane), "boa_memset")
+    n = C_ * vox
+    if comm.on_device:
+        t = comm.empty((n,), torch.float16)
+        one = (C.c_int * 3)(1, 1, n)
+        st = (C.c_longlong * 3)(0, 0, 1)
+        f = _Foreign(t)
+        check(ctx.lib.boa_copy3(ctx.h, buf.vp, 1, 0, st, one, f.vp, 1, 0, st), "boa_copy3")   # dtype 1 = 16-bit words
+        ctx.sync()
+        comm.all_reduce_sum(t)
+        check(ctx.lib.boa_copy3(ctx.h, f.vp, 1, 0, st, one, buf.vp, 1, 0, st), "boa_copy3")
+        ctx.sync()
+    else:
+        t = torch.from_numpy(buf.download((n,), np.uint16).view(np.float16).copy())
+        comm.all_reduce_sum(t)
+        buf.upload(t.numpy().view(np.uint16))
+
+
 @dataclass
 class TileShard:
     """What `HipPredictor.predict_segmentation_device(..., shard=...)` needs: the transport and the exchange mode."""

@@ -29,13 +29,18 @@ def predict_total(ct_xyz, part_models, class_map_inv, step_size=0.8):
     return np.ascontiguousarray(comb.transpose(2, 1, 0))
 
 
-def predict_part(data_xyz, models, class_map_inv, step_size, multimodel, spacing_xyz=None):
-    """One s0k_0000 sub-volume through every model (TS/nnunet.py:536-559 or :566-573).  A model entry may carry a sixth
+def predict_part(data_xyz, models, class_map_inv, step_size, multimodel, spacing_xyz=None, transpose_forward=None):
+    """One s0k_0000 sub-volume through every model (TS/nnunet.py:536-559 or :566-573).  `transpose_forward`: the plans' axis
+    permutation applied to the (z, y, x) array before cropping / resampling (default_preprocessor.py:57-60) and undone on the
+    segmentation (export_prediction.py:56-58).  A model entry may carry a sixth
     element, its plans' spacing (z, y, x): when it differs from the image's, nnU-Net resamples the normalised crop to the
     plans' grid (order 3) and the fold-mean logits back (order 1) before the argmax (default_preprocessor.py:82-93,
     export_prediction.py:25-33; oracle/nnunet_resample.py)."""
     from . import nnunet_resample as nnr
     data = np.ascontiguousarray(data_xyz.transpose(2, 1, 0))[None].astype(np.float32)
+    tf = [0, 1, 2] if transpose_forward is None else [int(v) for v in transpose_forward]
+    tb = [tf.index(i) for i in range(3)]
+    data = np.ascontiguousarray(data.transpose([0] + [i + 1 for i in tf]))
     bbox = labels.nonzero_bbox(data)
     sl = tuple(slice(a, b) for a, b in bbox)
     crop = data[(slice(None),) + sl]
@@ -47,6 +52,8 @@ def predict_part(data_xyz, models, class_map_inv, step_size, multimodel, spacing
         x = labels.ct_normalize(crop[0], ip["mean"], ip["std"], ip["percentile_00_5"], ip["percentile_99_5"])[None]
         shape = x.shape[1:]
         sp_zyx = None if spacing_xyz is None else [float(v) for v in list(spacing_xyz)[::-1]]
+        if sp_zyx is not None:
+            sp_zyx = [sp_zyx[i] for i in tf]
         new_shape = shape if (plan_sp is None or sp_zyx is None) else tuple(nnr.compute_new_shape(shape, sp_zyx, plan_sp))
         if tuple(new_shape) != tuple(shape):
             x = nnr.resample_to_shape(x, new_shape, sp_zyx, plan_sp, order=3).astype(np.float32)
@@ -59,11 +66,12 @@ def predict_part(data_xyz, models, class_map_inv, step_size, multimodel, spacing
         segs.append(seg)
         maps.append(pmap)
     comb = labels.merge_parts(segs, maps, class_map_inv) if multimodel else segs[0]
+    comb = comb.transpose(tb)
     return np.ascontiguousarray(comb.transpose(2, 1, 0))
 
 
 def predict_image(ct_xyz, spacing_xyz, models, class_map_inv=None, task_name="total", resample=1.5,
-                  resample_only_thickness=False, multimodel=True, force_split=False):
+                  resample_only_thickness=False, multimodel=True, force_split=False, transpose_forward=None):
     """TS/nnunet.py:nnUNet_predict_image (:453-699) for an input that is already RAS-canonical: resample (order 3 ->
     int32), optional triple z-split, predict, recombine, resample back (order 0)."""
     from . import resample as orsp
@@ -80,15 +88,15 @@ def predict_image(ct_xyz, spacing_xyz, models, class_map_inv=None, task_name="to
     sp_now = [float(v) for v in (rsp if rsp is not None else spacing)]
     if (np.prod(ss) > 512 * 512 * 900 and ss[2] > 200 and multimodel) or force_split:
         third, margin = ss[2] // 3, 20
-        p1 = predict_part(img[:, :, :third + margin], models, class_map_inv, step, multimodel, sp_now)
-        p2 = predict_part(img[:, :, third + 1 - margin:third * 2 + margin], models, class_map_inv, step, multimodel, sp_now)
-        p3 = predict_part(img[:, :, third * 2 + 1 - margin:], models, class_map_inv, step, multimodel, sp_now)
+        p1 = predict_part(img[:, :, :third + margin], models, class_map_inv, step, multimodel, sp_now, transpose_forward)
+        p2 = predict_part(img[:, :, third + 1 - margin:third * 2 + margin], models, class_map_inv, step, multimodel, sp_now, transpose_forward)
+        p3 = predict_part(img[:, :, third * 2 + 1 - margin:], models, class_map_inv, step, multimodel, sp_now, transpose_forward)
         seg = np.zeros(ss, dtype=np.uint8)
         seg[:, :, :third] = p1[:, :, :-margin]
         seg[:, :, third:third * 2] = p2[:, :, margin - 1:-margin]
         seg[:, :, third * 2:] = p3[:, :, margin - 1:]
     else:
-        seg = predict_part(img, models, class_map_inv, step, multimodel, sp_now)
+        seg = predict_part(img, models, class_map_inv, step, multimodel, sp_now, transpose_forward)
     if rsp is not None and zoom is not None:
         seg, _ = orsp.change_spacing_array(seg, rsp, rsp, target_shape=ct_xyz.shape, order=0, dtype=np.uint8)
     return seg

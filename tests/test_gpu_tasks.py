@@ -188,3 +188,37 @@ def test_crop_mask_and_permuted_axes(ctx):
     agree = float((got == want).mean())
     print("crop + permuted axes agreement", agree)
     assert agree >= 0.998      # measured 0.9997
+
+
+
+def test_transpose_forward_plans(ctx):
+    """Plans with a non-identity transpose_forward (default_preprocessor.py:57-60: the (z, y, x) array and its spacing are
+    permuted before cropping / resampling, export_prediction.py:54-58 permutes the segmentation back): device views vs the
+    oracle pipeline, anisotropic patch so that a wrong axis order cannot pass."""
+    import torch
+    from boa_hip import plans
+    from boa_hip.task import SegmentationTask
+    from oracle import pipeline as opipe
+    from oracle.network import build_from_arch, network_fn_from_module
+    tf = [1, 2, 0]
+    tb = [tf.index(i) for i in range(3)]
+    pj, dj = plans.synthetic_plans(patch=(16, 48, 32), features=(32, 64), num_classes=5, spacing=(1.5, 1.5, 1.5),
+                                   kernels=[[1, 3, 3], [3, 3, 3]], strides=[[1, 1, 1], [1, 2, 2]])
+    pj["transpose_forward"], pj["transpose_backward"] = tf, tb
+    cfg = plans.model_config_from_plans(pj, dj)
+    assert list(cfg.transpose_forward) == tf
+    sd = plans.synthetic_state_dict(cfg.geometry, seed=77)
+    net = build_from_arch(pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"], 1, 5)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    ct = _ct((52, 36, 44), 21)
+    ct[:5] = 0                                   # crop_to_nonzero has something to crop (in the transposed frame)
+    sp = (1.5, 1.5, 1.5)
+    want = opipe.predict_image(ct, sp, [([network_fn_from_module(net, 8)], (16, 48, 32), 5, cfg.intensity_properties["0"], None)], None,
+                               "other", None, multimodel=False, transpose_forward=tf)
+    t = SegmentationTask(ctx, "other", [(900, cfg, [plans.weight_blob_from_state_dict(cfg.geometry, sd)])], resample=None, max_batch=4)
+    got = t.predict_image(ct, np.diag([1.5, 1.5, 1.5, 1.0]))
+    t.close()
+    assert got.shape == ct.shape and (got[:5] == 0).all()
+    agree = float((got == want).mean())
+    print("transpose_forward agreement", agree)
+    assert agree >= 0.996

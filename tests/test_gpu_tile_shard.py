@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPE = (96, 40, 44)
 PARTS = ((801, 6, 1), (802, 4, 2))        # (task id, classes, folds)
+RS_SPACING = (1.5, 1.2, 1.3)              # array spacing (z, y, x) that differs from the plans' 1.5 mm: nnU-Net's own resampling runs
 
 
 def _free_port():
@@ -52,7 +53,7 @@ def _ct():
     return ct
 
 
-def _predict(ctx, shard=None, model_shard=None, max_batch=1):
+def _predict(ctx, shard=None, model_shard=None, max_batch=1, spacing_zyx=None):
     from boa_hip.task import SegmentationTask
     models, luts = _models()
     task = SegmentationTask(ctx, "total", models, resample=1.5, multimodel=True, max_batch=max_batch, part_luts=luts)
@@ -64,7 +65,7 @@ def _predict(ctx, shard=None, model_shard=None, max_batch=1):
     d_ct = ctx.from_numpy(_ct())
     d_lab = ctx.alloc(int(np.prod(SHAPE)))
     try:
-        task.predict_zyx_device(d_ct, SHAPE, d_lab, in_dtype=0)
+        task.predict_zyx_device(d_ct, SHAPE, d_lab, in_dtype=0, spacing_zyx=spacing_zyx)
         return d_lab.download(SHAPE, np.uint8)
     finally:
         d_ct.free()
@@ -88,10 +89,12 @@ def _worker(rank, world, port, mode, q, backend="gloo"):
         dist = D.init("gloo", rank, world)
         ctx = Context(0)
         comm = ts.ShardComm(dist, rank, world, "cpu")
+    sp = RS_SPACING if mode.endswith("+rs") else None    # "+rs": the array is NOT at the plans' spacing (nnU-Net resamples)
+    mode = mode.replace("+rs", "")
     if mode == "models":
-        lab = _predict(ctx, model_shard=comm, max_batch=4)
+        lab = _predict(ctx, model_shard=comm, max_batch=4, spacing_zyx=sp)
     else:
-        lab = _predict(ctx, ts.TileShard(comm, mode), max_batch=3)
+        lab = _predict(ctx, ts.TileShard(comm, mode), max_batch=3, spacing_zyx=sp)
     q.put((rank, lab))
     dist.barrier()
     ctx.close()
@@ -138,6 +141,22 @@ def test_single_process_labels_do_not_depend_on_the_tile_batch(single):
             np.testing.assert_array_equal(_predict(c, max_batch=mb), single)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("mode", ["exact+rs", "models+rs"])
+def test_sharding_with_plan_spacing_resampling_bit_identical(mode):
+    """Tile / model sharding together with nnU-Net's resampling to the plans' spacing (order 3 in, order 1 on the logits back,
+    then argmax): the tile-sharded ranks sum their plane-disjoint normalised logits before the fused resize + argmax, the
+    model-sharded ranks run their models exactly as one GPU does -> labels bit-identical to the single-process run."""
+    from boa_hip.device import Context
+    c = Context(0)
+    want = _predict(c, max_batch=4, spacing_zyx=RS_SPACING)
+    plain = _predict(c, max_batch=4)
+    c.close()
+    assert (want != plain).mean() > 0.05          # the resampling path really ran
+    got = _run(2, mode)
+    np.testing.assert_array_equal(got[0], want)
+    np.testing.assert_array_equal(got[1], want)
 
 
 def _n_gpus():
@@ -228,3 +247,25 @@ def test_bench_shared_volume_modes_run_over_gloo(shard):
     assert two["n_gpus"] == 2 and two["config"]["ranks_seen"] == 2 and two["scaling"] == "strong"
     assert one["n_gpus"] == 1 and one["scaling"] == "weak"
     assert two["tables"] == one["tables"]                       # same labels present, same aggregation groups
+
+
+
+@pytest.mark.parametrize("shard", ["volumes", "tiles", "models"])
+def test_bench_eight_ranks_wiring_over_gloo(shard):
+    """`bench.py --gpus 8` end to end with EIGHT ranks (gloo, all sharing cuda:0, one 128^3 volume each / shared): the launcher,
+    process-group set-up, barriers, the max-over-ranks reduction, rank counting and the three sharding modes' plumbing at the
+    world size of the node the driver's scaling run uses -- so that the first 8-GPU hardware run cannot die on wiring.  (The
+    RCCL transport itself needs one GPU per rank: test_rccl_two_gpus_bit_identical.)"""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(HERE, "bench.py"), "--size", "128", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-parity", "--no-h2h",
+           "--batch", "2", "--gpus", "8", "--backend", "gloo", "--shard", shard]
+    r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["config"]["ranks_seen"] == 8
+    assert line["scaling"] == ("weak" if shard == "volumes" else "strong")
+    assert line["value"] > 0 and line["tables"]["total_labels_present"] > 0
+    # whole-job aggregate: 8 volumes per step in the weak mode, one shared volume otherwise
+    per_step = line["value"] * line["ms_per_step"] / 1e3
+    assert abs(per_step - (8 if shard == "volumes" else 1)) < 1e-6
