@@ -27,9 +27,11 @@ from .plans import NetGeometry
 class HipPredictor:
     def __init__(self, ctx: Context, geometry: NetGeometry, tile_step_size: float = 0.5, use_gaussian: bool = True,
                  use_mirroring: bool = False, max_batch: int = 4, verbose: bool = False, precision: Optional[str] = None,
-                 allowed_mirroring_axes: Optional[Sequence[int]] = (0, 1, 2)):
+                 allowed_mirroring_axes: Optional[Sequence[int]] = None):
         # BOA runs every model with tta=False / *NoMirroring trainers (TS/python_api.py:753); use_mirroring=True is honoured
-        # as nnUNetPredictor does (predict_from_raw_data.py:541-557) with the checkpoint's `inference_allowed_mirroring_axes`
+        # as nnUNetPredictor does (predict_from_raw_data.py:541-557) with the checkpoint's `inference_allowed_mirroring_axes`:
+        # None (the *NoMirroring trainers, and the default here) means no mirroring even with use_mirroring=True.  The mirrored
+        # mean is taken in fp32 (the reference adds in the network's autocast dtype: fp16 on CUDA, fp32 on its CPU path)
         self.use_mirroring = bool(use_mirroring)
         self.allowed_mirroring_axes = None if allowed_mirroring_axes is None else tuple(int(a) for a in allowed_mirroring_axes)
         if self.use_mirroring and self.allowed_mirroring_axes is not None and \

@@ -302,7 +302,8 @@ class SegmentationTask:
                 out_shape = rs.zoomed_shape(in_shape, zoom)
                 key = None
                 if self.resample_cache is not None and resident:
-                    key = (data.buf.ptr, view.offset, view.shape, view.strides, str(view.dtype), str(cast), tuple(out_shape))
+                    key = (data.buf.ptr, view.offset, view.shape, view.strides, str(view.dtype), str(cast), tuple(out_shape),
+                           tuple(float(z) for z in zoom))   # (the cache lives for ONE resident volume: pipeline.run_resident)
                 if key is not None and key in self.resample_cache:
                     img_rsp = DevArray(ctx, self.resample_cache[key], out_shape, np.int32)      # (not owned: the cache's)
                 else:

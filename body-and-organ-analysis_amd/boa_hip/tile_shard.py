@@ -153,6 +153,12 @@ class ShardComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         self._done()
 
+    def make_room(self, ctx):
+        """RCCL / torch allocate from the same HBM as the engine's caching allocator, whose parked blocks they cannot reclaim:
+        release them before the first exchange buffers of a volume are created (device transport only)."""
+        if self.on_device and ctx.info()["free_mem"] < (16 << 30):   # (only when HBM is actually short: re-filling the pool costs hipMallocs)
+            ctx.lib.boa_trim(ctx.h)
+
 
 # ---------------------------------------------------------------------------------------------------- protocol
 def run_fold_sharded(engine, plan: RowPlan, comm: ShardComm, mode: str = "exact") -> Tuple[int, int]:
@@ -311,6 +317,7 @@ def all_reduce_labels(ctx, comm: ShardComm, buf, n: int):
     if comm.world == 1:
         return
     if comm.on_device:
+        comm.make_room(ctx)
         t = comm.empty((n,), torch.uint8)
         one = (C.c_int * 3)(1, 1, n)
         st = (C.c_longlong * 3)(0, 0, 1)

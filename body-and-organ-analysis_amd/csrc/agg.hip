@@ -945,9 +945,15 @@ extern "C" int boa_ccl26(boa_ctx* c, const uint8_t* dev_mask, int Z, int Y, int 
     // synchronise (the BCA post-processing chains 16 of these per volume)
     int* d_count = nullptr;
     BOA_TRY(boa_malloc(c, sizeof(int), (void**)&d_count));
-    BOA_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
     static const bool flat = getenv("BOA_CCL_FLAT") != nullptr;  // the one-level version (A/B switch)
-    if (flat) BOA_HIP_TRY(hipMemsetAsync(dev_sizes, 0, n * sizeof(uint32_t), c->stream));
+    {   // (an early return must hand the pooled counter back)
+        hipError_t e0 = hipMemsetAsync(d_count, 0, sizeof(int), c->stream);
+        if (e0 == hipSuccess && flat) e0 = hipMemsetAsync(dev_sizes, 0, n * sizeof(uint32_t), c->stream);
+        if (e0 != hipSuccess) {
+            boa_free(c, d_count);
+            BOA_HIP_TRY(e0);
+        }
+    }
     unsigned grid = (unsigned)((n + 255) / 256);
     KernelTimer t(c, BOA_K_MORPH, 0, (double)n * 14.0);
     if (flat) {
@@ -1016,7 +1022,13 @@ extern "C" int boa_ccl_filter_largest(boa_ctx* c, const int32_t* dev_roots, cons
     if (n == 0) return BOA_OK;
     unsigned long long* d_best = nullptr;
     BOA_TRY(boa_malloc(c, sizeof(unsigned long long), (void**)&d_best));   // (pooled: no synchronisation around the two kernels)
-    BOA_HIP_TRY(hipMemsetAsync(d_best, 0, sizeof(unsigned long long), c->stream));
+    {
+        const hipError_t e0 = hipMemsetAsync(d_best, 0, sizeof(unsigned long long), c->stream);
+        if (e0 != hipSuccess) {   // (an early return must hand the pooled block back)
+            boa_free(c, d_best);
+            BOA_HIP_TRY(e0);
+        }
+    }
     unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_ccl_best, dim3(std::min<unsigned>(grid, (unsigned)c->cu_count * 8)), dim3(256), 0, c->stream, dev_sizes, n, d_best);
     hipLaunchKernelGGL(k_ccl_apply_largest, dim3(grid), dim3(256), 0, c->stream, dev_roots, n, d_best, dev_seg,

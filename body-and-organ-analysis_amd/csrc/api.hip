@@ -104,8 +104,14 @@ static size_t pool_round(size_t bytes) {
 extern "C" int boa_malloc(boa_ctx* c, size_t bytes, void** dev_out) {
     BOA_REQUIRE(c && dev_out, "boa_malloc: NULL argument");
     if (c->pool_cap == 0) {
+        // cap of the parked bytes: $BOA_POOL_GB, else 48 GB but never more than a sixth of the device's memory (torch / RCCL
+        // allocations of the same process cannot reclaim parked blocks: the sharded paths call boa_trim before collectives)
         const char* e = getenv("BOA_POOL_GB");
-        const double gb = e ? atof(e) : 48.0;
+        double gb = e ? atof(e) : 48.0;
+        if (!e) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) gb = std::min(gb, (double)tot / 6.0 / (double)(1ull << 30));
+        }
         c->pool_cap = gb > 0 ? (size_t)(gb * (double)(1ull << 30)) : 1;  // 1 byte: nothing is ever parked
     }
     const size_t sz = pool_round(bytes);
