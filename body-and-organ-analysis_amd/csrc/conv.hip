@@ -730,11 +730,41 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
     // fetch() issues the loads into registers, commit() converts and writes them to the other LDS buffer afterwards
     constexpr int NPRE = (HV + 255) / 256;
     float pre[NPRE];
+    // this thread's halo voxels (tile independent): packed coordinates x | y << 8 | z << 16 and the voxel's linear offset in the
+    // volume relative to the halo origin -- the per-tile gather is then three range tests and one add per element (the first
+    // version decomposed the index and rebuilt a 64-bit address per element and tile: ~80 instructions each, as much as the
+    // tile's MFMA + epilogue work)
+    int hc[NPRE], hrel[NPRE];
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+        const int i = min(tid + 256 * j, HV - 1);
+        const int z = i % H2, r = i / H2, y = r % H1, x = r / H1;
+        hc[j] = x | (y << 8) | (z << 16);
+        hrel[j] = (x * p.V1 + y) * p.V2 + z;
+    }
     auto fetch = [&](const Seq& q) {
         int sp = q.sp;
         const int tz = sp % p.t2;
         sp /= p.t2;
         const int ty = sp % p.t1, tx = sp / p.t1;
+        if (p.vol && p.flip == 0) {
+            // halo origin in patch coordinates (conv padding 1) and in the volume; valid halo range per axis: inside the patch
+            // (conv / tile padding reads zero) and inside the volume (pad_nd_image zeros)
+            const int bx = tx * MF0 - 1, by = ty * MF1 - 1, bz = tz * MF2 - 1;
+            const int ox = p.origins[q.n * 3 + 0] - p.o0 + bx, oy = p.origins[q.n * 3 + 1] - p.o1 + by, oz = p.origins[q.n * 3 + 2] - p.o2 + bz;
+            const int xl = max(-bx, -ox), xh = min(p.P0 - bx, p.V0 - ox);      // halo x valid iff xl <= x < xh
+            const int yl = max(-by, -oy), yh = min(p.P1 - by, p.V1 - oy);
+            const int zl = max(-bz, -oz), zh = min(p.P2 - bz, p.V2 - oz);
+            const float* base = p.vol + ((ptrdiff_t)ox * p.V1 + oy) * p.V2 + oz;
+#pragma unroll
+            for (int j = 0; j < NPRE; ++j) {
+                const int x = hc[j] & 255, y = (hc[j] >> 8) & 255, z = hc[j] >> 16;
+                const bool ok = (unsigned)(x - xl) < (unsigned)max(xh - xl, 0) && (unsigned)(y - yl) < (unsigned)max(yh - yl, 0) &&
+                                (unsigned)(z - zl) < (unsigned)max(zh - zl, 0);
+                pre[j] = ok ? base[hrel[j]] : 0.f;
+            }
+            return;
+        }
         if (p.vol) {
             // patch coordinates of the halo origin (conv padding 1) and the tile's position in the volume
             const int bx = tx * MF0 - 1, by = ty * MF1 - 1, bz = tz * MF2 - 1;
@@ -818,10 +848,16 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
                 v[gq * 4 + 2] = acc[gq * 4 + 2] + bq[gq].z;
                 v[gq * 4 + 3] = acc[gq * 4 + 3] + bq[gq].w;
             }
+            // packed fp32 statistics (v_pk_add_f32 / v_pk_fma_f32: the same operations per entry, two entries per instruction)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                st_s[i] += v[i];
-                st_q[i] = __builtin_fmaf(v[i], v[i], st_q[i]);
+            for (int i = 0; i < 8; ++i) {
+                typedef float cf2 __attribute__((ext_vector_type(2)));
+                const cf2 vv = cf2{v[2 * i], v[2 * i + 1]};
+                cf2 s2 = cf2{st_s[2 * i], st_s[2 * i + 1]}, q2 = cf2{st_q[2 * i], st_q[2 * i + 1]};
+                s2 = s2 + vv;
+                q2 = __builtin_elementwise_fma(vv, vv, q2);
+                st_s[2 * i] = s2.x; st_s[2 * i + 1] = s2.y;
+                st_q[2 * i] = q2.x; st_q[2 * i + 1] = q2.y;
             }
             unsigned w8[8];
 #pragma unroll
@@ -833,14 +869,21 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
                     lo4[e] = __uint_as_float(sw[0]);
                     hi4[e] = __uint_as_float(sw[1]);
                 }
-                union {
-                    unsigned u;
-                    __half h[2];
-                } c;
-                c.h[0] = __float2half_rn(lo4[0]); c.h[1] = __float2half_rn(lo4[1]); w8[pr * 4 + 0] = c.u;
-                c.h[0] = __float2half_rn(lo4[2]); c.h[1] = __float2half_rn(lo4[3]); w8[pr * 4 + 1] = c.u;
-                c.h[0] = __float2half_rn(hi4[0]); c.h[1] = __float2half_rn(hi4[1]); w8[pr * 4 + 2] = c.u;
-                c.h[0] = __float2half_rn(hi4[2]); c.h[1] = __float2half_rn(hi4[3]); w8[pr * 4 + 3] = c.u;
+                // one v_cvt_pk_f16_f32 (RTNE, same rounding as __float2half_rn) per output word
+                typedef float cvf2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 cvh2 __attribute__((ext_vector_type(2)));
+                auto pk = [](float a, float b) {
+                    union {
+                        cvh2 v;
+                        unsigned u;
+                    } c;
+                    c.v = __builtin_convertvector(cvf2{a, b}, cvh2);
+                    return c.u;
+                };
+                w8[pr * 4 + 0] = pk(lo4[0], lo4[1]);
+                w8[pr * 4 + 1] = pk(lo4[2], lo4[3]);
+                w8[pr * 4 + 2] = pk(hi4[0], hi4[1]);
+                w8[pr * 4 + 3] = pk(hi4[2], hi4[3]);
             }
             // chunk-planar [N][2][voxel][16]: lane (voxel, kh) owns plane kh -> a wave stores two runs of 1 KiB
             __half* dst = p.out + ((size_t)(n * 2 + kh) * ovox + ((size_t)(tx * MF0 + x) * p.P1 + ty * MF1 + y) * p.P2 + tz * MF2 + l31) * 16;
