@@ -73,6 +73,8 @@ _PROTOS = {
     "boa_net_set_mirroring": (i32, [vp, i32]),
     "boa_net_forward": (i32, [vp, vp, ip, ip, i32, vp]),
     "boa_net_predict_sliding_window": (i32, [vp, vp, ip, ip, ip, ip, i32, vp, vp, vp]),
+    "boa_net_labels_supported": (i32, [vp, ip, i32]),
+    "boa_net_predict_labels_fold": (i32, [vp, vp, ip, ip, ip, ip, i32, vp, vp, i32, i32, vp, i32, vp, ip, ip, vp]),
     "boa_conv_block_test": (i32, [vp, vp, i32, i32, ip, vp, vp, vp, vp, i32, ip, ip, i32, i32, vp]),
     "boa_convtranspose_test": (i32, [vp, vp, i32, i32, ip, vp, vp, i32, ip, vp]),
     "boa_tissue_aggregate": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),

@@ -57,6 +57,9 @@ class HipPredictor:
         self._net = None
         self._gauss_dev: Optional[DeviceBuffer] = None
         self._loaded_fold = None
+        # label-only path: gather form of the tile loop (boa_net_predict_labels_fold) when the network / tile layout qualifies;
+        # False keeps the scatter loop (one fused head launch per tile into fp16 accumulator planes)
+        self.use_gather_head = True
         ctx.register(self)
 
     # ---- model management ---------------------------------------------------------------------------
@@ -214,9 +217,6 @@ class HipPredictor:
                 work[name] = b
             return b
 
-        acc = buf("acc", C_ * nvox * 2)
-        nacc = buf("n", nvox * 2)
-        fold = buf("fold", C_ * nvox * 2) if nf > 1 else None
         flag = buf("flag", 4)
         flag.zero()
         lut_arr = None
@@ -226,6 +226,16 @@ class HipPredictor:
         lut_p = lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None
         crop = any(b != 0 for b in below) or list(PV) != list(V)
         direct = resample_to is None
+        if direct and self.use_gather_head and self._predict_labels_fused(dvol, V, PV, below, origins, labels_out, lut_p, merge, crop, flag, buf):
+            if int(flag.download((1,), np.int32)[0]):
+                raise RuntimeError("Encountered inf in predicted array. Aborting...")
+            if own:
+                for b in work.values():
+                    b.free()
+            return
+        acc = buf("acc", C_ * nvox * 2)
+        nacc = buf("n", nvox * 2)
+        fold = buf("fold", C_ * nvox * 2) if nf > 1 else None
         for f in range(nf):
             self._run_fold(dvol, V, PV, below, origins, acc, nacc, f)
             last = f == nf - 1
@@ -246,6 +256,31 @@ class HipPredictor:
         if own:
             for b in work.values():
                 b.free()
+
+    def _predict_labels_fused(self, dvol, V, PV, below, origins, labels_out, lut_p, merge, crop, flag, buf) -> bool:
+        """The gather form of the tile loop (boa_net_predict_labels_fold): every tile's last decoder activation goes to a stash,
+        one pass per fold walks the volume with the fp16 running sums in registers and ends in the labels -- no accumulator
+        planes.  Same arithmetic and rounding order as the scatter loop below (labels bit-identical).  False = not applicable
+        (exact mode, mirroring, > 32 classes, features[0] != 32, irregular tile list, stash does not fit): the caller runs
+        the scatter loop."""
+        nf = len(self.list_of_parameters)
+        self._ensure_net(0)
+        op = origins.ctypes.data_as(C.POINTER(C.c_int))
+        if not self.lib.boa_net_labels_supported(self._net, op, origins.shape[0]):
+            return False
+        C_, nvox = self.geom.num_classes, int(np.prod(PV))
+        fold = buf("fold", C_ * nvox * 2) if nf > 1 else None
+        g = self._gaussian()
+        for f in range(nf):
+            self._ensure_net(f)
+            rc = self.lib.boa_net_predict_labels_fold(
+                self._net, dvol.vp, int3(V), int3(PV), int3(below), op, origins.shape[0], g.vp if g else None,
+                fold.vp if fold else None, f, nf, lut_p, 1 if merge else 0, labels_out.vp, int3(below) if crop else None,
+                int3(V) if crop else None, flag.vp)
+            if rc == -3 and f == 0:      # BOA_ENOMEM: the stash does not fit -> scatter loop
+                return False
+            check(rc, "boa_net_predict_labels_fold")
+        return True
 
     def _predict_segmentation_sharded(self, dvol, V, labels_out, lut, merge, work, shard, resample_to=None):
         from . import tile_shard as ts

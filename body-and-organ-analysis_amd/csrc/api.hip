@@ -57,6 +57,7 @@ extern "C" void boa_destroy(boa_ctx* c) {
     for (auto& r : c->ws_runs) hipFree(r.second);
     for (auto& b : c->pool_free) hipFree(b.second);
     for (auto& b : c->pool_live) hipFree(b.first);  // buffers the caller never freed
+    if (c->stash) hipFree(c->stash);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }

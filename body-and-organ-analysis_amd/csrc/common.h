@@ -71,6 +71,10 @@ struct boa_ctx {
     std::unordered_map<void*, size_t> pool_live;
     size_t pool_bytes = 0;          // bytes parked in pool_free
     size_t pool_cap = 0;            // 0 = not initialised (BOA_POOL_GB, default 48; 0 disables pooling)
+    // stash of the fused sliding-window head (boa_net_predict_labels_fold): the last decoder activation of every tile of the
+    // current volume; grow-only, shared by the context's networks (they run one after the other on the stream)
+    void* stash = nullptr;
+    size_t stash_bytes = 0;
 };
 int boa_malloc_raw(boa_ctx* c, size_t bytes, void** dev_out);
 

@@ -1239,6 +1239,137 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
     }
 }
 
+// Register-weights variant for Cin = 16 NCC <= 128 (the 32^3 -> 64^3 and 64^3 -> 128^3 transposed convs, 75 % of the class's
+// time): a wave covers G groups of 32 input voxels, staged once into its LDS slice, and per (x tap, y tap, cout chunk) pass loads
+// the pass's TZ x NCC weight fragments ONCE into registers for all G groups.  k_convt_mfma re-reads them from L2 for every 32
+// voxels: 1 KiB of weights per input voxel of the 64 -> 32 layer against 640 bytes of activations moved -- the kernel was bound
+// by L2 -> CU weight traffic, not by HBM.  Same arithmetic, same output order.
+template <int TZ, int NCC, int G>
+__global__ __launch_bounds__(256) void k_convt_mfma_rw(ConvTArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int kh = lane >> 5;
+    const unsigned in_vox = (unsigned)(p.Di * p.Hi * p.Wi);
+    const unsigned total = (unsigned)p.N * in_vox;
+    constexpr int SLAB = 2 * 32 * TZ * 32;  // bytes: [2 planes][32 * TZ output voxels][16 halves]
+    unsigned char* lds = smem + (size_t)wave * (G * NCC * 1024 + SLAB);  // [g][cc][khalf][32 voxels][8 halves] + slab
+    unsigned char* slab = lds + G * NCC * 1024;
+    const unsigned g0 = ((unsigned)blockIdx.x * 4 + wave) * (32 * G);  // first flattened (n, voxel) of this wave
+    union {
+        unsigned u;
+        ct_h2 v;
+    } sl2;
+    sl2.v = ct_h2{(_Float16)p.slope, (_Float16)p.slope};
+    // stage the wave's G x 32 voxels with the deferred norm applied
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const unsigned gv = g0 + 32 * g + l31;
+        const bool valid = gv < total;
+        const unsigned n = valid ? gv / in_vox : 0;
+        const unsigned vi = valid ? gv - n * in_vox : 0;
+        const __half* src_l = p.src + ((size_t)n * NCC * in_vox + vi) * 16 + kh * 8;
+        const unsigned* ss16_l = p.ss16 ? p.ss16 + ((size_t)n * p.Cin + kh * 8) : nullptr;
+        uint4 val[NCC];
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) val[cc] = *(const uint4*)(src_l + (size_t)cc * in_vox * 16);
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+            uint4 o = val[cc];
+            if (ss16_l) {
+                const uint4 w0 = *(const uint4*)(ss16_l + cc * 16), w1 = *(const uint4*)(ss16_l + cc * 16 + 4);
+                o = convt_norm_act8_pk(o, w0, w1, sl2.u);
+            }
+            if (!valid) o = make_uint4(0, 0, 0, 0);
+            *(uint4*)(lds + (((g * NCC + cc) * 2 + kh) * 32 + l31) * 16) = o;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int Ho = p.Hi * p.s1, Wo = p.Wi * p.s2;
+    const size_t ovox = (size_t)(p.Di * p.s0) * Ho * Wo;
+    const int nco = p.Cout / 32;
+    const int npairs = p.s0 * p.s1 * nco;
+    // store side (per group): this lane's pieces lane + 64 k of each plane of the slab (see k_convt_mfma)
+    unsigned char* optr[G][TZ];
+    unsigned ovalid = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int k = 0; k < TZ; ++k) {
+            const int ov = (lane + 64 * k) >> 1;
+            const int j = ov / TZ, tz = ov % TZ;
+            const unsigned gg = g0 + 32 * g + j;
+            const bool ok = gg < total;
+            ovalid |= ok ? (1u << (g * TZ + k)) : 0u;
+            const unsigned nn = ok ? gg / in_vox : 0;
+            const unsigned v2 = ok ? gg - nn * in_vox : 0;
+            const unsigned r2 = v2 / (unsigned)p.Wi;
+            const int iz = (int)(v2 - r2 * (unsigned)p.Wi);
+            const int ix = (int)(r2 / (unsigned)p.Hi), iy = (int)(r2 - (unsigned)ix * (unsigned)p.Hi);
+            const size_t ospat = ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2 + tz);
+            optr[g][k] = (unsigned char*)p.out + ((size_t)nn * (p.Cout / 16) * ovox + ospat) * 32 + 16 * (lane & 1);
+        }
+    const unsigned char* wbase = (const unsigned char*)p.wpk;
+    const unsigned wlane = ((unsigned)kh * (unsigned)p.Cout + (unsigned)l31) * 16u;
+    const unsigned wstep_cc = 2u * (unsigned)p.Cout * 16u;  // bytes per (tap, chunk)
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int pr = blockIdx.y; pr < npairs; pr += gridDim.y) {
+        const int txy = pr / nco, co = pr - txy * nco;
+        const int ty = txy % p.s1, tx = txy / p.s1;
+        float4 bq[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) bq[gq] = *(const float4*)(p.bias + co * 32 + 8 * gq + 4 * kh);
+        const int tap0 = (tx * p.s1 + ty) * p.s2;
+        const unsigned char* wpass = wbase + ((size_t)tap0 * NCC * wstep_cc + (size_t)co * 32 * 16);  // uniform
+        f16x8 a[TZ][NCC];   // the pass's weights, once for all G groups
+#pragma unroll
+        for (int t = 0; t < TZ; ++t)
+#pragma unroll
+            for (int cc = 0; cc < NCC; ++cc) a[t][cc] = *(const f16x8*)(wpass + (size_t)(t * NCC + cc) * wstep_cc + wlane);
+        const size_t poff = ((size_t)(co * 2) * ovox + ((size_t)tx * Ho + ty) * Wo) * 32;  // uniform; plane pl adds ovox * 32
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            f32x16 acc[TZ];
+            const unsigned char* bfrag = lds + ((g * NCC * 2 + kh) * 32 + l31) * 16;  // + cc * 1024
+#pragma unroll
+            for (int cc = 0; cc < NCC; ++cc) {
+                const f16x8 bf = *(const f16x8*)(bfrag + cc * 1024);
+#pragma unroll
+                for (int t = 0; t < TZ; ++t)
+                    acc[t] = cc == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][cc], bf, zero, 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t][cc], bf, acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+                for (int t = 0; t < TZ; ++t) {
+                    union {
+                        uint2 u;
+                        __half h[4];
+                    } pk;
+                    pk.h[0] = __float2half_rn(acc[t][gq * 4 + 0] + bq[gq].x);
+                    pk.h[1] = __float2half_rn(acc[t][gq * 4 + 1] + bq[gq].y);
+                    pk.h[2] = __float2half_rn(acc[t][gq * 4 + 2] + bq[gq].z);
+                    pk.h[3] = __float2half_rn(acc[t][gq * 4 + 3] + bq[gq].w);
+                    *(uint2*)(slab + ((gq >> 1) * 32 * TZ + l31 * TZ + t) * 32 + (8 * (gq & 1) + 4 * kh) * 2) = pk.u;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int k = 0; k < TZ; ++k) {
+                    const int piece = lane + 64 * k;
+                    const uint4 d = *(const uint4*)(slab + pl * 32 * TZ * 32 + piece * 16);
+                    if ((ovalid >> (g * TZ + k)) & 1u) *(uint4*)(optr[g][k] + poff + (size_t)pl * ovox * 32) = d;
+                }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], const int s[3], int Cout,
                       const __half* wpk, const float* bias, float slope, __half* out) {
     BOA_REQUIRE(src.C % 16 == 0 && Cout % 32 == 0, "convT: channels %d -> %d unsupported", src.C, Cout);
@@ -1262,7 +1393,24 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
     (void)once;
     const double taps = (double)s[0] * s[1] * s[2];
     KernelTimer tm(ctx, BOA_K_CONVT, 2.0 * total * taps * src.C * Cout, 2.0 * total * (src.C + taps * Cout));
-    if (s[2] == 2)
+    static const bool no_rw = getenv("BOA_CONVT_NO_RW") != nullptr;
+    const bool rw = !no_rw && s[2] == 2 && src.ss16 != nullptr && (src.C == 64 || src.C == 128);
+    if (rw) {
+        // register-weights variant: 4 groups of 32 voxels per wave (512 voxels per block)
+        constexpr int G = 4;
+        const int gxr = (int)((total + 128 * G - 1) / (128 * G));
+        const int gyr = std::min(npairs, std::max(1, ceil_div(gy_mult * ctx->cu_count, gxr)));
+        const size_t ldsr = (size_t)4 * ((size_t)G * (src.C / 16) * 1024 + 2 * 32 * 2 * 32);
+        if (src.C == 64) {
+            static bool o1 = (hipFuncSetAttribute((const void*)k_convt_mfma_rw<2, 4, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+            (void)o1;
+            hipLaunchKernelGGL((k_convt_mfma_rw<2, 4, G>), dim3(gxr, gyr), dim3(256), ldsr, ctx->stream, a);
+        } else {
+            static bool o2 = (hipFuncSetAttribute((const void*)k_convt_mfma_rw<2, 8, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+            (void)o2;
+            hipLaunchKernelGGL((k_convt_mfma_rw<2, 8, G>), dim3(gxr, gyr), dim3(256), ldsr, ctx->stream, a);
+        }
+    } else if (s[2] == 2)
         hipLaunchKernelGGL(k_convt_mfma<2>, dim3(gx, gy), dim3(256), lds, ctx->stream, a);
     else
         hipLaunchKernelGGL(k_convt_mfma<1>, dim3(gx, gy), dim3(256), lds, ctx->stream, a);

@@ -1,0 +1,334 @@
+// Fused head of the sliding window: 1x1x1 conv + Gaussian weighting + fp16 accumulation over ALL covering tiles + normalisation +
+// fold sum / mean + argmax + label remap in ONE pass over the volume ("gather" form of NN/inference/predict_from_raw_data.py:
+// 560-631 + export_prediction.py:14-71 for identity resampling).
+//
+// The reference adds tile after tile into fp16 accumulators (`predicted_logits[sl] += prediction * gaussian`,
+// `n_predictions[sl] += gaussian`, :611-614); the scatter form (k_head_mfma, one launch per tile in canonical order) therefore
+// reads and writes the C + 1 accumulator planes once per tile that covers a voxel -- 104 of its 170 bytes per voxel and tile --
+// and k_finalize_labels reads them once more.  Here the conv stack leaves the last decoder activation of EVERY tile of the
+// volume in a stash (16.8 GB for the 125 tiles of a 512^3 part model: HBM has room), and each wave takes 32 consecutive z voxels
+// of the volume, walks the tiles that cover them IN ASCENDING TILE INDEX (the reference's order, so every fp16 rounding happens
+// in the same sequence), computes the tile's logits for its voxels with the same two MFMAs as k_head_mfma and keeps the C + 1
+// running sums in registers: no accumulator planes exist at all, the only traffic is the stash read (66 B per voxel and covering
+// tile) and one label byte per voxel.  Arithmetic per (voxel, tile), identical to k_head_mfma / k_finalize_labels:
+//   x = lrelu(fma(act, scale, shift)) in packed fp16; logit = MFMA(w, x) + bias (fp32); pr = logit * g (fp32);
+//   acc = half(float(acc) + pr); n = half(float(n) + g);   then  q = half(float(acc) / float(n)), fold sum / mean in half,
+//   numpy argmax (first maximum, first NaN wins), lut / merge, crop.
+// Several folds: one pass per fold, the normalised logits of a fold are added into a [C][voxels] fp16 buffer (`fold`), the last
+// pass divides by the number of folds and takes the argmax (predict_from_raw_data.py:483-500).
+#include "conv.h"
+
+#ifndef GH_WAVES
+#define GH_WAVES 4
+#endif
+typedef _Float16 gh2_t __attribute__((ext_vector_type(2)));
+
+struct GatherArgs {
+    const __half* act;            // stash [tile][2 planes][pv][16 halves]: raw output of the last decoder conv
+    const unsigned* ssp;          // [tile][2 k-halves][16 words]: packed fp16 (scale, shift) of its InstanceNorm, k_head_mfma's layout
+    const float* w;               // [C][32] head weights (this fold)
+    const float* bias;            // [C]
+    const unsigned short* gauss;  // [pv] fp16 or nullptr (weight 1)
+    int C, P0, P1, P2, V0, V1, V2, n0, n1, n2;
+    const int* tab;               // device: [tile origins per axis: n0 + n1 + n2][cover of x: V0][cover of y: V1][cover of the z runs]
+                                  // cover word = first covering tile | count << 8 (host-built: the walk is scalar table look-ups)
+    unsigned short* fold;         // [C][V0 V1 V2] fp16 (several folds) or nullptr
+    int fold_mode;                // 0 single fold; 1 first of several (store); 2 middle (add); 3 last (add, / n_folds, argmax)
+    int n_folds;
+    unsigned char* labels;
+    int merge, crop, o0, o1, o2, c0, c1, c2;
+    int* inf_flag;
+    float slope;
+    int ss_in_lds;                // the packed (scale, shift) table of all tiles fits the dynamic LDS allocation
+    unsigned char lut[256];
+};
+
+// fp32 (scale, shift) [tile][32][2] -> the packed layout the head reads: [tile][kh][step 0: sc x4, sh x4 | step 1: sc x4, sh x4]
+__global__ void k_pack_head_ss(const float* __restrict__ ss, unsigned* __restrict__ out, int n_tiles) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles * 2) return;
+    const int tile = t >> 1, k = t & 1;
+    const float* s = ss + (size_t)tile * 64;
+    unsigned* o = out + (size_t)t * 16;
+    union {
+        unsigned u;
+        gh2_t v;
+    } cv;
+    for (int i = 0; i < 4; ++i) {
+        const int c0 = 8 * k + 2 * i, c1 = 16 + 8 * k + 2 * i;
+        cv.v = gh2_t{(_Float16)s[2 * c0], (_Float16)s[2 * c0 + 2]};
+        o[i] = cv.u;
+        cv.v = gh2_t{(_Float16)s[2 * c0 + 1], (_Float16)s[2 * c0 + 3]};
+        o[4 + i] = cv.u;
+        cv.v = gh2_t{(_Float16)s[2 * c1], (_Float16)s[2 * c1 + 2]};
+        o[8 + i] = cv.u;
+        cv.v = gh2_t{(_Float16)s[2 * c1 + 1], (_Float16)s[2 * c1 + 3]};
+        o[12 + i] = cv.u;
+    }
+}
+
+template <bool GAUSS, bool SSLDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8))) void k_gather_head(GatherArgs p) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    const int* __restrict__ sx = p.tab;
+    const int* __restrict__ sy = p.tab + p.n0;
+    const int* __restrict__ sz = p.tab + p.n0 + p.n1;
+    const int* __restrict__ cvx = sz + p.n2;
+    const int* __restrict__ cvy = cvx + p.V0;
+    const int* __restrict__ cvz = cvy + p.V1;
+    f16x8 a0, a1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a0[i] = l31 < p.C ? (_Float16)p.w[l31 * 32 + 8 * kh + i] : (_Float16)0.f;
+        a1[i] = l31 < p.C ? (_Float16)p.w[l31 * 32 + 16 + 8 * kh + i] : (_Float16)0.f;
+    }
+    // this lane's 16 biases (D-fragment rows 8 gq + 4 kh + e) live in LDS, re-read per tile pair: the kernel waits on HBM round
+    // trips, so VGPRs (waves in flight) matter more than four ds_read_b128 per pair
+    __shared__ __attribute__((aligned(16))) float s_bz[2][16];
+    if (threadIdx.x < 32) {
+        const int k = threadIdx.x >> 4, i = threadIdx.x & 15;
+        const int c = 8 * (i >> 2) + 4 * k + (i & 3);
+        s_bz[k][i] = c < p.C ? p.bias[c] : 0.f;
+    }
+    __syncthreads();
+    const gh2_t sl = gh2_t{(_Float16)p.slope, (_Float16)p.slope};
+    auto xform = [&](uint4 raw, uint4 scw, uint4 shw) {
+        union {
+            uint4 u;
+            gh2_t v[4];
+            f16x8 f;
+        } x, sc, sh;
+        x.u = raw;
+        sc.u = scw;
+        sh.u = shw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const gh2_t y = __builtin_elementwise_fma(x.v[i], sc.v[i], sh.v[i]);
+            x.v[i] = __builtin_elementwise_max(y, y * sl);
+        }
+        return x.f;
+    };
+    const size_t pv = (size_t)p.P0 * p.P1 * p.P2;
+    const size_t vv = (size_t)p.V0 * p.V1 * p.V2;
+    const int mpr = (p.V2 + 31) / 32;
+    // (32-bit run indices: 64-bit divisions cost ~100 instructions each; the host checks that the run count fits)
+    const unsigned n_mt = (unsigned)p.V0 * (unsigned)p.V1 * (unsigned)mpr;
+    const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), nw = gridDim.x * 4u;   // (wave-uniform: scalar tile walk)
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // every tile's packed (scale, shift) table in LDS (128 B per tile) when it fits (SSLDS): four ds_read_b128 per (run, tile)
+    // pair instead of four L2 round trips
+    extern __shared__ __attribute__((aligned(16))) unsigned s_ssp[];
+    if (SSLDS) {
+        const int n_tiles = p.n0 * p.n1 * p.n2;
+        for (int i = threadIdx.x; i < n_tiles * 8; i += 256) ((uint4*)s_ssp)[i] = ((const uint4*)p.ssp)[i];
+        __syncthreads();
+    }
+    typedef __attribute__((address_space(1))) const unsigned char* gptr_t;
+    typedef unsigned gu4_t __attribute__((ext_vector_type(4)));
+    auto gload4 = [](gptr_t b, unsigned off) {
+        const gu4_t v = *(const __attribute__((address_space(1))) gu4_t*)(b + off);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    bool any_inf = false;
+    for (unsigned mt = gw; mt < n_mt; mt += nw) {
+        const unsigned row = mt / (unsigned)mpr;
+        const int zb = (int)(mt - row * (unsigned)mpr) * 32;
+        const int x = (int)(row / (unsigned)p.V1), y = (int)(row - (unsigned)(row / (unsigned)p.V1) * (unsigned)p.V1);
+        const int z = zb + l31;
+        const bool zvalid = z < p.V2;
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float nacc = 0.f;
+        // covering tiles in ascending tile index: x outermost, z innermost (predict_from_raw_data.py:506-538)
+        // (wave-uniform table look-ups: scalar loads; the first version scanned the origins in LDS and divided per pair -- the walk
+        //  alone took 5 of the kernel's 9.6 ms per 512^3 part model)
+        const int wx = cvx[x], wy = cvy[y], wz = cvz[zb >> 5];
+        const int fx = wx & 255, cx = wx >> 8, fy = wy & 255, cy = wy >> 8, fz = wz & 255, cz = wz >> 8;
+        for (int ix = fx; ix < fx + cx; ++ix) {
+            const int dx = x - sx[ix];
+            for (int iy = fy; iy < fy + cy; ++iy) {
+                const int dy = y - sy[iy];
+                const unsigned rowoff = (unsigned)(dx * p.P1 + dy) * (unsigned)p.P2;   // tile-relative voxel index of (dx, dy, 0)
+                const unsigned tile0 = (unsigned)((ix * p.n1 + iy) * p.n2);
+                for (int iz = fz; iz < fz + cz; ++iz) {
+                    const int tz0 = sz[iz];
+                    const bool in = zvalid && z >= tz0 && z < tz0 + p.P2;
+                    const unsigned tile = tile0 + (unsigned)iz;
+                    const unsigned tvl = rowoff + (unsigned)(in ? z - tz0 : 0);
+                    // wave-uniform 64-bit base + 32-bit lane offset (scalar-base global loads)
+                    gptr_t ab = (gptr_t)p.act + (size_t)tile * 2 * pv * 32;
+                    asm volatile("" : "+s"(ab));
+                    unsigned o0 = tvl * 32u + (unsigned)kh * 16u;
+                    asm volatile("" : "+v"(o0));
+                    const uint4 r0 = gload4(ab, o0);
+                    gptr_t ab1 = ab + pv * 32;
+                    asm volatile("" : "+s"(ab1));
+                    unsigned o1 = o0;
+                    asm volatile("" : "+v"(o1));
+                    const uint4 r1 = gload4(ab1, o1);
+                    float g = 1.0f;
+                    if (GAUSS) {
+                        gptr_t gb = (gptr_t)p.gauss;
+                        asm volatile("" : "+s"(gb));
+                        unsigned og = tvl * 2u;
+                        asm volatile("" : "+v"(og));
+                        g = us2f(*(const __attribute__((address_space(1))) unsigned short*)(gb + og));
+                    }
+                    uint4 sc0, sh0, sc1, sh1;
+                    if (SSLDS) {
+                        const uint4* sw = (const uint4*)(s_ssp + (tile * 2 + kh) * 16);
+                        sc0 = sw[0]; sh0 = sw[1]; sc1 = sw[2]; sh1 = sw[3];
+                    } else {
+                        const uint4* sw = (const uint4*)(p.ssp + ((size_t)tile * 2 + kh) * 16);
+                        sc0 = sw[0]; sh0 = sw[1]; sc1 = sw[2]; sh1 = sw[3];
+                    }
+                    f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xform(r0, sc0, sh0), zero, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xform(r1, sc1, sh1), d, 0, 0, 0);
+                    if (in) {
+                        // two entries per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_cvt_pk_f16_f32): the same fp32 operations
+                        // and RTNE roundings per entry -- the kernel is VALU-bound (~700 wave instructions per 32-voxel run)
+                        typedef float gf2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const gf2_t sum = gf2_t{d[2 * i], d[2 * i + 1]} + gf2_t{s_bz[kh][2 * i], s_bz[kh][2 * i + 1]};
+                            const gf2_t pr = GAUSS ? sum * gf2_t{g, g} : sum;                    // prediction *= gaussian (fp32)
+                            const gf2_t t = gf2_t{acc[2 * i], acc[2 * i + 1]} + pr;              // fp16 += fp32: fp32 add ...
+                            const gh2_t h = __builtin_convertvector(t, gh2_t);                   // ... RTNE to fp16
+                            acc[2 * i] = (float)h.x;
+                            acc[2 * i + 1] = (float)h.y;
+                        }
+                        nacc = us2f(f2us(nacc + g));
+                    }
+                }
+            }
+        }
+        // normalise, fold sum / mean, argmax (k_finalize_labels)
+        float best = 0.f;
+        int bidx = 1 << 20;
+        bool bnan = false, have = false;
+        const size_t vi = ((size_t)x * p.V1 + y) * p.V2 + z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
+            if (c >= p.C || !zvalid) continue;
+            unsigned short h = f2us(__fdiv_rn(acc[i], nacc));   // torch.div(half, half): fp32 divide, RTNE to half
+            if ((h & 0x7FFF) == 0x7C00) any_inf = true;
+            if (p.fold_mode != 0) {
+                unsigned short* fp = p.fold + (size_t)c * vv + vi;
+                if (p.fold_mode >= 2) h = f2us(us2f(*fp) + us2f(h));                                  // prediction += fold
+                if (p.fold_mode == 3 && p.n_folds > 1) h = f2us(__fdiv_rn(us2f(h), (float)p.n_folds));  // prediction /= n_folds
+                if (p.fold_mode != 3) {
+                    *fp = h;
+                    continue;
+                }
+            }
+            const float f = us2f(h);
+            const bool isn = f != f;
+            // numpy argmax over ascending classes: first maximum; the first NaN wins over everything
+            if (!have) {
+                best = f;
+                bidx = c;
+                bnan = isn;
+                have = true;
+            } else if (!bnan && (isn || f > best)) {
+                best = f;
+                bidx = c;
+                bnan = isn;
+            }
+        }
+        if (p.fold_mode == 1 || p.fold_mode == 2) continue;
+        // the voxel's other 16 classes live in lane ^ 32: combine (NaN first, then value, then the lower class index)
+        {
+            const float ob = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(bidx, 32);
+            const int on = __shfl_xor((int)bnan, 32);
+            const int oh = __shfl_xor((int)have, 32);
+            if (oh) {
+                bool take;
+                if (!have)
+                    take = true;
+                else if (bnan || on)
+                    take = on && (!bnan || oi < bidx);
+                else
+                    take = ob > best || (ob == best && oi < bidx);
+                if (take) {
+                    best = ob;
+                    bidx = oi;
+                }
+            }
+        }
+        if (kh == 0 && zvalid) {
+            int ox = x, oy = y, oz = z;
+            size_t oidx = vi;
+            bool inside = true;
+            if (p.crop) {
+                ox -= p.o0;
+                oy -= p.o1;
+                oz -= p.o2;
+                inside = ox >= 0 && oy >= 0 && oz >= 0 && ox < p.c0 && oy < p.c1 && oz < p.c2;
+                oidx = ((size_t)ox * p.c1 + oy) * p.c2 + oz;
+            }
+            if (inside) {
+                if (p.merge) {
+                    if (bidx != 0) p.labels[oidx] = p.lut[bidx];
+                } else {
+                    p.labels[oidx] = p.lut[bidx];
+                }
+            }
+        }
+    }
+    if (any_inf) atomicOr(p.inf_flag, 1);
+}
+
+int launch_pack_head_ss(boa_ctx* ctx, const float* ss, unsigned* out, int n_tiles) {
+    hipLaunchKernelGGL(k_pack_head_ss, dim3((unsigned)((n_tiles * 2 + 63) / 64)), dim3(64), 0, ctx->stream, ss, out, n_tiles);
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, const float* w, const float* bias, const uint16_t* gauss,
+                       int C, const int P[3], const int PV[3], const int ntile[3], const int* dev_tab, uint16_t* fold, int fold_mode,
+                       int n_folds, const uint8_t* host_lut, int merge, uint8_t* labels, const int* crop_off, const int* crop_dims,
+                       int* inf_flag, float slope, int tiles_total) {
+    BOA_REQUIRE(C >= 1 && C <= 32 && ntile[0] < 256 && ntile[1] < 256 && ntile[2] < 256, "gather head: C=%d / %d+%d+%d tiles per axis unsupported", C,
+                ntile[0], ntile[1], ntile[2]);
+    GatherArgs a;
+    a.act = act; a.ssp = ssp; a.w = w; a.bias = bias; a.gauss = gauss; a.C = C;
+    a.P0 = P[0]; a.P1 = P[1]; a.P2 = P[2]; a.V0 = PV[0]; a.V1 = PV[1]; a.V2 = PV[2];
+    a.n0 = ntile[0]; a.n1 = ntile[1]; a.n2 = ntile[2]; a.tab = dev_tab;
+    a.fold = fold; a.fold_mode = fold_mode; a.n_folds = n_folds; a.labels = labels; a.merge = merge;
+    a.crop = crop_off != nullptr;
+    a.o0 = a.o1 = a.o2 = 0;
+    a.c0 = PV[0]; a.c1 = PV[1]; a.c2 = PV[2];
+    if (crop_off) {
+        a.o0 = crop_off[0]; a.o1 = crop_off[1]; a.o2 = crop_off[2];
+        a.c0 = crop_dims[0]; a.c1 = crop_dims[1]; a.c2 = crop_dims[2];
+    }
+    a.inf_flag = inf_flag; a.slope = slope;
+    for (int i = 0; i < 256; ++i) a.lut[i] = host_lut ? host_lut[i] : (unsigned char)i;
+    const long long n_mt = (long long)PV[0] * PV[1] * ((PV[2] + 31) / 32);
+    BOA_REQUIRE(n_mt < (1ll << 31), "gather head: volume too large for 32-bit run indices");
+    const unsigned grid = (unsigned)std::min<long long>(std::max<long long>((n_mt + 3) / 4, 1), (long long)ctx->cu_count * 16);
+    // algorithmic bytes: every tile's stash is read once (64 B activation + 2 B Gaussian per voxel), one label byte per voxel
+    // (+ the fold buffer's read-modify-write)
+    const double pvd = (double)P[0] * P[1] * P[2], vvd = (double)PV[0] * PV[1] * PV[2];
+    const double bytes = (double)tiles_total * pvd * 66.0 + vvd * (fold_mode == 0 ? 1.0 : (fold_mode == 1 ? 2.0 * C : 4.0 * C));
+    const size_t ss_bytes = (size_t)tiles_total * 128;
+    a.ss_in_lds = ss_bytes <= 96 * 1024 ? 1 : 0;
+    static bool once = (hipFuncSetAttribute((const void*)k_gather_head<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
+    (void)once;
+    KernelTimer tm(ctx, BOA_K_HEAD_ACCUM, 2.0 * (double)tiles_total * pvd * 32 * C, bytes);
+    if (gauss && a.ss_in_lds)
+        hipLaunchKernelGGL((k_gather_head<true, true>), dim3(grid), dim3(256), ss_bytes, ctx->stream, a);
+    else if (gauss)
+        hipLaunchKernelGGL((k_gather_head<true, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    else if (a.ss_in_lds)
+        hipLaunchKernelGGL((k_gather_head<false, true>), dim3(grid), dim3(256), ss_bytes, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_gather_head<false, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    tm.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}

@@ -658,6 +658,133 @@ extern "C" int boa_net_predict_sliding_window(boa_net* net, const float* dev_vol
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Fused sliding window -> labels (head_gather.hip): the conv stack writes the last decoder activation of EVERY tile of the
+// volume into the context's stash, then one gather pass per fold walks the volume.  Conditions (else the caller uses
+// boa_net_predict_sliding_window + boa_finalize_labels): production precision, no test-time mirroring, features[0] == 32,
+// <= 32 classes, tile origins = the full cartesian grid of per-axis steps in canonical (x outer, z inner) order.
+static bool grid_origins(const int* o, int n, std::vector<int> (&steps)[3]) {
+    for (int a = 0; a < 3; ++a) steps[a].clear();
+    if (n < 1) return false;
+    // canonical order: the last axis varies fastest
+    for (int t = 0; t < n && (t == 0 || o[t * 3 + 2] > o[(t - 1) * 3 + 2]); ++t) steps[2].push_back(o[t * 3 + 2]);
+    const int n2 = (int)steps[2].size();
+    if (n % n2) return false;
+    for (int t = 0; t < n; t += n2) {
+        if (t > 0 && o[t * 3 + 1] <= o[(t - n2) * 3 + 1]) break;
+        steps[1].push_back(o[t * 3 + 1]);
+    }
+    const int n1 = (int)steps[1].size();
+    if (n % (n1 * n2)) return false;
+    for (int t = 0; t < n; t += n1 * n2) steps[0].push_back(o[t * 3]);
+    const int n0 = (int)steps[0].size();
+    if ((long long)n0 * n1 * n2 != n) return false;
+    for (int a = 0; a < 3; ++a)
+        for (size_t i = 1; i < steps[a].size(); ++i)
+            if (steps[a][i] <= steps[a][i - 1]) return false;
+    for (int t = 0; t < n; ++t) {
+        const int iz = t % n2, iy = (t / n2) % n1, ix = t / (n1 * n2);
+        if (o[t * 3] != steps[0][ix] || o[t * 3 + 1] != steps[1][iy] || o[t * 3 + 2] != steps[2][iz]) return false;
+    }
+    return n0 < 256 && n1 < 256 && n2 < 256;
+}
+
+extern "C" int boa_net_labels_supported(boa_net* net, const int* host_origins, int n_tiles) {
+    if (!net || !host_origins) return 0;
+    static const bool off = getenv("BOA_NO_GATHER_HEAD") != nullptr;
+    if (off || net->precision != 0 || net->mirror_mask != 0 || net->d.features[0] != 32 || net->d.num_classes > 32) return 0;
+    std::vector<int> steps[3];
+    return grid_origins(host_origins, n_tiles, steps) ? 1 : 0;
+}
+
+extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume, const int V[3], const int PV[3], const int* vol_off,
+                                           const int* host_origins, int n_tiles, const uint16_t* dev_gauss, uint16_t* dev_fold,
+                                           int fold_index, int n_folds, const uint8_t* host_lut, int merge, uint8_t* dev_labels_out,
+                                           const int* crop_off, const int* crop_dims, int* dev_inf_flag) {
+    BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_inf_flag, "boa_net_predict_labels_fold: NULL argument");
+    BOA_REQUIRE(boa_net_labels_supported(net, host_origins, n_tiles), "boa_net_predict_labels_fold: unsupported network / tile layout");
+    BOA_REQUIRE(n_folds >= 1 && fold_index >= 0 && fold_index < n_folds && (n_folds == 1 || dev_fold), "boa_net_predict_labels_fold: folds");
+    BOA_REQUIRE(fold_index + 1 < n_folds || dev_labels_out, "boa_net_predict_labels_fold: the last fold needs the label buffer");
+    boa_ctx* c = net->ctx;
+    const boa_net_desc& d = net->d;
+    const int zero[3] = {0, 0, 0};
+    const int* off = vol_off ? vol_off : zero;
+    for (int a = 0; a < 3; ++a)
+        BOA_REQUIRE(PV[a] >= d.patch[a] && off[a] >= 0 && off[a] + V[a] <= PV[a],
+                    "fused sliding window: padded dim %d (%d) must cover patch (%d) and volume (%d at %d)", a, PV[a], d.patch[a], V[a], off[a]);
+    std::vector<int> steps[3];
+    grid_origins(host_origins, n_tiles, steps);
+    const int F0 = d.features[0];
+    const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2];
+    // stash layout: [activations][fp32 ss][packed ss16 of the conv stack][head ss table][steps]
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_act = 0, o_ss = align((size_t)n_tiles * pv * F0 * sizeof(__half)), o_ss16 = align(o_ss + (size_t)n_tiles * F0 * 2 * sizeof(float)),
+                 o_ssp = align(o_ss16 + (size_t)n_tiles * F0 * sizeof(unsigned)), o_steps = align(o_ssp + (size_t)n_tiles * 32 * sizeof(unsigned)),
+                 need = align(o_steps + ((size_t)n_tiles + PV[0] + PV[1] + PV[2] + 64) * sizeof(int));
+    if (c->stash_bytes < need) {
+        BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->stash) hipFree(c->stash);
+        c->stash = nullptr;
+        c->stash_bytes = 0;
+        boa_trim(c);
+        if (hipMalloc(&c->stash, need) != hipSuccess) {
+            (void)hipGetLastError();
+            c->stash = nullptr;
+            boa_set_error("fused sliding window: %zu bytes of stash do not fit", need);
+            return BOA_ENOMEM;
+        }
+        c->stash_bytes = need;
+    }
+    unsigned char* base = (unsigned char*)c->stash;
+    __half* s_act = (__half*)(base + o_act);
+    float* s_ss = (float*)(base + o_ss);
+    unsigned* s_ss16 = (unsigned*)(base + o_ss16);
+    unsigned* s_ssp = (unsigned*)(base + o_ssp);
+    int* s_steps = (int*)(base + o_steps);
+    ConvLayer& last = net->dec.back().back();
+    __half* keep_out = last.out;
+    float* keep_ss = last.ss;
+    unsigned* keep_ss16 = last.ss16;
+    int rc = BOA_OK;
+    for (int t0 = 0; t0 < n_tiles && rc == BOA_OK; t0 += net->maxN) {
+        const int nb = std::min(net->maxN, n_tiles - t0);
+        // the last decoder conv of this batch writes straight into the stash slots of its tiles
+        last.out = s_act + (size_t)t0 * pv * F0;
+        last.ss = s_ss + (size_t)t0 * F0 * 2;
+        last.ss16 = s_ss16 + (size_t)t0 * F0;
+        rc = net_forward_stack(net, dev_volume, V, off, host_origins + (size_t)t0 * 3, nb);
+    }
+    last.out = keep_out;
+    last.ss = keep_ss;
+    last.ss16 = keep_ss16;
+    if (rc) return rc;
+    BOA_TRY(launch_pack_head_ss(c, s_ss, s_ssp, n_tiles));
+    // walk table: tile origins per axis, then per coordinate the first covering tile and the count (x, y), per 32-voxel z run the
+    // tiles that intersect the run
+    std::vector<int> tab;
+    for (int a = 0; a < 3; ++a)
+        for (int v : steps[a]) tab.push_back(v);
+    auto cover = [&](int a, int lo, int hi) {
+        int first = 0, cnt = 0;
+        for (size_t i = 0; i < steps[a].size(); ++i)
+            if (steps[a][i] <= hi && steps[a][i] + d.patch[a] > lo) {
+                if (!cnt) first = (int)i;
+                ++cnt;
+            }
+        return first | (cnt << 8);
+    };
+    for (int x = 0; x < PV[0]; ++x) tab.push_back(cover(0, x, x));
+    for (int y = 0; y < PV[1]; ++y) tab.push_back(cover(1, y, y));
+    for (int zb = 0; zb < PV[2]; zb += 32) tab.push_back(cover(2, zb, std::min(zb + 31, PV[2] - 1)));
+    BOA_HIP_TRY(hipMemcpyAsync(s_steps, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    BOA_HIP_TRY(hipStreamSynchronize(c->stream));   // (the table is a stack-lifetime host vector)
+    c->prof_break = true;
+    const int ntile[3] = {(int)steps[0].size(), (int)steps[1].size(), (int)steps[2].size()};
+    const int mode = n_folds == 1 ? 0 : (fold_index == 0 ? 1 : (fold_index + 1 == n_folds ? 3 : 2));
+    return launch_gather_head(c, s_act, s_ssp, net->head_w, net->head_b, dev_gauss, d.num_classes, d.patch, PV, ntile, s_steps, dev_fold, mode,
+                              n_folds, host_lut, merge, dev_labels_out, crop_off, crop_dims, dev_inf_flag, d.lrelu_slope, n_tiles);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // tile-sharded sliding window (several GPUs on one volume): the rank that owns tile rows [b0, b1) along
 // axis 0 cannot add the first `defer` planes of its row-b0 tiles before the lower rank's partial sums for those
 // planes have arrived (the reference's fp16 `+=` runs in ascending tile order per voxel).  The head input of those

@@ -200,6 +200,24 @@ int boa_net_predict_sliding_window(boa_net* net, const float* dev_volume, const 
                                    const int* vol_off, const int* host_origins, int n_tiles,
                                    const uint16_t* dev_gauss, uint16_t* dev_acc, uint16_t* dev_n);
 
+/* Fused form of the same loop for the label-only path (csrc/head_gather.hip): the conv stack leaves the last decoder activation
+ * of EVERY tile in a stash, then one pass over the volume walks, per voxel, the covering tiles in ascending tile index (the
+ * reference's `+=` order, predict_from_raw_data.py:611-614) with the running fp16 sums in registers and goes on to the
+ * normalisation, fold sum / mean (:483-500), argmax, label remap and crop of boa_finalize_labels -- the accumulator planes never
+ * exist.  Same arithmetic and rounding sequence as boa_net_predict_sliding_window + boa_finalize_labels (labels bit-identical;
+ * tests/test_gpu_gather_head.py).  One call per fold (after boa_net_load_weights), fold_index ascending:
+ *   dev_fold        fp16 [C][PV] scratch, n_folds > 1 only (the fold sum lives there between the calls)
+ *   dev_labels_out  written by the LAST fold's call (merge / lut / crop_off / crop_dims as in boa_finalize_labels)
+ *   dev_inf_flag    set non-zero if a normalised logit is +-inf (:622-625)
+ * boa_net_labels_supported: 1 when the network / tile layout qualifies (production precision, no mirroring, 32 features at
+ * full resolution, <= 32 classes, tile origins = the cartesian grid of compute_steps_for_sliding_window in canonical order).
+ * Returns BOA_ENOMEM when the stash (n_tiles x patch voxels x 64 B) does not fit: the caller falls back to the loop above. */
+int boa_net_labels_supported(boa_net* net, const int* host_origins, int n_tiles);
+int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume, const int V[3], const int PV[3], const int* vol_off,
+                                const int* host_origins, int n_tiles, const uint16_t* dev_gauss, uint16_t* dev_fold,
+                                int fold_index, int n_folds, const uint8_t* host_lut, int merge, uint8_t* dev_labels_out,
+                                const int* crop_off, const int* crop_dims, int* dev_inf_flag);
+
 /* ---- one volume on several GPUs (SURVEY 8e "tile partitioning"): each rank owns a block of tile rows along axis 0 ----
  * Same loop as boa_net_predict_sliding_window over THIS rank's tiles, except that for tile i the first
  * host_defer_planes[i] planes (axis 0) are not accumulated: their head input is kept in *stash_out.  The caller places

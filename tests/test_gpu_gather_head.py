@@ -1,0 +1,160 @@
+"""The gather form of the sliding-window tile loop (csrc/head_gather.hip, boa_net_predict_labels_fold): labels must be
+BIT-IDENTICAL to the scatter loop (boa_net_predict_sliding_window + boa_finalize_labels), which tests/test_gpu_head.py pins bit for
+bit to the reference's accumulate arithmetic (golden G3 geometries, 512^3) and test_gpu_seams.py to its argmax (G6).  Both walk
+every voxel's covering tiles in ascending tile index with the same fp32 add + RTNE rounding per step; the gather form keeps the
+running sums in registers instead of fp16 planes in HBM."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from boa_hip.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _pred(ctx, patch, nc, folds, step, gaussian=True, features=(32, 64), batch=3):
+    from boa_hip import plans
+    from boa_hip.predictor import HipPredictor
+    pj, dj = plans.synthetic_plans(patch=patch, features=features, num_classes=nc)
+    geom = plans.model_config_from_plans(pj, dj).geometry
+    p = HipPredictor(ctx, geom, tile_step_size=step, max_batch=batch, use_gaussian=gaussian)
+    p.set_parameters([plans.weight_blob_from_state_dict(geom, plans.synthetic_state_dict(geom, 40 + f)) for f in range(folds)])
+    return p
+
+
+@pytest.mark.parametrize("patch,shape,nc,folds,step,gaussian", [
+    ((32, 32, 32), (70, 50, 96), 5, 1, 0.5, True),        # 3 x 2 x 5 tiles, z a multiple of 32
+    ((32, 32, 32), (44, 40, 52), 27, 1, 0.8, True),       # 27 classes, step 0.8, z extent not a multiple of 32, odd origins
+    ((32, 32, 64), (33, 47, 150), 7, 3, 0.5, True),       # three folds: fp16 fold sum and mean
+    ((32, 32, 32), (20, 40, 45), 4, 2, 0.5, True),        # volume smaller than the patch on axis 0: pad_nd_image + crop
+    ((32, 64, 32), (64, 64, 64), 12, 1, 0.5, False),      # use_gaussian=False (weight 1)
+])
+def test_gather_labels_equal_scatter_labels(ctx, patch, shape, nc, folds, step, gaussian):
+    """Three results must coincide: (a) the gather form; (b) the ORACLE's tile loop (oracle.sliding_window: accumulate_tile /
+    finalize_logits / ensemble_folds / argmax, pinned to the reference by golden G3 / G3b / G6) fed with the device's own per-tile
+    fp32 logits (k_head_mfma's logits mode: the same MFMA / bias arithmetic); (c) the scatter form whenever it ran the MFMA head
+    (tile origins 8-aligned along z) -- with unaligned origins the scatter loop falls back to an fp32 VALU head whose logits
+    differ in the last bits, so (c) is then only required to agree on >= 99.9 % of the voxels."""
+    from oracle import labels as olab
+    from oracle import sliding_window as osw
+    from boa_hip import sliding_window as sw
+    p = _pred(ctx, patch, nc, folds, step, gaussian)
+    x = np.random.default_rng(sum(shape)).standard_normal((1, *shape)).astype(np.float32)
+    lut = (np.arange(nc) * 3 % 251).astype(np.uint8)
+    lut[0] = 0
+    ctx.counters(reset=True)
+    p.use_gather_head = False
+    want = p.predict_segmentation(x)
+    want_lut = p.predict_segmentation(x, lut=lut)
+    cs = ctx.counters(reset=True)
+    scatter_heads = cs["head_mfma"] + cs["head_valu"]
+    p.use_gather_head = True
+    got = p.predict_segmentation(x)
+    got_lut = p.predict_segmentation(x, lut=lut)
+    cnt = ctx.counters()
+    assert scatter_heads > 0 and cnt["head_mfma"] == 0 and cnt["head_valu"] == 0      # the gather path launched no per-tile head
+    assert len(np.unique(want)) > 2
+    # (b) oracle loop over the device's per-tile logits
+    PV, below = sw.pad_amounts(list(shape), list(patch))
+    origins = np.asarray(sw.get_sliding_window_origins(PV, list(patch), step), dtype=np.int32)
+    xp = np.zeros((1, *PV), np.float32)
+    xp[(slice(None),) + tuple(slice(b, b + v) for b, v in zip(below, shape))] = x
+    g = osw.compute_gaussian(tuple(patch), 1. / 8, 10) if gaussian else None
+    fold_logits = []
+    for f in range(folds):
+        p._ensure_net(f)
+        tiles = p.network_forward(xp, origins)
+        acc = np.zeros((nc, *PV), np.float16)
+        n = np.zeros(PV, np.float16)
+        for t, o in enumerate(origins):
+            osw.accumulate_tile(acc, n, tiles[t], g, tuple(int(v) for v in o))
+        fold_logits.append(osw.finalize_logits(acc, n))
+    logits = osw.ensemble_folds(fold_logits)
+    oracle_lab = olab.argmax_labels(logits)[tuple(slice(b, b + v) for b, v in zip(below, shape))]
+    p.close()
+    np.testing.assert_array_equal(got, oracle_lab)
+    np.testing.assert_array_equal(got_lut, lut[oracle_lab])
+    if cs["head_valu"] == 0:
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got_lut, want_lut)
+    else:
+        agree = float((got == want).mean())
+        print(f"scatter loop ran the VALU head ({cs['head_valu']} tiles): agreement with the gather form {agree:.5f}")
+        assert agree >= 0.999
+
+
+def test_gather_merge_into_existing_labels(ctx):
+    """merge=True (multi-model tasks, TS/nnunet.py:553-556): background never overwrites, later parts do."""
+    p = _pred(ctx, (32, 32, 32), 6, 1, 0.5)
+    shape = (48, 40, 64)
+    x = np.random.default_rng(3).standard_normal((1, *shape)).astype(np.float32)
+    lut = np.array([0, 11, 12, 13, 14, 15], dtype=np.uint8)
+    outs = []
+    for fused in (False, True):
+        p.use_gather_head = fused
+        dvol = ctx.from_numpy(x)
+        lab = ctx.from_numpy(np.full(shape, 99, dtype=np.uint8))
+        p.predict_segmentation_device(dvol, list(shape), lab, lut=lut, merge=True)
+        outs.append(lab.download(shape, np.uint8))
+        dvol.free()
+        lab.free()
+    p.close()
+    assert (outs[0] == 99).any() and (outs[0] != 99).any()
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_gather_inf_flag(ctx):
+    """Weights scaled so that the fp16 accumulators overflow: both forms must raise the reference's RuntimeError (:622-625)."""
+    from boa_hip import plans
+    from boa_hip.predictor import HipPredictor
+    pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=3)
+    geom = plans.model_config_from_plans(pj, dj).geometry
+    sd = plans.synthetic_state_dict(geom, 1)
+    key = [k for k in sd if "seg_layers" in k and k.endswith("weight")][-1]
+    sd[key] = sd[key] * 2e4          # (finite in fp16; the Gaussian-weighted fp16 sums overflow)
+    x = np.random.default_rng(0).standard_normal((1, 40, 36, 64)).astype(np.float32)
+    for fused in (False, True):
+        p = HipPredictor(ctx, geom, tile_step_size=0.5, max_batch=2)
+        p.set_parameters([plans.weight_blob_from_state_dict(geom, sd)])
+        p.use_gather_head = fused
+        with pytest.raises(RuntimeError, match="inf"):
+            p.predict_segmentation(x)
+        p.close()
+
+
+def test_total_pipeline_same_labels_both_forms(ctx):
+    """Five part models with crop + CTNormalization + merge through the task driver: the gather form (default) and the scatter
+    form give the same label volume -- bit for bit when the scatter loop ran the MFMA head throughout (aligned tile origins), within
+    99.9 % when it fell back to the fp32 VALU head for unaligned tiles (step 0.8 on a 32^3 patch: origins 0 / 9 / 20)."""
+    from boa_hip import label_maps, plans, totalseg
+    rng = np.random.default_rng(11)
+    ct = rng.normal(0, 300, size=(44, 40, 52)).astype(np.int16)
+    ct[ct == 0] = 1
+    ct[:3] = 0
+    models = []
+    for tid, nc in zip(label_maps.PART_TASK_IDS, (25, 27, 19, 24, 27)):
+        pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc)
+        cfg = plans.model_config_from_plans(pj, dj)
+        models.append((tid, cfg, [plans.weight_blob_from_state_dict(cfg.geometry, plans.synthetic_state_dict(cfg.geometry, seed=tid))]))
+    outs = []
+    for fused in (True, False):
+        ts = totalseg.TotalSegmentatorHip(ctx, models, step_size=0.8, max_batch=4)
+        for _, _, p, _ in ts.parts:
+            p.use_gather_head = fused
+        ctx.counters(reset=True)
+        outs.append(ts.predict(ct))
+        cnt = ctx.counters()
+        ts.close()
+    if cnt["head_valu"] == 0:
+        np.testing.assert_array_equal(outs[0], outs[1])
+    else:
+        agree = float((outs[0] == outs[1]).mean())
+        print("gather vs scatter (VALU head on unaligned tiles) agreement", agree)
+        assert agree >= 0.999

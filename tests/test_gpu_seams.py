@@ -293,6 +293,7 @@ def test_sliding_window_end_to_end(ctx):
         vol = rng.standard_normal((1, *shape)).astype(np.float32)
         p = HipPredictor(ctx, geom, tile_step_size=step, max_batch=3)
         p.set_parameters([blob])
+        ctx.counters(reset=True)
         got = p.predict_sliding_window_return_logits(vol)
         seg = p.predict_segmentation(vol)
         ref, nw, _ = osw.predict_sliding_window_return_logits(network_fn_from_module(net, 8), vol, list(geom.patch_size),
@@ -309,8 +310,14 @@ def test_sliding_window_end_to_end(ctx):
         print(f"{shape} step {step}: max|err|={err:.4g} range={rng_:.4g} label agreement={agree:.5f}")
         assert err <= 0.003 * rng_                    # measured 8.2e-4 .. 8.8e-4 of the range
         assert agree >= 0.998                         # measured 0.99957 / 0.99968
-        # on-device argmax is exactly the argmax of the on-device fp16 logits
-        np.testing.assert_array_equal(seg, got.argmax(0).astype(np.uint8))
+        # the label path (gather form of the tile loop, MFMA head arithmetic throughout: tests/test_gpu_gather_head.py pins it bit for
+        # bit) against the argmax of the logits API's fp16 logits (scatter loop): identical when that loop ran the MFMA head for every
+        # tile; for tile origins that are not 8-aligned along z it falls back to the fp32 VALU head, whose logits differ in the last
+        # bits (both are valid fp16-mode results)
+        if ctx.counters()["head_valu"] == 0:
+            np.testing.assert_array_equal(seg, got.argmax(0).astype(np.uint8))
+        else:
+            assert float((seg == got.argmax(0)).mean()) >= 0.999
         p.close()
 
 

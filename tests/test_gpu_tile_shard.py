@@ -62,6 +62,12 @@ def _predict(ctx, shard=None, model_shard=None, max_batch=1, spacing_zyx=None):
     for _, _, p, _ in task.parts:
         p.tile_step_size = 0.5
     task.shard = shard
+    # the sharded paths run the scatter form of the tile loop (fp16 accumulator planes, overlap slabs exchanged); the unsharded
+    # reference does too, so that "bit-identical" compares like with like also for this geometry's unaligned tile origins (the
+    # gather form computes every tile's head on the matrix cores, the scatter form falls back to the fp32 VALU head for z origins
+    # that are not 8-aligned: tests/test_gpu_gather_head.py)
+    for _, _, p, _ in task.parts:
+        p.use_gather_head = False
     d_ct = ctx.from_numpy(_ct())
     d_lab = ctx.alloc(int(np.prod(SHAPE)))
     try:
