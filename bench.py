@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 HBM_PEAK_GBPS = 8000.0               # same guide: 8 TB/s spec (6.3 TB/s measured for a float4 copy)
 HBM_COPY_GBPS = 6300.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_fetch_write_512.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_fetch_write_512.json")
 
 
 def parse_args():
@@ -494,8 +494,8 @@ def main():
                        "tflop_per_volume": flops_per_volume / 1e12, "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
                        "precision": "fp16 activations/weights, fp32 MFMA accumulate, fp16 logit accumulators (reference semantics)",
                        "input": "int16 CT resident in HBM at the start of the timed region; label volumes stay in HBM, tables on the host"},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_ws<R,K> (all MFMA 3x3x3 / 1x3x3 conv launches of the step: wave-specialised "
-                                                    "implicit GEMM, v_mfma_f32_32x32x16_f16)",
+            "roofline": {"bound": "mfma", "kernel": "k_conv_ws<R,K> + k_conv_ns<S,WN,RM> (all MFMA 3x3x3 / 1x3x3 conv launches of the step: "
+                                                    "wave-specialised implicit GEMM, v_mfma_f32_32x32x16_f16; k_conv_ns = the stride-2 layers)",
                          "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
                          "launches": conv["launches"], "avg_launch_ms": conv_ms / max(conv["launches"], 1),
@@ -513,6 +513,8 @@ def main():
                                "frac_of_measured_copy": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6 / HBM_COPY_GBPS,
                                "ms": prof[k]["ms"], "launches": prof[k]["launches"]}
                            for k in ("head_accum", "finalize_argmax", "convT_mfma", "conv_first") if prof[k]["launches"]},
+            # (head_accum: since round 3 the gather form of the tile loop -- stash read + labels, no accumulator planes, no separate
+            #  finalize pass; its algorithmic bytes are 66 B per voxel and covering tile, a third of the scatter form's)
             "kernel_variants": counters,
             "median_ms_per_step": float(np.median(step_s)) * 1e3,
             "total_only": total_only,
@@ -525,7 +527,7 @@ def main():
         # process), launch-weighted mean over the k_conv_ws launches; per launch like `achieved`
         try:
             pj_ = json.load(open(PMC_PROFILE))
-            rows = [v for k, v in pj_["kernels"].items() if "k_conv_ws" in k]
+            rows = [v for k, v in pj_["kernels"].items() if "k_conv_ws" in k or "k_conv_ns" in k]
             nd = sum(v["dispatches"] for v in rows)
             res["roofline"]["traffic"] = 1e6 * 1.048576 * sum(
                 v["dispatches"] * (v["fetch_MB_corrected_per_dispatch"] + v["write_MB_per_dispatch"]) for v in rows) / nd

@@ -2,10 +2,10 @@
 # Round profile (run on the GPU box from the repo root):
 #   1. rocprofv3 --kernel-trace --stats of the default bench command (total+bca, 512^3)      -> <tag>_bench512_kernel_stats.csv
 #   2. FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, as MI355X_MICROARCH.md prescribes) of the SAME workload's
-#      `total` half at 512^3 (one volume: 625 tile forwards through the same k_conv_ws launches) -> <tag>_pmc_fetch_write_512.json
+#      total+bca workload at 512^3 (one volume, 1 605 tile forwards) -> <tag>_pmc_fetch_write_512.json
 #   3. matrix-core counters (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE) on one 8-tile batch   -> <tag>_pmc_mfma.json
 # Results land in gpurun_out/prof_<tag>/, the summaries to commit in gpurun_out/profiles_<tag>/ (copy them into profiles/).
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -15,7 +15,7 @@ rm -rf $OUT $SUM; mkdir -p $OUT $SUM
 CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-parity --no-h2h"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $CMD > $SUM/${TAG}_bench512_rocprof_run.log 2>&1)
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $SUM/${TAG}_bench512_kernel_stats.csv
-PMCCMD="python $ROOT/bench.py --models total --steps 1 --warmup 0 --no-cpu --no-parity --no-h2h"
+PMCCMD="python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-parity --no-h2h"   # the total+bca workload the bench line reports
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 1200 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o $TAG -- $PMCCMD > $OUT/pmc_$c.log 2>&1)
 done
