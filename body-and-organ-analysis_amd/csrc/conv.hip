@@ -887,6 +887,7 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
             }
             // chunk-planar [N][2][voxel][16]: lane (voxel, kh) owns plane kh -> a wave stores two runs of 1 KiB
             __half* dst = p.out + ((size_t)(n * 2 + kh) * ovox + ((size_t)(tx * MF0 + x) * p.P1 + ty * MF1 + y) * p.P2 + tz * MF2 + l31) * 16;
+            // (streaming `nt` stores were measured: 0 ... -10 %)
             *(uint4*)dst = make_uint4(w8[0], w8[1], w8[2], w8[3]);
             *(uint4*)(dst + 8) = make_uint4(w8[4], w8[5], w8[6], w8[7]);
         }

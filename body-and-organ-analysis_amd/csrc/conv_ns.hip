@@ -122,6 +122,16 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
         rg.has_ss = 0;
         rg.skip_halo = 0;
         int pcc = 0;
+        int ptr_n = 0;
+        // debug timeline of producer wave 4 of block 0 (second half of the trace buffer): 1 barrier passed, 8 next tile set up,
+        // 2 chunk committed, 3 next loads issued
+#define NS_PSTAMP(code)                                                                                                          \
+    do {                                                                                                                         \
+        if (p.trace && blockIdx.x == 0 && wave == 4 && lane == 0 && ptr_n < WS_TRACE_SLOTS / 2) {                                  \
+            p.trace[WS_TRACE_SLOTS / 2 + ptr_n] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
+            ++ptr_n;                                                                                                             \
+        }                                                                                                                        \
+    } while (0)
         const bool live = !(dbg & 2);
         if (live && my_chunks > 0) {
             seq_first(p, pseq);
@@ -133,15 +143,23 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
             if (live && g + 1 < my_chunks) {
                 unsigned char* nxt = bufs + ((g + 1) & 1) * buf_bytes;
                 const bool do_issue = g + 2 < my_chunks;
+                NS_PSTAMP(1);
                 if (do_issue && pcc == 0) {  // (before the commit: see k_conv_ws)
                     seq_next(p, pseq);
                     prod_setup(p, ptc, pc, items);
+                    NS_PSTAMP(8);
+                }
+                if (p.trace) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    NS_PSTAMP(7);
                 }
                 prod_commit(p, rg, nxt, q, HV, plane, dbg);
+                NS_PSTAMP(2);
                 if (do_issue) {
                     prod_issue(p, ptc, items, pc.in_halo, pcc, false, q, dbg, rg);
                     if (++pcc == ncc) pcc = 0;
                 }
+                NS_PSTAMP(3);
             }
             __syncthreads();
         }
@@ -461,6 +479,10 @@ int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
         fprintf(stderr, "[ns-trace] Cin=%d Cout=%d in=%d s=%d:", a.C0 + a.C1, a.Cout, a.Di, a.s0);
         for (int i = 1; i < 80 && host[i]; ++i)
             fprintf(stderr, " %d:%llu", (int)(host[i] >> 56), (host[i] & 0x00ffffffffffffffull) - (host[i - 1] & 0x00ffffffffffffffull));
+        fprintf(stderr, "\n[ns-trace] producer:");
+        const unsigned long long* hp = host + WS_TRACE_SLOTS / 2;
+        for (int i = 41; i < 110 && hp[i]; ++i)
+            fprintf(stderr, " %d:%llu", (int)(hp[i] >> 56), (hp[i] & 0x00ffffffffffffffull) - (hp[i - 1] & 0x00ffffffffffffffull));
         fprintf(stderr, "\n");
     }
     BOA_HIP_TRY(hipGetLastError());
