@@ -1694,6 +1694,27 @@ int launch_head(boa_ctx* ctx, const __half* act, const float* ss, int F0, const 
     } else if (logits_out && mfma_shape && ((uintptr_t)logits_out) % 16 == 0) {
         hipLaunchKernelGGL(k_head_mfma<true>, dim3(mfma_grid), dim3(256), 0, ctx->stream, a);
         ctx->counters[BOA_CNT_HEAD_MFMA]++;
+    } else if (!logits_out && mfma_shape) {
+        // accumulators that do not allow the 16-byte read-modify-write (tile z origin / volume z extent not 8-aligned: the common
+        // case for real CT sizes): the SAME MFMA logits (logits mode) into a scratch buffer, then the reference's accumulate step on
+        // them (k_accumulate_tile: identical arithmetic, tests/test_gpu_head.py) -- so that every tile's logits come from the same
+        // kernel whatever its alignment, and the logits API agrees bit for bit with the label path (gather head).  (Round 2 fell
+        // back to an fp32 VALU head here, whose logits differ in the last bits.)
+        float* tmp = nullptr;
+        if (boa_malloc(ctx, (size_t)C * pv * sizeof(float), (void**)&tmp) != BOA_OK) {
+            tm.stop();
+            return BOA_ENOMEM;
+        }
+        HeadArgs al = a;
+        al.logits = tmp;
+        hipLaunchKernelGGL(k_head_mfma<true>, dim3(mfma_grid), dim3(256), 0, ctx->stream, al);
+        tm.stop();
+        ctx->counters[BOA_CNT_HEAD_MFMA]++;
+        const int rc = boa_accumulate_tile(ctx, tmp, gauss, acc, nacc, C, P, PV, start);
+        boa_free(ctx, tmp);
+        if (rc) return rc;
+        BOA_HIP_TRY(hipGetLastError());
+        return BOA_OK;
     } else {
         if (pair)
             hipLaunchKernelGGL((k_head<32, 2>), dim3((unsigned)((pv / 2 + 255) / 256)), dim3(256), lds, ctx->stream, a);

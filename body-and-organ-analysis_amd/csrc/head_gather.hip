@@ -208,6 +208,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
         int bidx = 1 << 20;
         bool bnan = false, have = false;
         const size_t vi = ((size_t)x * p.V1 + y) * p.V2 + z;
+        // Single fold (the part models): q(a) = half(a / n) is a monotone function of the running sum a (same positive divisor, RTNE
+        // twice), so the argmax and the inf flag follow from the extremes -- two divisions per lane instead of sixteen (the
+        // divisions were a third of the kernel's instructions at ~2 covering tiles per voxel).  first-maximum semantics: the winner
+        // is the LOWEST class whose quotient equals the maximum's; only classes within 2^-8 of the largest sum can round to the
+        // same half, and those few get their exact quotient.  NaN sums, quotients in the fp16-subnormal range and a zero maximum
+        // take the general path (wave-uniform).
+        bool fast = p.fold_mode == 0;
+        float amax = 0.f, amin = 0.f, asum = 0.f;
+        int imax = 1 << 20;
+        if (fast) {
+            bool first = true;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
+                if (c >= p.C) continue;
+                const float a = acc[i];
+                asum += a;
+                if (first || a > amax) {   // (ascending classes, strict >: the lane's first maximum)
+                    amax = a;
+                    imax = c;
+                }
+                amin = first ? a : fminf(amin, a);
+                first = false;
+            }
+            const unsigned short hmax = f2us(__fdiv_rn(amax, nacc)), hmin = f2us(__fdiv_rn(amin, nacc));
+            const float qmax = us2f(hmax);
+            const bool lane_has = imax < (1 << 20);
+            // (lanes without classes -- kh = 1 when C <= 4 -- and runs beyond the volume do not vote)
+            const bool slow = zvalid && lane_has && (asum != asum || !(fabsf(qmax) >= 1.3e-4f));
+            if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+                fast = false;
+            } else {   // (every lane runs this block: the shuffles and ballots below must stay convergent)
+                if (zvalid && lane_has && ((hmax & 0x7FFF) == 0x7C00 || (hmin & 0x7FFF) == 0x7C00)) any_inf = true;
+                // the voxel's maximum over both lanes (the other 16 classes live in lane ^ 32; a lane without classes -- kh = 1
+                // when C <= 4 -- carries the sentinel index)
+                const float oa = __shfl_xor(amax, 32), oq = __shfl_xor(qmax, 32);
+                const int oi = __shfl_xor(imax, 32);
+                float gmax = amax, gq = qmax;
+                int gi = imax;
+                if (oi < (1 << 20) && (!lane_has || oa > gmax || (oa == gmax && oi < gi))) {
+                    gmax = oa;
+                    gq = oq;
+                    gi = oi;
+                }
+                // lower classes whose quotient ties with the maximum's
+                const float lo = gmax - fabsf(gmax) * 0.00390625f;
+                int ci = gi;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
+                    const bool cand = zvalid && c < p.C && c < gi && acc[i] >= lo;
+                    if (__builtin_amdgcn_ballot_w64(cand) != 0) {
+                        const float q = us2f(f2us(__fdiv_rn(acc[i], nacc)));
+                        if (cand && q == gq) ci = min(ci, c);
+                    }
+                }
+                bidx = min(ci, __shfl_xor(ci, 32));
+                have = true;
+            }
+        }
+        if (!fast) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
@@ -237,9 +298,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
                 bnan = isn;
             }
         }
+        }
         if (p.fold_mode == 1 || p.fold_mode == 2) continue;
         // the voxel's other 16 classes live in lane ^ 32: combine (NaN first, then value, then the lower class index)
-        {
+        if (!fast) {
             const float ob = __shfl_xor(best, 32);
             const int oi = __shfl_xor(bidx, 32);
             const int on = __shfl_xor((int)bnan, 32);

@@ -691,7 +691,9 @@ static bool grid_origins(const int* o, int n, std::vector<int> (&steps)[3]) {
 extern "C" int boa_net_labels_supported(boa_net* net, const int* host_origins, int n_tiles) {
     if (!net || !host_origins) return 0;
     static const bool off = getenv("BOA_NO_GATHER_HEAD") != nullptr;
-    if (off || net->precision != 0 || net->mirror_mask != 0 || net->d.features[0] != 32 || net->d.num_classes > 32) return 0;
+    // (patch z extent a multiple of 32 and <= 31 classes: the shapes for which the scatter loop's head runs on the matrix cores too,
+    //  so that the label path and the logits API share one head arithmetic)
+    if (off || net->precision != 0 || net->mirror_mask != 0 || net->d.features[0] != 32 || net->d.num_classes > 31 || net->d.patch[2] % 32 != 0) return 0;
     std::vector<int> steps[3];
     return grid_origins(host_origins, n_tiles, steps) ? 1 : 0;
 }

@@ -210,7 +210,7 @@ int boa_net_predict_sliding_window(boa_net* net, const float* dev_volume, const 
  *   dev_labels_out  written by the LAST fold's call (merge / lut / crop_off / crop_dims as in boa_finalize_labels)
  *   dev_inf_flag    set non-zero if a normalised logit is +-inf (:622-625)
  * boa_net_labels_supported: 1 when the network / tile layout qualifies (production precision, no mirroring, 32 features at
- * full resolution, <= 32 classes, tile origins = the cartesian grid of compute_steps_for_sliding_window in canonical order).
+ * full resolution, <= 31 classes, patch z extent a multiple of 32, tile origins = the cartesian grid of compute_steps_for_sliding_window in canonical order).
  * Returns BOA_ENOMEM when the stash (n_tiles x patch voxels x 64 B) does not fit: the caller falls back to the loop above. */
 int boa_net_labels_supported(boa_net* net, const int* host_origins, int n_tiles);
 int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume, const int V[3], const int PV[3], const int* vol_off,

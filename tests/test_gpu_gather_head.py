@@ -158,3 +158,43 @@ def test_total_pipeline_same_labels_both_forms(ctx):
         agree = float((outs[0] == outs[1]).mean())
         print("gather vs scatter (VALU head on unaligned tiles) agreement", agree)
         assert agree >= 0.999
+
+
+
+@pytest.mark.parametrize("nc", [2, 4, 5, 13])
+def test_gather_ties_and_small_class_counts(ctx, nc):
+    """Single-fold fast path of the gather epilogue (argmax from the extremes of the running sums + exact quotients of the
+    near-maximum classes): head rows duplicated so that classes TIE exactly -- across the two lanes that hold a voxel's classes and
+    within one -- and class counts for which the second lane holds no class at all (nc <= 4).  Labels must equal numpy's argmax
+    (first maximum) of the oracle loop over the device's per-tile logits."""
+    from boa_hip import plans, sliding_window as sw
+    from boa_hip.predictor import HipPredictor
+    from oracle import labels as olab
+    from oracle import sliding_window as osw
+    patch, shape, step = (32, 32, 32), (40, 36, 64), 0.5
+    pj, dj = plans.synthetic_plans(patch=patch, features=(32, 64), num_classes=nc)
+    geom = plans.model_config_from_plans(pj, dj).geometry
+    sd = plans.synthetic_state_dict(geom, 7)
+    kw = [k for k in sd if "seg_layers" in k and k.endswith("weight")][-1]
+    kb = kw[:-6] + "bias"
+    dup = [(1, 0)] if nc == 2 else [(2, 0), (3, 1)] if nc == 4 else [(4, 0), (3, 1)] if nc == 5 else [(5, 2), (9, 2), (12, 7), (1, 0)]
+    for dst, src in dup:           # class dst := class src (exact ties wherever src wins)
+        sd[kw][dst] = sd[kw][src]
+        sd[kb][dst] = sd[kb][src]
+    p = HipPredictor(ctx, geom, tile_step_size=step, max_batch=3)
+    p.set_parameters([plans.weight_blob_from_state_dict(geom, sd)])
+    x = np.random.default_rng(nc).standard_normal((1, *shape)).astype(np.float32)
+    got = p.predict_segmentation(x)
+    origins = np.asarray(sw.get_sliding_window_origins(list(shape), list(patch), step), dtype=np.int32)
+    g = osw.compute_gaussian(tuple(patch), 1. / 8, 10)
+    tiles = p.network_forward(x, origins)
+    p.close()
+    acc = np.zeros((nc, *shape), np.float16)
+    n = np.zeros(shape, np.float16)
+    for t, o in enumerate(origins):
+        osw.accumulate_tile(acc, n, tiles[t], g, tuple(int(v) for v in o))
+    want = olab.argmax_labels(osw.finalize_logits(acc, n))
+    for dst, src in dup:
+        assert not (want == dst).any() or dst < src        # a duplicated higher class never wins a tie
+    assert len(np.unique(want)) >= min(nc, 3) - 1
+    np.testing.assert_array_equal(got, want)
