@@ -26,13 +26,23 @@ OVERVIEW_NAMES = ["First", "25%", "Central", "75%", "Last"]
 
 
 def apply_hu_window(image: np.ndarray, hu_min: float = -150.0, hu_max: float = 400.0) -> np.ndarray:
-    return np.clip((image - hu_min) / (hu_max - hu_min), 0.0, 1.0) * 255.0
+    """overlay.py:20-23: HU -> [0, 255] grey ramp between hu_min and hu_max (same operation order, golden G14)."""
+    ramp = np.subtract(image, hu_min)            # int HU -> fp64, float32 HU stays float32 (numpy promotion, as there)
+    ramp /= (hu_max - hu_min)
+    np.clip(ramp, 0.0, 1.0, out=ramp)
+    ramp *= 255.0
+    return ramp
 
 
 def blend_overlay(gray_image: np.ndarray, color_rgb: np.ndarray, mask: np.ndarray, opacity: float) -> np.ndarray:
-    gray_rgb = gray_image[..., np.newaxis]
-    blended = gray_rgb * (1 - opacity) + color_rgb.astype(np.float64) * opacity
-    return np.where(mask[..., np.newaxis], blended, gray_rgb)
+    """overlay.py:5-13: grey slice [Y][X] + per-pixel colour [Y][X][3]; pixels under `mask` are the opacity mix, the others
+    the grey value on all three channels.  Only the masked pixels are mixed (the figure is mostly background)."""
+    out = np.repeat(np.asarray(gray_image, dtype=np.float64)[:, :, None], 3, axis=2)
+    sel = np.asarray(mask, dtype=bool)
+    if sel.any():
+        keep = 1 - opacity
+        out[sel] = out[sel] * keep + np.asarray(color_rgb)[sel].astype(np.float64) * opacity
+    return out
 
 
 def overview_locations(num_slices: int) -> List[int]:
