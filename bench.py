@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host (PCIe-inclusive) extra")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp16-vs-exact-mode label flip sample")
     ap.add_argument("--cpu-tiles", type=int, default=8)
+    ap.add_argument("--lanes", type=int, default=2, choices=[2, 3],
+                    help="streams of the overlap extra: 2 = `total` | both BCA nets, 3 = `total` | body_parts | body_regions")
+    ap.add_argument("--no-lanes", action="store_true", help="skip the two-lane extra (`total` and the BCA nets on two streams)")
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events (measures their overhead; roofline fields become 0)")
     ap.add_argument("--shard", choices=["volumes", "tiles", "models"], default="volumes",
                     help="N>1: 'volumes' = one volume per GPU, no data-path collective (weak scaling, default); 'tiles' = all "
@@ -274,6 +277,7 @@ def main():
     from boa_hip import sliding_window as sw
     from boa_hip.devarray import DevArray
     from boa_hip.device import Context
+    from boa_hip.lanes import TotalBcaRunner
     from boa_hip.pipeline import BcaPipelineHip
     from boa_hip.task import SegmentationTask
 
@@ -335,6 +339,7 @@ def main():
             class_voxels += 5 * (cfg.geometry.num_classes + 1.0) * float(np.prod(vs))
 
     d_ct = DevArray.from_numpy(ctx, ct)                                  # resident int16 CT, file axis order
+    runner = TotalBcaRunner(total_task, pipe, label_map, cnr_adjustment=True)
 
     stage_log = {}
 
@@ -344,43 +349,23 @@ def main():
             stage_log[name] = stage_log.get(name, 0.0) + time.perf_counter() - t0
         return time.perf_counter()
 
-    def step(d_in, download=False):
-        """One CT through total -> total measurements -> bca.  `download`: also bring the label volumes to the host."""
-        outs = []
-        ts_ = time.perf_counter()
-        d_total = total_task.predict_image(d_in, affine, return_device=True)
-        outs.append(d_total)
-        ts_ = stage("total", ts_)
-        # compute_measurements' view: SimpleITK (z,y,x) arrays of the file (BOA/compute/measurements.py:257-258)
-        c_zyx = d_in.transpose((2, 1, 0)).contiguous(np.int16, force_copy=True)
-        s_zyx = d_total.transpose((2, 1, 0)).contiguous(force_copy=True)
-        # device passes now; the per-label order statistics (pure numpy on the downloaded histogram) on a worker thread under
-        # the BCA nets' kernels -- joined before the step ends, so every step still delivers its complete tables
-        fin, d_mask = M.total_measurements(ctx, None, None, label_map, (1.5, 1.5, 1.5), cnr_adjustment=True, d_ct=c_zyx.buf,
-                                           d_lab=s_zyx.buf, shape=c_zyx.shape, mask_on_device=True, defer_host=pipe is not None)
-        d_mask.free()
-        c_zyx.free()
-        s_zyx.free()
-        ts_ = stage("total measurements", ts_)
-        res = None
-        if pipe is not None:
-            box = {}
-            th = threading.Thread(target=lambda: box.update(meas=fin()))
-            th.start()
-            res = pipe.run_resident(d_in, affine, d_total)
-            outs += [res["body_parts"], res["body_regions"], res["tissues"]]
-            th.join()
-            meas = box["meas"]
-            ts_ = stage("bca", ts_)
-        else:
-            meas = fin
-        host = [a.download() for a in outs] if download else None
+    def step(d_in, download=False, run=None):
+        """One CT through total -> total measurements -> bca (boa_hip/lanes.py).  `download`: also bring the label volumes to
+        the host.  `run`: the TotalBcaRunner (default: the one-stream runner of the timed region)."""
+        clock = [time.perf_counter()]
+
+        def on_stage(name):
+            clock[0] = stage(name, clock[0])
+
+        out = (run or runner).run_resident(d_in, affine, (1.5, 1.5, 1.5), on_stage)
+        outs = [out[k] for k in ("total", "body_parts", "body_regions", "tissues") if k in out]
         chk = None
         if download:
+            host = [a.download() for a in outs]
             chk = int(host[0].astype(np.int64).sum())
         for a in outs:
             a.free()
-        return meas, res["bca_measurements"] if res else None, chk
+        return out["total_measurements"], out.get("bca_measurements"), chk
 
     def barrier():
         ctx.sync()
@@ -447,6 +432,41 @@ def main():
             total_task.predict_image(d_ct, affine, return_device=True).free()
         ctx.sync()
         total_only = {"volumes_per_s": 2.0 / (time.perf_counter() - tb), "steps": 2, "tile_forwards_per_volume": 625}
+    two_lanes = None
+    if rank == 0 and with_bca and args.gpus == 1 and not args.no_lanes:
+        # the product's two-lane mode (boa_hip/lanes.py): `total` + its measurements on this context's stream, both BCA nets +
+        # post-processing + tissues on a second context (own stream, pool, predictors) of the same GPU; same kernels, same
+        # results (tests/test_gpu_lanes.py).  Timed outside the headline region because the per-class HIP-event times of two
+        # overlapping streams would no longer describe one kernel each: event profiling is off here.
+        try:
+            ctx2 = Context(local_rank)
+            ctx3 = Context(local_rank) if args.lanes >= 3 else None
+            pipe2 = BcaPipelineHip(ctx2, bm["body_parts"], bm["body_regions"], fast_bca=False, max_batch=args.batch, parts_ctx=ctx3)
+            run2 = TotalBcaRunner(total_task, pipe2, label_map, cnr_adjustment=True)
+            step(d_ct, run=run2)
+            ctx.sync()
+            ctx2.sync()
+            tl = []
+            tb = time.perf_counter()
+            for _ in range(args.steps):
+                t_s = time.perf_counter()
+                step(d_ct, run=run2)
+                tl.append(time.perf_counter() - t_s)
+            ctx.sync()
+            ctx2.sync()
+            el2 = time.perf_counter() - tb
+            two_lanes = {"value": args.steps / el2, "unit": "volumes/s", "ms_per_step": el2 * 1e3 / args.steps, "steps": args.steps,
+                         "median_ms_per_step": float(np.median(tl)) * 1e3, "vs_one_stream": (args.steps / el2) / (args.steps / elapsed),
+                         "note": "TotalBcaRunner with the BCA half on a second context/stream of the same GPU; event profiling off; "
+                                 "labels and tables identical to the one-stream run"}
+            two_lanes["lanes"] = args.lanes
+            pipe2.close()
+            ctx2.close()
+            if ctx3 is not None:
+                ctx3.close()
+        except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
+            two_lanes = {"error": f"{type(e).__name__}: {e}"}
+        log(f"two lanes: {two_lanes}")
     h2h = None
     if rank == 0 and not args.no_h2h and args.gpus == 1:
         # PCIe-inclusive: upload the CT, download `total` + the three BCA label volumes (tables are host dicts already);
@@ -518,6 +538,7 @@ def main():
             "kernel_variants": counters,
             "median_ms_per_step": float(np.median(step_s)) * 1e3,
             "total_only": total_only,
+            "two_lanes": two_lanes,
             "host_to_host": h2h,
             "tables": {"total_labels_present": int(sum(1 for v in meas["segmentations"]["total"].values() if v.get("present"))) if meas else None,
                        "bca_aggregated_groups": len(bca_js.get("aggregated", {})) if bca_js else None},

@@ -45,6 +45,7 @@ _PROTOS = {
     "boa_malloc": (i32, [vp, u64, C.POINTER(vp)]),
     "boa_free": (i32, [vp, vp]),
     "boa_trim": (i32, [vp]),
+    "boa_bind_thread": (i32, [vp]),
     "boa_mfma_peak": (i32, [vp, i32, i32, C.POINTER(C.c_double)]),
     "boa_memset": (i32, [vp, vp, i32, u64]),
     "boa_h2d": (i32, [vp, vp, vp, u64]),

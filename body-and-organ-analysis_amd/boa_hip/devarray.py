@@ -120,6 +120,14 @@ class DevArray:
         self.copy_to(out)
         return out
 
+    def to_context(self, ctx: Context) -> "DevArray":
+        """A contiguous copy owned by another Context of the same GPU (its pool, its stream): the copy is issued on the
+        DESTINATION's stream, so the source must be complete (its own context synchronised) before this is called."""
+        out = DevArray.empty(ctx, self.shape, self.dtype)
+        check(ctx.lib.boa_copy3(ctx.h, self.buf.vp, _CODES[self.dtype], self.offset, _ll3(self.strides), _i3(self.shape),
+                                out.buf.vp, _CODES[out.dtype], out.offset, _ll3(out.strides)), "boa_copy3")
+        return out
+
     def download(self) -> np.ndarray:
         a = self.contiguous()
         return a.buf.download(a.shape, a.dtype)

@@ -141,6 +141,10 @@ class Context:
     def sync(self):
         check(self.lib.boa_sync(self.h), "boa_sync")
 
+    def bind_thread(self):
+        """Called by a host thread other than the creating one before it drives this context (boa_bind_thread)."""
+        check(self.lib.boa_bind_thread(self.h), "boa_bind_thread")
+
     def info(self):
         name = C.create_string_buffer(256)
         cu = C.c_int()

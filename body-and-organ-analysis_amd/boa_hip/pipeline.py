@@ -80,8 +80,16 @@ class BcaPipelineHip:
     """parts_model / regions_model: (ModelConfig, [weight blob per fold])."""
 
     def __init__(self, ctx: Context, parts_model: Tuple[ModelConfig, Sequence[np.ndarray]],
-                 regions_model: Tuple[ModelConfig, Sequence[np.ndarray]], fast_bca: bool = False, max_batch: int = 16):
+                 regions_model: Tuple[ModelConfig, Sequence[np.ndarray]], fast_bca: bool = False, max_batch: int = 16,
+                 parts_ctx: Optional[Context] = None):
+        """`parts_ctx`: a second Context of the same GPU (own stream and pool).  The body_parts net and its post-processing
+        then run on it, driven by a worker thread, while body_regions runs on `ctx` (the two only meet in the tissue stage;
+        with `crop_body` the second net needs the first one's output and the pipeline stays on one stream).  Same kernels on
+        the same data either way: the results are bit-identical."""
         self.ctx = ctx
+        self.parts_ctx = parts_ctx if parts_ctx is not ctx else None
+        if self.parts_ctx is not None and self.parts_ctx.device != ctx.device:
+            raise ValueError("BcaPipelineHip: parts_ctx must be on the same GPU")
         self.tasks: Dict[str, SegmentationTask] = {}
         for name, model in (("body_parts", parts_model), ("body_regions", regions_model)):
             if model is None:      # this task's output is reloaded from an earlier run (recompute=False): no network needed
@@ -91,7 +99,8 @@ class BcaPipelineHip:
             blobs = list(blobs)[:len(info["folds"])]
             if len(blobs) != len(info["folds"]):
                 raise ValueError(f"{name}: {len(info['folds'])} folds expected, {len(blobs)} weight sets given")
-            self.tasks[name] = SegmentationTask(ctx, name, [(info["task_id"], cfg, blobs)], resample=info["resample"],
+            tctx = self.parts_ctx if (name == "body_parts" and self.parts_ctx is not None) else ctx
+            self.tasks[name] = SegmentationTask(tctx, name, [(info["task_id"], cfg, blobs)], resample=info["resample"],
                                                 resample_only_thickness=True, multimodel=False, max_batch=max_batch)
 
         # (agg_shard.AggComm, tile_shard.ShardComm): several ranks share every volume also in the aggregation half -- CC
@@ -106,25 +115,26 @@ class BcaPipelineHip:
                           done=None) -> DevArray:
         """BCA/infer/infer.py:39-89 on resident data: network labels on the input grid (file axis order), then the task's
         post-processing applied to the SimpleITK view (z,y,x) of the file; returns the cleaned labels in file order."""
+        ctx = self.tasks[task_name].ctx if task_name in self.tasks else self.ctx
         if done is not None:   # `inference(recompute=False)` found <task>.nii.gz: already post-processed (infer.py:58-61)
-            return DevArray.from_numpy(self.ctx, np.ascontiguousarray(done, dtype=np.uint8))
+            return DevArray.from_numpy(ctx, np.ascontiguousarray(done, dtype=np.uint8))
         if raw is None:
-            with _Stage(self.ctx, f"{task_name}: networks"):
+            with _Stage(ctx, f"{task_name}: networks"):
                 d_raw = self.tasks[task_name].predict_image(d_ct, affine, force_split=force_split, crop_mask=crop, return_device=True)
         else:
-            d_raw = DevArray.from_numpy(self.ctx, np.ascontiguousarray(raw, dtype=np.uint8))
-        with _Stage(self.ctx, f"{task_name}: post-processing"):
+            d_raw = DevArray.from_numpy(ctx, np.ascontiguousarray(raw, dtype=np.uint8))
+        with _Stage(ctx, f"{task_name}: post-processing"):
             zyx = d_raw.transpose((2, 1, 0)).contiguous(force_copy=True)
             d_raw.free()
             if task_name == "body_parts":
-                buf = bca.postprocess_part_segmentation_device(self.ctx, zyx.buf, zyx.shape)
+                buf = bca.postprocess_part_segmentation_device(ctx, zyx.buf, zyx.shape)
                 zyx.free()
-                zyx = DevArray(self.ctx, buf, zyx.shape, np.uint8)
+                zyx = DevArray(ctx, buf, zyx.shape, np.uint8)
             elif task_name == "body_regions":
                 if self.agg is not None and self.agg[0].world > 1:
-                    bca.postprocess_region_segmentation_device_sharded(self.ctx, self.agg, zyx.buf, zyx.shape)
+                    bca.postprocess_region_segmentation_device_sharded(ctx, self.agg, zyx.buf, zyx.shape)
                 else:
-                    bca.postprocess_region_segmentation_device(self.ctx, zyx.buf, zyx.shape)
+                    bca.postprocess_region_segmentation_device(ctx, zyx.buf, zyx.shape)
             else:
                 zyx.free()
                 raise ValueError(task_name)
@@ -135,7 +145,7 @@ class BcaPipelineHip:
     def inference(self, task_name: str, ct: np.ndarray, affine: np.ndarray, force_split: bool = False,
                   crop: Optional[np.ndarray] = None, raw: Optional[np.ndarray] = None) -> np.ndarray:
         """`inference()` for one BCA task on host arrays (file axis order) -> cleaned labels (file axis order)."""
-        d_ct = DevArray.from_numpy(self.ctx, SegmentationTask._supported(ct))
+        d_ct = DevArray.from_numpy(self.tasks[task_name].ctx if task_name in self.tasks else self.ctx, SegmentationTask._supported(ct))
         try:
             out = self._inference_device(task_name, d_ct, np.asarray(affine, dtype=np.float64), force_split, crop, raw)
             try:
@@ -144,6 +154,39 @@ class BcaPipelineHip:
                 out.free()
         finally:
             d_ct.free()
+
+    def _both_nets_two_streams(self, d_ct, affine, force_split, raw_regions, done_regions, keep):
+        """body_parts on `parts_ctx` (worker thread), body_regions on `ctx` (calling thread); hand-over by value: the CT is
+        copied into the second pool before the net starts, the cleaned labels back after that stream synchronised."""
+        import threading
+        ctx, pctx = self.ctx, self.parts_ctx
+        ctx.sync()                                    # the CT is complete before the other stream copies it
+        ct_p = d_ct.to_context(pctx)
+        box: dict = {}
+
+        def lane():
+            try:
+                pctx.bind_thread()
+                box["parts"] = self._inference_device("body_parts", ct_p, affine, force_split, None, None, None)
+                pctx.sync()
+            except BaseException as e:  # noqa: BLE001  (re-raised on the calling thread)
+                box["error"] = e
+
+        th = threading.Thread(target=lane, name="boa-lane-body-parts")
+        th.start()
+        try:
+            d_regions = self._inference_device("body_regions", d_ct, affine, force_split, None, raw_regions, done_regions)
+            keep.append(d_regions)
+        finally:
+            th.join()
+            ct_p.free()
+        if "error" in box:
+            raise RuntimeError("the body_parts lane failed") from box["error"]
+        d_parts = box["parts"].to_context(ctx)
+        keep.append(d_parts)
+        ctx.sync()                                    # the copy is done before its source goes back to the other pool
+        box["parts"].free()
+        return d_parts, d_regions
 
     def _lps_zyx(self, d: DevArray, affine: np.ndarray, dtype=None) -> DevArray:
         """BCA/io.py:78-94 `process_image` as a device view: reorient to LPS, SimpleITK array order (z,y,x), contiguous."""
@@ -181,7 +224,9 @@ class BcaPipelineHip:
                      force_split: bool = False, raw_parts: Optional[np.ndarray] = None, raw_regions: Optional[np.ndarray] = None,
                      done_parts: Optional[np.ndarray] = None, done_regions: Optional[np.ndarray] = None) -> dict:
         """`run` on device-resident inputs (CT and `total` labels in the file's axis order; neither is freed here): the three
-        label volumes come back as contiguous DevArrays in file axis order (the caller frees them), the tables as dicts."""
+        label volumes come back as contiguous DevArrays in file axis order (the caller frees them), the tables as dicts.
+        `d_total` may be a callable returning the DevArray: it is called when the vertebra table needs the `total` labels,
+        i.e. after both nets and their post-processing (boa_hip/lanes.py runs `total` on a second stream meanwhile)."""
         ctx = self.ctx
         affine = np.asarray(affine, dtype=np.float64)
         live = []
@@ -189,14 +234,22 @@ class BcaPipelineHip:
         # both nets see the same CT at the same (sx, sy, 5 mm) grid: the cubic resampling runs once (unless the second net
         # works on a body crop)
         rs_cache: dict = {}
-        for t in self.tasks.values():
-            t.resample_cache = rs_cache
+        two_streams = (self.parts_ctx is not None and not crop_body and raw_parts is None and done_parts is None
+                       and "body_parts" in self.tasks)
+        if not two_streams:
+            for t in self.tasks.values():
+                t.resample_cache = rs_cache
         try:
-            d_parts = self._inference_device("body_parts", d_ct, affine, force_split, None, raw_parts, done_parts)
-            keep.append(d_parts)
-            crop = d_parts.download() if crop_body else None
-            d_regions = self._inference_device("body_regions", d_ct, affine, force_split, crop, raw_regions, done_regions)
-            keep.append(d_regions)
+            if two_streams:
+                d_parts, d_regions = self._both_nets_two_streams(d_ct, affine, force_split, raw_regions, done_regions, keep)
+            else:
+                if self.parts_ctx is not None and "body_parts" in self.tasks and done_parts is None and raw_parts is None:
+                    raise NotImplementedError("crop_body with a parts_ctx: build the pipeline on one Context")
+                d_parts = self._inference_device("body_parts", d_ct, affine, force_split, None, raw_parts, done_parts)
+                keep.append(d_parts)
+                crop = d_parts.download() if crop_body else None
+                d_regions = self._inference_device("body_regions", d_ct, affine, force_split, crop, raw_regions, done_regions)
+                keep.append(d_regions)
             with _Stage(ctx, "LPS reload, body-part flags, vertebrae, tissues + tables, JSON"):
                 _, laff = orientation.with_axcodes(np.empty(d_ct.shape, dtype=np.uint8), affine, "LPS")
                 sp = np.sqrt(np.sum(np.asarray(laff, dtype=np.float64)[:3, :3] ** 2, axis=0))
@@ -216,6 +269,8 @@ class BcaPipelineHip:
                 else:
                     flags = bca.examined_body_part(present, spacing)
                 vertebrae = {}
+                if callable(d_total):
+                    d_total = d_total()
                 if d_total is not None:
                     tot_l = self._lps_zyx(d_total, affine)
                     live.append(tot_l)

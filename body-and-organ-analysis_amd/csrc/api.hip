@@ -116,6 +116,7 @@ extern "C" int boa_malloc(boa_ctx* c, size_t bytes, void** dev_out) {
         c->pool_cap = gb > 0 ? (size_t)(gb * (double)(1ull << 30)) : 1;  // 1 byte: nothing is ever parked
     }
     const size_t sz = pool_round(bytes);
+    std::lock_guard<std::recursive_mutex> lock(c->pool_mu);
     auto it = c->pool_free.lower_bound(sz);
     if (it != c->pool_free.end() && it->first - sz <= std::max<size_t>(sz / 4, 2u << 20)) {
         *dev_out = it->second;
@@ -132,6 +133,7 @@ extern "C" int boa_malloc(boa_ctx* c, size_t bytes, void** dev_out) {
 extern "C" int boa_free(boa_ctx* c, void* dev) {
     BOA_REQUIRE(c, "ctx is NULL");
     if (!dev) return BOA_OK;
+    std::lock_guard<std::recursive_mutex> lock(c->pool_mu);
     auto it = c->pool_live.find(dev);
     if (it == c->pool_live.end()) {  // not one of ours (or allocated raw): synchronise, then release
         BOA_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -154,8 +156,20 @@ extern "C" int boa_free(boa_ctx* c, void* dev) {
     return BOA_OK;
 }
 
+static int trim_locked(boa_ctx* c);
 extern "C" int boa_trim(boa_ctx* c) {
     BOA_REQUIRE(c, "ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lock(c->pool_mu);
+    return trim_locked(c);
+}
+
+extern "C" int boa_bind_thread(boa_ctx* c) {
+    BOA_REQUIRE(c, "ctx is NULL");
+    BOA_HIP_TRY(hipSetDevice(c->device));
+    return BOA_OK;
+}
+
+static int trim_locked(boa_ctx* c) {
     if (c->pool_free.empty()) return BOA_OK;
     BOA_HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto& b : c->pool_free) hipFree(b.second);

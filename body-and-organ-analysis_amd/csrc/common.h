@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <map>
 #include <unordered_map>
+#include <mutex>
 #include <vector>
 
 #include "boa_hip.h"
@@ -67,6 +68,7 @@ struct boa_ctx {
     // (a freed block goes back to `pool_free` without a device synchronisation and is handed out again for a request of
     // about its size; every use of a block is enqueued on `stream`, so reuse is ordered).  Network activations and weight
     // arenas use boa_malloc_raw / hipFree and never enter the pool.
+    std::recursive_mutex pool_mu;             // the pool may be entered from several host threads (Python finalisers, two-lane runs)
     std::multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_live;
     size_t pool_bytes = 0;          // bytes parked in pool_free

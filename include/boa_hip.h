@@ -55,6 +55,11 @@ int boa_device_info(boa_ctx* ctx, char* name, int name_len, int* cu_count, size_
 int boa_malloc(boa_ctx* ctx, size_t bytes, void** dev_out);
 int boa_free(boa_ctx* ctx, void* dev);
 int boa_trim(boa_ctx* ctx);
+/* Several contexts may live on one GPU (each with its own stream and pool: boa_hip/lanes.py runs `total` and the BCA nets on two),
+ * each driven by one host thread at a time; the pool itself is mutex-protected.  A host thread other than the one that called
+ * boa_init makes the context's GPU its current device with this call before it drives the context (torch does the same per
+ * thread with torch.cuda.set_device). */
+int boa_bind_thread(boa_ctx* ctx);
 /* Diagnostics (not on the data path): the rate a pure v_mfma_f32_32x32x16_f16 loop sustains on this GPU -- no memory, no LDS,
  * one wave per SIMD with 4 independent accumulator chains -- with near-constant operands (random_operands = 0) or operands whose
  * bits differ per lane and element (1).  The part is power-limited under matrix load: the second figure (1.5-1.7 PFLOP/s measured,
