@@ -944,8 +944,11 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
         m.w = w; m.bias = bias; m.out = out; m.partials = partials; m.nslots = nblk_tab;
         m.t0 = P[0] / MF0; m.t1 = P[1] / MF1; m.t2 = P[2] / MF2;
         m.vw = std::min(m.t0 * m.t1 * m.t2, ctx->cu_count);
-        hipLaunchKernelGGL(k_conv_first_mfma, dim3((unsigned)std::min<long long>((long long)m.vw * N, ctx->cu_count)), dim3(256), 0,
-                           ctx->stream, m);
+        // (physical workgroup b runs the virtual workgroups b, b + G, ...: any G gives the same results; more than one workgroup
+        //  per CU hides the halo gather's and the stores' latency -- the kernel is a 3.4 GB write per 25 tiles)
+        static const int grid_mult = getenv("BOA_FIRST_GRID") ? std::max(1, atoi(getenv("BOA_FIRST_GRID"))) : 4;
+        hipLaunchKernelGGL(k_conv_first_mfma, dim3((unsigned)std::min<long long>((long long)m.vw * N, (long long)ctx->cu_count * grid_mult)),
+                           dim3(256), 0, ctx->stream, m);
         ctx->counters[BOA_CNT_FIRST_MFMA]++;
         tm.stop();
         BOA_HIP_TRY(hipGetLastError());
@@ -1397,20 +1400,26 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
     static const bool no_rw = getenv("BOA_CONVT_NO_RW") != nullptr;
     const bool rw = !no_rw && s[2] == 2 && src.ss16 != nullptr && (src.C == 64 || src.C == 128);
     if (rw) {
-        // register-weights variant: 4 groups of 32 voxels per wave (512 voxels per block)
-        constexpr int G = 4;
+        // register-weights variant: G groups of 32 voxels per wave (G x 128 voxels per block)
+        static const int g128 = getenv("BOA_CONVT_G128") ? atoi(getenv("BOA_CONVT_G128")) : 2;   // (32^3 -> 64^3: 125 -> 105 us per 8 tiles: two workgroups per CU)
+        static const int g64 = getenv("BOA_CONVT_G64") ? atoi(getenv("BOA_CONVT_G64")) : 2;
+        const int G = src.C == 64 ? g64 : g128;
         const int gxr = (int)((total + 128 * G - 1) / (128 * G));
         const int gyr = std::min(npairs, std::max(1, ceil_div(gy_mult * ctx->cu_count, gxr)));
         const size_t ldsr = (size_t)4 * ((size_t)G * (src.C / 16) * 1024 + 2 * 32 * 2 * 32);
-        if (src.C == 64) {
-            static bool o1 = (hipFuncSetAttribute((const void*)k_convt_mfma_rw<2, 4, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-            (void)o1;
-            hipLaunchKernelGGL((k_convt_mfma_rw<2, 4, G>), dim3(gxr, gyr), dim3(256), ldsr, ctx->stream, a);
-        } else {
-            static bool o2 = (hipFuncSetAttribute((const void*)k_convt_mfma_rw<2, 8, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-            (void)o2;
-            hipLaunchKernelGGL((k_convt_mfma_rw<2, 8, G>), dim3(gxr, gyr), dim3(256), ldsr, ctx->stream, a);
-        }
+        static bool o1 = (hipFuncSetAttribute((const void*)k_convt_mfma_rw<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                          hipFuncSetAttribute((const void*)k_convt_mfma_rw<2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                          hipFuncSetAttribute((const void*)k_convt_mfma_rw<2, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                          hipFuncSetAttribute((const void*)k_convt_mfma_rw<2, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)o1;
+        if (src.C == 64 && G == 4)
+            hipLaunchKernelGGL((k_convt_mfma_rw<2, 4, 4>), dim3(gxr, gyr), dim3(256), ldsr, ctx->stream, a);
+        else if (src.C == 64)
+            hipLaunchKernelGGL((k_convt_mfma_rw<2, 4, 2>), dim3(gxr, gyr), dim3(256), ldsr, ctx->stream, a);
+        else if (G == 4)
+            hipLaunchKernelGGL((k_convt_mfma_rw<2, 8, 4>), dim3(gxr, gyr), dim3(256), ldsr, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_convt_mfma_rw<2, 8, 2>), dim3(gxr, gyr), dim3(256), ldsr, ctx->stream, a);
     } else if (s[2] == 2)
         hipLaunchKernelGGL(k_convt_mfma<2>, dim3(gx, gy), dim3(256), lds, ctx->stream, a);
     else
