@@ -155,9 +155,10 @@ class BcaPipelineHip:
         finally:
             d_ct.free()
 
-    def _both_nets_two_streams(self, d_ct, affine, force_split, raw_regions, done_regions, keep):
+    def _both_nets_two_streams(self, d_ct, affine, force_split, raw_regions, done_regions, keep, crop_body=False):
         """body_parts on `parts_ctx` (worker thread), body_regions on `ctx` (calling thread); hand-over by value: the CT is
-        copied into the second pool before the net starts, the cleaned labels back after that stream synchronised."""
+        copied into the second pool before the net starts, the cleaned labels back after that stream synchronised.
+        `crop_body`: body_regions needs the body mask first -- the two nets then run one after the other."""
         import threading
         ctx, pctx = self.ctx, self.parts_ctx
         ctx.sync()                                    # the CT is complete before the other stream copies it
@@ -172,20 +173,32 @@ class BcaPipelineHip:
             except BaseException as e:  # noqa: BLE001  (re-raised on the calling thread)
                 box["error"] = e
 
+        def parts_here():
+            if "error" in box:
+                raise RuntimeError("the body_parts lane failed") from box["error"]
+            d = box["parts"].to_context(ctx)
+            keep.append(d)
+            ctx.sync()                                # the copy is done before its source goes back to the other pool
+            box.pop("parts").free()
+            return d
+
         th = threading.Thread(target=lane, name="boa-lane-body-parts")
         th.start()
+        d_parts = None
         try:
-            d_regions = self._inference_device("body_regions", d_ct, affine, force_split, None, raw_regions, done_regions)
+            if crop_body:
+                th.join()
+                d_parts = parts_here()
+            crop = d_parts.download() if crop_body else None
+            d_regions = self._inference_device("body_regions", d_ct, affine, force_split, crop, raw_regions, done_regions)
             keep.append(d_regions)
         finally:
             th.join()
             ct_p.free()
-        if "error" in box:
-            raise RuntimeError("the body_parts lane failed") from box["error"]
-        d_parts = box["parts"].to_context(ctx)
-        keep.append(d_parts)
-        ctx.sync()                                    # the copy is done before its source goes back to the other pool
-        box["parts"].free()
+            if "error" in box and "parts" in box:
+                box.pop("parts").free()
+        if d_parts is None:
+            d_parts = parts_here()
         return d_parts, d_regions
 
     def _lps_zyx(self, d: DevArray, affine: np.ndarray, dtype=None) -> DevArray:
@@ -234,17 +247,14 @@ class BcaPipelineHip:
         # both nets see the same CT at the same (sx, sy, 5 mm) grid: the cubic resampling runs once (unless the second net
         # works on a body crop)
         rs_cache: dict = {}
-        two_streams = (self.parts_ctx is not None and not crop_body and raw_parts is None and done_parts is None
-                       and "body_parts" in self.tasks)
+        two_streams = self.parts_ctx is not None and raw_parts is None and done_parts is None and "body_parts" in self.tasks
         if not two_streams:
             for t in self.tasks.values():
                 t.resample_cache = rs_cache
         try:
             if two_streams:
-                d_parts, d_regions = self._both_nets_two_streams(d_ct, affine, force_split, raw_regions, done_regions, keep)
+                d_parts, d_regions = self._both_nets_two_streams(d_ct, affine, force_split, raw_regions, done_regions, keep, crop_body)
             else:
-                if self.parts_ctx is not None and "body_parts" in self.tasks and done_parts is None and raw_parts is None:
-                    raise NotImplementedError("crop_body with a parts_ctx: build the pipeline on one Context")
                 d_parts = self._inference_device("body_parts", d_ct, affine, force_split, None, raw_parts, done_parts)
                 keep.append(d_parts)
                 crop = d_parts.download() if crop_body else None

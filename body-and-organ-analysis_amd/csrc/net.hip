@@ -816,7 +816,6 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
     BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_acc && dev_n && host_defer_planes && stash_out,
                 "boa_net_predict_sliding_window_deferred: NULL argument");
     const boa_net_desc& d = net->d;
-    BOA_REQUIRE(net->precision == 0, "deferred sliding window (tile sharding) is not available in the fp32 exact mode");
     BOA_REQUIRE(net->mirror_mask == 0, "deferred sliding window (tile sharding) is not available with test-time mirroring");
     const int zero[3] = {0, 0, 0};
     const int* off = vol_off ? vol_off : zero;
@@ -827,6 +826,8 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
     const int F = d.features[0];
     const size_t plane = (size_t)d.patch[1] * d.patch[2];
     const size_t pv = (size_t)d.patch[0] * plane;
+    const bool f32 = net->precision == 1;   // exact mode: channels-last fp32 records, the first dp planes are a contiguous prefix
+    const size_t esz = f32 ? 4 : 2;
     boa_stash* st = new boa_stash;
     st->ctx = net->ctx;
     size_t bytes = 0;
@@ -839,7 +840,7 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
         if (dp == 0) continue;
         boa_stash::Item it;
         it.act_off = bytes;
-        bytes += ((size_t)dp * plane * F * 2 + 255) / 256 * 256;
+        bytes += ((size_t)dp * plane * F * esz + 255) / 256 * 256;
         it.ss_off = bytes;
         bytes += 256 * ((F * 2 * 4 + 255) / 256);
         it.planes = dp;
@@ -858,7 +859,7 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
         ConvLayer& last = net->dec.back().back();
         for (int i = 0; i < nb && rc == BOA_OK; ++i) {
             const int* stt = host_origins + (size_t)(t0 + i) * 3;
-            const __half* act = last.out + (size_t)i * pv * F;
+            const __half* act = f32 ? nullptr : last.out + (size_t)i * pv * F;
             const float* ss = last.ss + (size_t)i * F * 2;
             int dp = host_defer_planes[t0 + i];
             if (dp > 0) {
@@ -866,7 +867,10 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
                 // chunk-planar: the first dp axis-0 planes of every 16-channel plane; the stash keeps them planar with its own
                 // plane stride (dp * plane voxels)
                 bool ok_copy = true;
-                for (int k = 0; k < F / 16 && ok_copy; ++k)
+                if (f32)
+                    ok_copy = hipMemcpyAsync(st->arena + it.act_off, last.out32 + (size_t)i * pv * F, (size_t)dp * plane * F * 4,
+                                             hipMemcpyDeviceToDevice, net->ctx->stream) == hipSuccess;
+                for (int k = 0; !f32 && k < F / 16 && ok_copy; ++k)
                     ok_copy = hipMemcpyAsync(st->arena + it.act_off + (size_t)k * dp * plane * 32, act + (size_t)k * pv * 16,
                                              (size_t)dp * plane * 32, hipMemcpyDeviceToDevice, net->ctx->stream) == hipSuccess;
                 if (!ok_copy ||
@@ -881,9 +885,7 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
             if (dp < d.patch[0]) {
                 int P[3] = {d.patch[0] - dp, d.patch[1], d.patch[2]};
                 int s2[3] = {stt[0] + dp, stt[1], stt[2]};
-                rc = launch_head(net->ctx, act + (size_t)dp * plane * 16, ss, F, P, d.num_classes, net->head_w, net->head_b,
-                                 d.lrelu_slope, nullptr, dev_gauss ? dev_gauss + (size_t)dp * plane : nullptr, dev_acc, dev_n,
-                                 PV, s2, pv);
+                rc = net_head(net, i, P, dp, nullptr, dev_gauss ? dev_gauss + (size_t)dp * plane : nullptr, dev_acc, dev_n, PV, s2);
             }
         }
     }
@@ -901,9 +903,14 @@ extern "C" int boa_net_apply_deferred(boa_net* net, const boa_stash* st, const u
     const boa_net_desc& d = net->d;
     for (const boa_stash::Item& it : st->items) {  // the stash keeps the canonical tile order
         int P[3] = {it.planes, d.patch[1], d.patch[2]};
-        BOA_TRY(launch_head(net->ctx, (const __half*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
-                            d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
-                            dev_acc, dev_n, PV, it.start, (size_t)it.planes * d.patch[1] * d.patch[2]));
+        if (net->precision == 1)
+            BOA_TRY(launch_head_f32(net->ctx, (const float*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
+                                    d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
+                                    dev_acc, dev_n, PV, it.start));
+        else
+            BOA_TRY(launch_head(net->ctx, (const __half*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
+                                d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
+                                dev_acc, dev_n, PV, it.start, (size_t)it.planes * d.patch[1] * d.patch[2]));
     }
     return BOA_OK;
 }

@@ -65,6 +65,12 @@ def test_two_lanes_equal_one_stream():
             np.testing.assert_array_equal(alone_c[k], alone_a[k], err_msg=k)
             np.testing.assert_array_equal(alone_c[k], ref[0][k], err_msg=k)
         assert alone_c["bca_measurements"] == alone_a["bca_measurements"] == ref[2]
+        # crop_body: body_regions waits for the body mask of the other stream
+        crop_a = pipe_a.run(ct, aff, crop_body=True)
+        crop_c = pipe_c.run(ct, aff, crop_body=True)
+        for k in ("body_parts", "body_regions", "tissues"):
+            np.testing.assert_array_equal(crop_c[k], crop_a[k], err_msg=k)
+        assert crop_c["bca_measurements"] == crop_a["bca_measurements"]
         pipe_c.close()
         # the one-stream runner is unaffected by the second context's work
         again = _collect(one.run_resident(d_ct, aff))

@@ -53,10 +53,11 @@ def _ct():
     return ct
 
 
-def _predict(ctx, shard=None, model_shard=None, max_batch=1, spacing_zyx=None):
+def _predict(ctx, shard=None, model_shard=None, max_batch=1, spacing_zyx=None, precision=None):
     from boa_hip.task import SegmentationTask
     models, luts = _models()
-    task = SegmentationTask(ctx, "total", models, resample=1.5, multimodel=True, max_batch=max_batch, part_luts=luts)
+    task = SegmentationTask(ctx, "total", models, resample=1.5, multimodel=True, max_batch=max_batch, part_luts=luts,
+                            precision=precision)
     task.model_shard = model_shard
     task.step_size = 0.5
     for _, _, p, _ in task.parts:
@@ -96,11 +97,12 @@ def _worker(rank, world, port, mode, q, backend="gloo"):
         ctx = Context(0)
         comm = ts.ShardComm(dist, rank, world, "cpu")
     sp = RS_SPACING if mode.endswith("+rs") else None    # "+rs": the array is NOT at the plans' spacing (nnU-Net resamples)
-    mode = mode.replace("+rs", "")
+    prec = "fp32" if mode.endswith("+f32") else None      # "+f32": the fp32 exact mode of the network
+    mode = mode.replace("+rs", "").replace("+f32", "")
     if mode == "models":
-        lab = _predict(ctx, model_shard=comm, max_batch=4, spacing_zyx=sp)
+        lab = _predict(ctx, model_shard=comm, max_batch=4, spacing_zyx=sp, precision=prec)
     else:
-        lab = _predict(ctx, ts.TileShard(comm, mode), max_batch=3, spacing_zyx=sp)
+        lab = _predict(ctx, ts.TileShard(comm, mode), max_batch=3, spacing_zyx=sp, precision=prec)
     q.put((rank, lab))
     dist.barrier()
     ctx.close()
@@ -161,6 +163,18 @@ def test_sharding_with_plan_spacing_resampling_bit_identical(mode):
     c.close()
     assert (want != plain).mean() > 0.05          # the resampling path really ran
     got = _run(2, mode)
+    np.testing.assert_array_equal(got[0], want)
+    np.testing.assert_array_equal(got[1], want)
+
+
+def test_fp32_exact_mode_tile_sharding_bit_identical(single):
+    """The network's fp32 exact mode under tile sharding: the deferred planes keep their fp32 channels-last head input."""
+    from boa_hip.device import Context
+    c = Context(0)
+    want = _predict(c, max_batch=4, precision="fp32")
+    c.close()
+    assert 0 < (want != single).mean() < 0.05      # a different arithmetic, the same segmentation up to near-ties
+    got = _run(2, "exact+f32")
     np.testing.assert_array_equal(got[0], want)
     np.testing.assert_array_equal(got[1], want)
 
