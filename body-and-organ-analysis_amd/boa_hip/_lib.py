@@ -46,6 +46,8 @@ _PROTOS = {
     "boa_free": (i32, [vp, vp]),
     "boa_trim": (i32, [vp]),
     "boa_bind_thread": (i32, [vp]),
+    "boa_host_alloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
+    "boa_host_free": (i32, [vp, vp]),
     "boa_mfma_peak": (i32, [vp, i32, i32, C.POINTER(C.c_double)]),
     "boa_memset": (i32, [vp, vp, i32, u64]),
     "boa_h2d": (i32, [vp, vp, vp, u64]),

@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes as C
+import threading
 import weakref
 
 import numpy as np
@@ -21,6 +22,59 @@ def _close_all():
             c.close()
         except Exception:
             pass
+
+
+PINNED_MIN_BYTES = 1 << 20     # downloads of at least this many bytes land in page-locked memory (PCIe at link speed)
+
+
+PINNED_CACHE_BYTES = 8 << 30   # page-locking costs more than the copy it speeds up: released blocks are kept for reuse up to this
+_PINNED_FREE: dict = {}        # rounded size -> [host pointers]
+_PINNED_CACHED = [0]
+_PINNED_LOCK = threading.Lock()
+
+
+def _pinned_round(nbytes: int) -> int:
+    return (int(nbytes) + (2 << 20) - 1) & ~((2 << 20) - 1)
+
+
+class _PinnedBlock:
+    """Page-locked host memory (boa_host_alloc) exposed through the array interface; goes back to the process-wide cache (or
+    to the system beyond PINNED_CACHE_BYTES) with the last array viewing it."""
+
+    def __init__(self, lib, ptr: int, nbytes: int, size: int):
+        self._lib, self._ptr, self._size = lib, ptr, size
+        self.__array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            with _PINNED_LOCK:
+                if _PINNED_CACHED[0] + self._size <= PINNED_CACHE_BYTES:
+                    _PINNED_FREE.setdefault(self._size, []).append(self._ptr)
+                    _PINNED_CACHED[0] += self._size
+                    return
+            self._lib.boa_host_free(None, C.c_void_p(self._ptr))
+        except Exception:
+            pass
+
+
+def _pinned_take(size: int):
+    with _PINNED_LOCK:
+        lst = _PINNED_FREE.get(size)
+        if lst:
+            _PINNED_CACHED[0] -= size
+            return lst.pop()
+    return None
+
+
+def pinned_trim(lib=None):
+    """Release every cached page-locked block."""
+    lib = lib or _lib.lib()
+    with _PINNED_LOCK:
+        for lst in _PINNED_FREE.values():
+            for ptr in lst:
+                lib.boa_host_free(None, C.c_void_p(ptr))
+        _PINNED_FREE.clear()
+        _PINNED_CACHED[0] = 0
 
 
 class DeviceBuffer:
@@ -54,7 +108,8 @@ class DeviceBuffer:
         return self
 
     def download(self, shape, dtype) -> np.ndarray:
-        out = np.empty(shape, dtype=dtype)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        out = self.ctx.pinned_empty(shape, dtype) if nbytes >= PINNED_MIN_BYTES else np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes, (out.nbytes, self.nbytes)
         check(self.ctx.lib.boa_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), out.nbytes))
         return out
@@ -87,7 +142,8 @@ class BufferView:
             check(self.ctx.lib.boa_memset(self.ctx.h, self.vp, 0, self.nbytes))
 
     def download(self, shape, dtype) -> np.ndarray:
-        out = np.empty(shape, dtype=dtype)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        out = self.ctx.pinned_empty(shape, dtype) if nbytes >= PINNED_MIN_BYTES else np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes, (out.nbytes, self.nbytes)
         if out.nbytes:
             check(self.ctx.lib.boa_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.vp, out.nbytes))
@@ -128,6 +184,23 @@ class Context:
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
+
+    def pinned_empty(self, shape, dtype) -> np.ndarray:
+        """numpy array in page-locked host memory (what `torch.empty(..., pin_memory=True)` is to the reference): uploads from
+        it and downloads into it run at PCIe link speed.  Falls back to ordinary memory if the allocation is refused."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape))
+        if n == 0:
+            return np.empty(shape, dtype=dtype)
+        size = _pinned_round(n * dtype.itemsize)
+        ptr = _pinned_take(size)
+        if ptr is None:
+            p = C.c_void_p()
+            if self.lib.boa_host_alloc(self.h, size, C.byref(p)) != 0:
+                return np.empty(shape, dtype=dtype)
+            ptr = p.value
+        block = _PinnedBlock(self.lib, ptr, n * dtype.itemsize, size)
+        return np.asarray(block).view(dtype).reshape(shape)
 
     def from_numpy(self, arr: np.ndarray) -> DeviceBuffer:
         a = np.ascontiguousarray(arr)

@@ -202,6 +202,26 @@ extern "C" int boa_d2h(boa_ctx* c, void* host_dst, const void* dev_src, size_t b
     return BOA_OK;
 }
 
+extern "C" int boa_host_alloc(boa_ctx* c, size_t bytes, void** host_out) {
+    BOA_REQUIRE(c && host_out, "boa_host_alloc: NULL argument");
+    BOA_HIP_TRY(hipSetDevice(c->device));
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        boa_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return BOA_ENOMEM;
+    }
+    *host_out = p;
+    return BOA_OK;
+}
+
+extern "C" int boa_host_free(boa_ctx*, void* host) {
+    if (!host) return BOA_OK;
+    BOA_HIP_TRY(hipHostFree(host));
+    return BOA_OK;
+}
+
 extern "C" int boa_sync(boa_ctx* c) {
     BOA_REQUIRE(c, "ctx is NULL");
     c->prof_break = true;

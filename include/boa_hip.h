@@ -68,6 +68,11 @@ int boa_mfma_peak(boa_ctx* ctx, int random_operands, int iters, double* tflops_o
 int boa_memset(boa_ctx* ctx, void* dev, int value, size_t bytes);
 int boa_h2d(boa_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);   /* synchronous */
 int boa_d2h(boa_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);   /* synchronous */
+/* Page-locked host memory for the volumes that cross PCIe (what `tensor.pin_memory()` is to the reference): boa_h2d / boa_d2h
+ * from / to such a buffer run at link speed instead of through the runtime's pageable staging copies.  boa_host_free accepts
+ * ctx == NULL (the buffer may outlive the context that allocated it). */
+int boa_host_alloc(boa_ctx* ctx, size_t bytes, void** host_out);
+int boa_host_free(boa_ctx* ctx, void* host);
 int boa_sync(boa_ctx* ctx);
 /* HIP-event timing on the context stream: ms between the two marks (boa_timer_stop synchronises). */
 int boa_timer_start(boa_ctx* ctx, int slot);

@@ -36,3 +36,33 @@ def test_pool_reuses_blocks_in_stream_order_and_trims():
     np.testing.assert_array_equal(e.download((1 << 18,), np.int32), x[: 1 << 18])
     e.free()
     ctx.close()
+
+
+def test_pinned_host_arrays_round_trip_and_are_reused():
+    """Context.pinned_empty / DeviceBuffer.download: page-locked numpy arrays (boa_host_alloc); a released block is handed out
+    again for a request of the same rounded size instead of being page-locked anew."""
+    from boa_hip import device
+    from boa_hip.device import Context
+    c = Context(0)
+    try:
+        a = c.pinned_empty((300, 200, 40), np.int16)
+        a[...] = np.random.default_rng(0).integers(-1000, 3000, size=a.shape, dtype=np.int16)
+        ptr = a.ctypes.data
+        d = c.from_numpy(a)
+        back = d.download(a.shape, np.int16)
+        np.testing.assert_array_equal(back, a)
+        assert back.ctypes.data != ptr
+        keep = a.copy()
+        del a
+        b = c.pinned_empty((300, 200, 40), np.int16)       # same rounded size: the cached block
+        assert b.ctypes.data == ptr
+        b[...] = 7
+        assert keep.max() > 7                                # the copy was not affected
+        small = d.download((10,), np.int16)                  # small transfers stay in ordinary memory
+        np.testing.assert_array_equal(small, keep.ravel()[:10])
+        d.free()
+        del b, back
+        device.pinned_trim(c.lib)
+        assert device._PINNED_CACHED[0] == 0
+    finally:
+        c.close()

@@ -17,6 +17,8 @@ tid, cfg, blob, _ = synthetic.total_part_models()[0]
 p = HipPredictor(ctx, cfg.geometry, tile_step_size=0.8, max_batch=batch)
 p.set_parameters([blob])
 vol = np.random.default_rng(0).standard_normal((1, 160, 160, 224)).astype(np.float32)
+if os.environ.get("LAYER_PROF_ZERO"):     # degenerate data: what the same instruction stream does when no operand bits toggle
+    vol[:] = 0
 origins = np.array([[0, 0, 0], [32, 32, 96], [16, 8, 40], [32, 0, 64], [0, 32, 0], [8, 8, 8], [1, 2, 3], [30, 30, 90]][:batch], dtype=np.int32)
 for it in range(2):
     print(f"--- pass {it}", file=sys.stderr)
