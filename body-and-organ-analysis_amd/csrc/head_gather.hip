@@ -19,7 +19,7 @@
 #include "conv.h"
 
 #ifndef GH_WAVES
-#define GH_WAVES 4
+#define GH_WAVES 6   // (4: 8.5 ms, 5: 7.5, 6: 7.2, 8: 7.2 per 512^3 part model -- latency-bound: occupancy pays more than the ~20 spilled registers cost)
 #endif
 typedef _Float16 gh2_t __attribute__((ext_vector_type(2)));
 
@@ -136,9 +136,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
         const int x = (int)(row / (unsigned)p.V1), y = (int)(row - (unsigned)(row / (unsigned)p.V1) * (unsigned)p.V1);
         const int z = zb + l31;
         const bool zvalid = z < p.V2;
-        float acc[16];
+        // the C running sums of this lane's 16 classes as 8 packed fp16 pairs (what the reference's fp16 accumulator planes hold)
+        unsigned acch[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 8; ++i) acch[i] = 0u;
         float nacc = 0.f;
         // covering tiles in ascending tile index: x outermost, z innermost (predict_from_raw_data.py:506-538)
         // (wave-uniform table look-ups: scalar loads; the first version scanned the origins in LDS and divided per pair -- the walk
@@ -193,10 +194,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
                         for (int i = 0; i < 8; ++i) {
                             const gf2_t sum = gf2_t{d[2 * i], d[2 * i + 1]} + gf2_t{s_bz[kh][2 * i], s_bz[kh][2 * i + 1]};
                             const gf2_t pr = GAUSS ? sum * gf2_t{g, g} : sum;                    // prediction *= gaussian (fp32)
-                            const gf2_t t = gf2_t{acc[2 * i], acc[2 * i + 1]} + pr;              // fp16 += fp32: fp32 add ...
-                            const gh2_t h = __builtin_convertvector(t, gh2_t);                   // ... RTNE to fp16
-                            acc[2 * i] = (float)h.x;
-                            acc[2 * i + 1] = (float)h.y;
+                            // fp16 += fp32: fp32 add, RTNE to fp16 -- v_fma_mix{lo,hi}_f16 with a multiplier of 1.0 is exactly that
+                            // (fp32 fma of (pr, 1.0, float(acc half)), then the conversion), one instruction per entry instead of
+                            // unpack + add + pack
+                            asm("v_fma_mixlo_f16 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+                                "v_fma_mixhi_f16 %0, %2, 1.0, %0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                : "+v"(acch[i])
+                                : "v"(pr.x), "v"(pr.y));
                         }
                         nacc = us2f(f2us(nacc + g));
                     }
@@ -204,6 +208,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
             }
         }
         // normalise, fold sum / mean, argmax (k_finalize_labels)
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[2 * i] = us2f((unsigned short)(acch[i] & 0xFFFFu));
+            acc[2 * i + 1] = us2f((unsigned short)(acch[i] >> 16));
+        }
         float best = 0.f;
         int bidx = 1 << 20;
         bool bnan = false, have = false;
