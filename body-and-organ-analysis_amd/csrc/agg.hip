@@ -541,12 +541,16 @@ extern "C" int boa_binary_erode(boa_ctx* c, const uint8_t* dev_mask, uint8_t* de
 #define AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 __device__ __forceinline__ int uf_find(int* L, int i) {
-    // path halving: every node on the way is re-pointed to its grandparent (a plain store: parents only ever move towards
-    // the root, so a racing walker at worst takes the longer way)
+    // path halving: every node on the way is re-pointed to its grandparent (parents only ever move towards the root, so a racing
+    // walker at worst takes the longer way).  The store is an agent-scope atomic store like every other access to L in the
+    // union kernels: a plain store stays dirty in the L2 of the XCD that issued it, and when that line is written back it can
+    // take stale copies of NEIGHBOURING words with it -- words that another XCD's atomicMin has meanwhile changed at the
+    // memory side.  Measured: with plain stores 1 labelling in ~200 lost one union (a voxel keeps a root that was merged away)
+    // whenever a second stream kept the GPU busy (tools/ccl_stress.py, tests/test_gpu_lanes.py); with atomic stores 0 in 2 400.
     int p = AGENT_LOAD(&L[i]);
     while (p != i) {
         const int gp = AGENT_LOAD(&L[p]);
-        if (gp != p) L[i] = gp;
+        if (gp != p) __hip_atomic_store(&L[i], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         i = p;
         p = gp;
     }
@@ -790,7 +794,8 @@ __global__ __launch_bounds__(256) void k_ccl_resolve(size_t n, int* L, unsigned 
                 const unsigned int c = sizes[i];
                 if (c) {
                     atomicAdd(&sizes[root], c);
-                    sizes[i] = 0;
+                    // (agent-scope store, not a plain one: the same line may hold a root's count that other XCDs are adding to)
+                    __hip_atomic_store(&sizes[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }

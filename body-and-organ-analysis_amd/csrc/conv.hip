@@ -660,13 +660,19 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
         a0[i] = (_Float16)p.w[k0 * 32 + l31];
         a1[i] = k1 < 27 ? (_Float16)p.w[k1 * 32 + l31] : (_Float16)0.f;
     }
+    // MFMA column (lane l31) <-> voxel lv of the 32-voxel row: even lanes take voxels 0-15, odd lanes 16-31, so that after the
+    // register transpose the lane pair (2m, 2m + 1) can exchange one 16-byte piece and ONE store instruction writes the complete
+    // 32-byte records of voxels 0-15 (the next one 16-31): whole 64-byte lines per instruction in this write-bound kernel
+    // (column = voxel made every instruction write bytes [0, 16) or [16, 32) of all 32 records)
+    const int lv = (l31 >> 1) + ((l31 & 1) << 4);
+    const bool odd = (l31 & 1) != 0;
     // LDS offsets (in halves) of this lane's 16 taps relative to the M-tile's first halo voxel
     int toff[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         int t = (i < 8 ? 8 * kh + i : 16 + 8 * kh + (i - 8));
         t = t < 27 ? t : 26;  // padded taps: any finite value (their weights are zero)
-        toff[i] = ((t / 9) * H1 + (t / 3) % 3) * H2 + t % 3 + l31;
+        toff[i] = ((t / 9) * H1 + (t / 3) % 3) * H2 + t % 3 + lv;
     }
     float4 bq[4];
 #pragma unroll
@@ -885,11 +891,19 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
                 w8[pr * 4 + 2] = pk(hi4[0], hi4[1]);
                 w8[pr * 4 + 3] = pk(hi4[2], hi4[3]);
             }
-            // chunk-planar [N][2][voxel][16]: lane (voxel, kh) owns plane kh -> a wave stores two runs of 1 KiB
-            __half* dst = p.out + ((size_t)(n * 2 + kh) * ovox + ((size_t)(tx * MF0 + x) * p.P1 + ty * MF1 + y) * p.P2 + tz * MF2 + l31) * 16;
+            // chunk-planar [N][2][voxel][16]: lane pair (2m, 2m + 1) of plane kh writes voxel m's record, then voxel 16 + m's
+            unsigned wa[4], wb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned n0 = (unsigned)__builtin_amdgcn_mov_dpp((int)w8[i], 0xB1, 0xF, 0xF, true);       // neighbour's piece 0
+                const unsigned n1 = (unsigned)__builtin_amdgcn_mov_dpp((int)w8[4 + i], 0xB1, 0xF, 0xF, true);   // neighbour's piece 1
+                wa[i] = odd ? n1 : w8[i];
+                wb[i] = odd ? w8[4 + i] : n0;
+            }
+            __half* dst = p.out + ((size_t)(n * 2 + kh) * ovox + ((size_t)(tx * MF0 + x) * p.P1 + ty * MF1 + y) * p.P2 + tz * MF2 + (l31 >> 1)) * 16 + (odd ? 8 : 0);
             // (streaming `nt` stores were measured: 0 ... -10 %)
-            *(uint4*)dst = make_uint4(w8[0], w8[1], w8[2], w8[3]);
-            *(uint4*)(dst + 8) = make_uint4(w8[4], w8[5], w8[6], w8[7]);
+            *(uint4*)dst = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+            *(uint4*)(dst + 16 * 16) = make_uint4(wb[0], wb[1], wb[2], wb[3]);
         }
         if (more) commit(buf ^ 1);
         __syncthreads();

@@ -367,3 +367,68 @@ def test_overview_and_l3_axes_on_resident_volumes(ctx):
     assert report.major_minor_axis(ctx, d_t, d_b, 99, (0.8, 0.8)) == (None, None)
     d_t.free()
     d_b.free()
+
+
+def test_ccl26_is_deterministic_next_to_a_second_stream():
+    """Roots are a function of the mask alone -- also while a second context / stream keeps the GPU busy with the body_parts
+    post-processing (its own CCLs, hole filling).  Regression: the union-find's path-halving stores were plain stores; a line
+    that stayed dirty in one XCD's L2 could take stale copies of neighbouring parent words with it when it was written back and
+    undo another XCD's memory-side atomicMin -- one lost union in ~200 labellings, only when something else shared the GPU
+    (tools/ccl_stress.py).  All stores to the parent array in the union kernels are agent-scope atomic stores now."""
+    import ctypes as C
+    import threading
+    from scipy import ndimage
+    from boa_hip import bca
+    from boa_hip._lib import check
+    from boa_hip.device import Context
+    shape = (96, 160, 224)
+    rng = np.random.default_rng(3)
+    sm = ndimage.gaussian_filter(rng.standard_normal(shape), 2.0)
+    lab = np.zeros(shape, np.uint8)
+    lab[sm > 0.02] = 9
+    lab[(sm > 0.02) & (rng.random(shape) < 0.2)] = 5
+    lab[sm < -0.25] = 3
+    masks = [lab != 0, (lab == 9) | (lab == 5), lab == 5, lab == 3]
+    n = int(np.prod(shape))
+    c0, c1 = Context(0), Context(0)
+    stop = [False]
+
+    def other_stream():
+        c1.bind_thread()
+        pl = np.zeros(shape, np.uint8)
+        pl[sm > 0.0] = 1
+        pl[sm < -0.1] = 2
+        while not stop[0]:
+            dd = c1.from_numpy(pl)
+            out = bca.postprocess_part_segmentation_device(c1, dd, shape)
+            c1.sync()
+            out.free()
+            dd.free()
+
+    try:
+        d_m = [c0.from_numpy(m.astype(np.uint8)) for m in masks]
+        d_r, d_s = c0.alloc(n * 4), c0.alloc(n * 4)
+
+        def roots(k):
+            check(c0.lib.boa_ccl26(c0.h, d_m[k].vp, shape[0], shape[1], shape[2], d_r.vp, d_s.vp, None), "boa_ccl26")
+            return d_r.download(shape, np.int32), d_s.download((n,), np.uint32)
+
+        ref = [roots(k) for k in range(len(masks))]
+        for k, m in enumerate(masks):       # the reference itself against scipy: root = smallest linear index of the component
+            lab_k, ncomp = ndimage.label(m, structure=np.ones((3, 3, 3)))
+            first = ndimage.minimum(np.arange(n).reshape(shape), lab_k, index=np.arange(1, ncomp + 1)).astype(np.int64)
+            np.testing.assert_array_equal(ref[k][0][m], first[lab_k[m] - 1])
+        th = threading.Thread(target=other_stream)
+        th.start()
+        try:
+            for it in range(1200):
+                k = it % len(masks)
+                got_r, got_s = roots(k)
+                assert np.array_equal(got_r, ref[k][0]), f"iteration {it}, mask {k}: {(got_r != ref[k][0]).sum()} roots differ"
+                assert np.array_equal(got_s, ref[k][1]), f"iteration {it}, mask {k}: component sizes differ"
+        finally:
+            stop[0] = True
+            th.join()
+    finally:
+        c0.close()
+        c1.close()
