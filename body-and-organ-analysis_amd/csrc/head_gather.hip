@@ -67,8 +67,11 @@ __global__ void k_pack_head_ss(const float* __restrict__ ss, unsigned* __restric
     }
 }
 
-template <bool GAUSS, bool SSLDS>
+// MULTI: several folds (fold buffer read-modify-write, general epilogue); the single-fold instantiation carries none of that code
+// (its 16 per-class plane pointers were the registers that spilled at six waves per SIMD)
+template <bool GAUSS, bool SSLDS, bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8))) void k_gather_head(GatherArgs p) {
+    const int fold_mode = MULTI ? p.fold_mode : 0;
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
     const int* __restrict__ sx = p.tab;
     const int* __restrict__ sy = p.tab + p.n0;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
         // is the LOWEST class whose quotient equals the maximum's; only classes within 2^-8 of the largest sum can round to the
         // same half, and those few get their exact quotient.  NaN sums, quotients in the fp16-subnormal range and a zero maximum
         // take the general path (wave-uniform).
-        bool fast = p.fold_mode == 0;
+        bool fast = fold_mode == 0;
         float amax = 0.f, amin = 0.f, asum = 0.f;
         int imax = 1 << 20;
         if (fast) {
@@ -285,11 +288,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
             if (c >= p.C || !zvalid) continue;
             unsigned short h = f2us(__fdiv_rn(acc[i], nacc));   // torch.div(half, half): fp32 divide, RTNE to half
             if ((h & 0x7FFF) == 0x7C00) any_inf = true;
-            if (p.fold_mode != 0) {
+            if (fold_mode != 0) {
                 unsigned short* fp = p.fold + (size_t)c * vv + vi;
-                if (p.fold_mode >= 2) h = f2us(us2f(*fp) + us2f(h));                                  // prediction += fold
-                if (p.fold_mode == 3 && p.n_folds > 1) h = f2us(__fdiv_rn(us2f(h), (float)p.n_folds));  // prediction /= n_folds
-                if (p.fold_mode != 3) {
+                if (fold_mode >= 2) h = f2us(us2f(*fp) + us2f(h));                                  // prediction += fold
+                if (fold_mode == 3 && p.n_folds > 1) h = f2us(__fdiv_rn(us2f(h), (float)p.n_folds));  // prediction /= n_folds
+                if (fold_mode != 3) {
                     *fp = h;
                     continue;
                 }
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
             }
         }
         }
-        if (p.fold_mode == 1 || p.fold_mode == 2) continue;
+        if (fold_mode == 1 || fold_mode == 2) continue;
         // the voxel's other 16 classes live in lane ^ 32: combine (NaN first, then value, then the lower class index)
         if (!fast) {
             const float ob = __shfl_xor(best, 32);
@@ -388,18 +391,25 @@ int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, con
     const double bytes = (double)tiles_total * pvd * 66.0 + vvd * (fold_mode == 0 ? 1.0 : (fold_mode == 1 ? 2.0 * C : 4.0 * C));
     const size_t ss_bytes = (size_t)tiles_total * 128;
     a.ss_in_lds = ss_bytes <= 96 * 1024 ? 1 : 0;
-    static bool once = (hipFuncSetAttribute((const void*)k_gather_head<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
-                        hipFuncSetAttribute((const void*)k_gather_head<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
+    static bool once = (hipFuncSetAttribute((const void*)k_gather_head<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
     (void)once;
     KernelTimer tm(ctx, BOA_K_HEAD_ACCUM, 2.0 * (double)tiles_total * pvd * 32 * C, bytes);
-    if (gauss && a.ss_in_lds)
-        hipLaunchKernelGGL((k_gather_head<true, true>), dim3(grid), dim3(256), ss_bytes, ctx->stream, a);
-    else if (gauss)
-        hipLaunchKernelGGL((k_gather_head<true, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
-    else if (a.ss_in_lds)
-        hipLaunchKernelGGL((k_gather_head<false, true>), dim3(grid), dim3(256), ss_bytes, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((k_gather_head<false, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    const size_t lds = a.ss_in_lds ? ss_bytes : 0;
+#define GH_LAUNCH(G, S, M) hipLaunchKernelGGL((k_gather_head<G, S, M>), dim3(grid), dim3(256), lds, ctx->stream, a)
+    const bool multi = fold_mode != 0;
+    if (gauss && a.ss_in_lds) {
+        if (multi) GH_LAUNCH(true, true, true); else GH_LAUNCH(true, true, false);
+    } else if (gauss) {
+        if (multi) GH_LAUNCH(true, false, true); else GH_LAUNCH(true, false, false);
+    } else if (a.ss_in_lds) {
+        if (multi) GH_LAUNCH(false, true, true); else GH_LAUNCH(false, true, false);
+    } else {
+        if (multi) GH_LAUNCH(false, false, true); else GH_LAUNCH(false, false, false);
+    }
+#undef GH_LAUNCH
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
