@@ -21,6 +21,33 @@ ctx_a, ctx_b, ctx_c = Context(0), Context(0), Context(0)
 bm = T._bca_models(2)
 pipe_a = BcaPipelineHip(ctx_a, bm["body_parts"], bm["body_regions"], fast_bca=True, max_batch=8)
 pipe_c = BcaPipelineHip(ctx_b, bm["body_parts"], bm["body_regions"], fast_bca=True, max_batch=8, parts_ctx=ctx_c if mode == "two" else None)
+if mode == "full":     # the whole total+bca runner, two and three lanes, labels and tables
+    from boa_hip import label_maps
+    from boa_hip.devarray import DevArray
+    from boa_hip.lanes import TotalBcaRunner
+    from boa_hip.task import SegmentationTask
+    lm = label_maps.measurement_label_map("total")
+    parts = [(tid, cfg, [blob]) for tid, cfg, blob, _ in synthetic.total_part_models()]
+    total = SegmentationTask(ctx_a, "total", parts, resample=1.5, multimodel=True, max_batch=8)
+    pipe_b = BcaPipelineHip(ctx_b, bm["body_parts"], bm["body_regions"], fast_bca=True, max_batch=8)
+    pipe_3 = BcaPipelineHip(ctx_b, bm["body_parts"], bm["body_regions"], fast_bca=True, max_batch=8, parts_ctx=ctx_c)
+    d_ct = DevArray.from_numpy(ctx_a, ct)
+    want = T._collect(TotalBcaRunner(total, pipe_a, lm).run_resident(d_ct, aff))
+    bad = 0
+    for it in range(n):
+        run = TotalBcaRunner(total, pipe_b if it % 2 == 0 else pipe_3, lm)
+        got = T._collect(run.run_resident(d_ct, aff))
+        for k in want[0]:
+            d = np.argwhere(got[0][k] != want[0][k])
+            if len(d):
+                bad += 1
+                print(f"run {it} ({2 + it % 2} lanes): {k}: {len(d)} voxels differ, first {d[:3].tolist()}", flush=True)
+        for j, name in ((1, "total measurements"), (2, "bca measurements"), (3, "vertebrae")):
+            if got[j] != want[j]:
+                bad += 1
+                print(f"run {it}: {name} differ", flush=True)
+    print(f"full: {n} runs, {bad} mismatches")
+    sys.exit(0)
 ref = pipe_a.run(ct, aff)
 bad = 0
 for it in range(n):
