@@ -429,13 +429,44 @@ def main():
             total_task.predict_image(d_ct, affine, return_device=True).free()
         ctx.sync()
         total_only = {"volumes_per_s": 2.0 / (time.perf_counter() - tb), "steps": 2, "tile_forwards_per_volume": 625}
+    h2h = None
+    if rank == 0 and not args.no_h2h and args.gpus == 1:
+        # PCIe-inclusive: upload the CT, download `total` + the three BCA label volumes (tables are host dicts already);
+        # median of 5 volumes
+        def host_to_host():
+            ctx.sync()
+            ts_h, chk = [], None
+            ct_host = ctx.pinned_empty(ct.shape, ct.dtype)      # the caller's buffer, page-locked (Context.pinned_empty); the label
+            ct_host[...] = ct                                    # volumes come back in page-locked arrays too (DeviceBuffer.download)
+            for _ in range(5):
+                tb = time.perf_counter()
+                d_up = DevArray.from_numpy(ctx, ct_host)
+                _, _, host = step(d_up, download=True)
+                d_up.free()
+                ctx.sync()
+                ts_h.append(time.perf_counter() - tb)
+                chk = int(np.sum(host[0], dtype=np.int64))       # (outside the clock: a checksum of the `total` labels that arrived)
+                del host
+            out = {"s_per_volume": float(np.median(ts_h)), "s_per_volume_all": ts_h, "steps": len(ts_h), "label_checksum": chk,
+                   "host_buffers": "page-locked (boa_host_alloc): 268 MB CT up, 4 x 134 MB label volumes down per volume"}
+            out["value"] = 1.0 / out["s_per_volume"]
+            return out
+
+        try:
+            h2h = host_to_host()
+        except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
+            h2h = {"error": f"{type(e).__name__}: {e}"}
+
     two_lanes = None
     if rank == 0 and with_bca and args.gpus == 1 and not args.no_lanes:
         # the product's two-lane mode (boa_hip/lanes.py): `total` + its measurements on this context's stream, both BCA nets +
         # post-processing + tissues on a second context (own stream, pool, predictors) of the same GPU; same kernels, same
         # results (tests/test_gpu_lanes.py).  Timed outside the headline region because the per-class HIP-event times of two
         # overlapping streams would no longer describe one kernel each: event profiling is off here.
+        ctx2 = ctx3 = pipe2 = None
         try:
+            check_trim = ctx.lib.boa_trim(ctx.h)                 # parked transient blocks back to the driver: the second context needs room
+            log(f"two lanes: free device memory before the second context {ctx.info()['free_mem'] / 2 ** 30:.1f} GiB (trim rc {check_trim})")
             ctx2 = Context(local_rank)
             ctx3 = Context(local_rank) if args.lanes >= 3 else None
             pipe2 = BcaPipelineHip(ctx2, bm["body_parts"], bm["body_regions"], fast_bca=False, max_batch=args.batch, parts_ctx=ctx3)
@@ -457,34 +488,16 @@ def main():
                          "note": "TotalBcaRunner with the BCA half on a second context/stream of the same GPU; event profiling off; "
                                  "labels and tables identical to the one-stream run"}
             two_lanes["lanes"] = args.lanes
-            pipe2.close()
-            ctx2.close()
-            if ctx3 is not None:
-                ctx3.close()
         except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
             two_lanes = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            for obj in (pipe2, ctx2, ctx3):
+                try:
+                    if obj is not None:
+                        obj.close()
+                except Exception:  # noqa: BLE001
+                    pass
         log(f"two lanes: {two_lanes}")
-    h2h = None
-    if rank == 0 and not args.no_h2h and args.gpus == 1:
-        # PCIe-inclusive: upload the CT, download `total` + the three BCA label volumes (tables are host dicts already);
-        # median of 5 volumes
-        ctx.sync()
-        ts_h, chk = [], None
-        ct_host = ctx.pinned_empty(ct.shape, ct.dtype)      # the caller's buffer, page-locked (Context.pinned_empty); the label
-        ct_host[...] = ct                                    # volumes come back in page-locked arrays too (DeviceBuffer.download)
-        for _ in range(5):
-            tb = time.perf_counter()
-            d_up = DevArray.from_numpy(ctx, ct_host)
-            _, _, host = step(d_up, download=True)
-            d_up.free()
-            ctx.sync()
-            ts_h.append(time.perf_counter() - tb)
-            chk = int(np.sum(host[0], dtype=np.int64))       # (outside the clock: a checksum of the `total` labels that arrived)
-            del host
-        h2h = {"s_per_volume": float(np.median(ts_h)), "s_per_volume_all": ts_h, "steps": len(ts_h), "label_checksum": chk,
-               "host_buffers": "page-locked (boa_host_alloc): 268 MB CT up, 4 x 134 MB label volumes down per volume"}
-        h2h["value"] = 1.0 / h2h["s_per_volume"]
-
     if rank == 0:
         conv = prof["conv_mfma"]
         conv_ms = conv["ms"]
