@@ -197,13 +197,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
                         for (int i = 0; i < 8; ++i) {
                             const gf2_t sum = gf2_t{d[2 * i], d[2 * i + 1]} + gf2_t{s_bz[kh][2 * i], s_bz[kh][2 * i + 1]};
                             const gf2_t pr = GAUSS ? sum * gf2_t{g, g} : sum;                    // prediction *= gaussian (fp32)
-                            // fp16 += fp32: fp32 add, RTNE to fp16 -- v_fma_mix{lo,hi}_f16 with a multiplier of 1.0 is exactly that
-                            // (fp32 fma of (pr, 1.0, float(acc half)), then the conversion), one instruction per entry instead of
-                            // unpack + add + pack
-                            asm("v_fma_mixlo_f16 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
-                                "v_fma_mixhi_f16 %0, %2, 1.0, %0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                                : "+v"(acch[i])
-                                : "v"(pr.x), "v"(pr.y));
+                            // fp16 += fp32: fp32 add, RTNE to fp16; the sums stay packed between tiles (8 registers instead of 16: the
+                            // kernel is latency-bound and wants waves, not fewer instructions).  v_fma_mix{lo,hi}_f16 with a multiplier of
+                            // 1.0 would do add + conversion in one instruction but is NOT the same arithmetic in rare cases (8 of 134 M
+                            // voxels of a 512^3 part model came out with another label than the scatter form: tests/test_gpu_fullsize.py)
+                            const float a0 = us2f((unsigned short)(acch[i] & 0xFFFFu)), a1 = us2f((unsigned short)(acch[i] >> 16));
+                            acch[i] = (unsigned)f2us(a0 + pr.x) | ((unsigned)f2us(a1 + pr.y) << 16);
                         }
                         nacc = us2f(f2us(nacc + g));
                     }

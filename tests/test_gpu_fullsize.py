@@ -197,6 +197,21 @@ def test_total_512_is_reproducible(ctx):
         runs.append(d_lab.download((nvox,), np.uint8))
     np.testing.assert_array_equal(runs[0], runs[1])
     assert len(np.unique(runs[0])) > 50
+    # the gather form of the tile loop (the default label path: one pass over the volume, fp16 running sums in registers) against
+    # the scatter form (fp16 accumulator planes, one head launch per tile in canonical order, finalize pass -- the form
+    # tests/test_gpu_head.py pins bit for bit to the oracle's accumulate) at the benchmark's full size: 125 tiles of 128^3
+    tid, p = preds[0]
+    forms = []
+    for fused in (True, False):
+        p.use_gather_head = fused
+        ctx.counters(reset=True)
+        d_lab.zero()
+        p.predict_segmentation_device(d_vol, shape, d_lab, lut=label_maps.part_lut(tid), merge=False, work=work)
+        forms.append(d_lab.download((nvox,), np.uint8))
+        assert ctx.counters()["head_valu"] == 0
+    p.use_gather_head = True
+    np.testing.assert_array_equal(forms[0], forms[1])
+    assert len(np.unique(forms[0])) > 10
     for _, p in preds:
         p.close()
     for b in list(work.values()) + [d_ct, d_vol, d_lab]:
