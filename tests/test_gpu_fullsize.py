@@ -200,19 +200,52 @@ def test_total_512_is_reproducible(ctx):
     # the gather form of the tile loop (the default label path: one pass over the volume, fp16 running sums in registers) against
     # the scatter form (fp16 accumulator planes, one head launch per tile in canonical order, finalize pass -- the form
     # tests/test_gpu_head.py pins bit for bit to the oracle's accumulate) at the benchmark's full size: 125 tiles of 128^3
-    tid, p = preds[0]
-    forms = []
-    for fused in (True, False):
-        p.use_gather_head = fused
-        ctx.counters(reset=True)
-        d_lab.zero()
-        p.predict_segmentation_device(d_vol, shape, d_lab, lut=label_maps.part_lut(tid), merge=False, work=work)
-        forms.append(d_lab.download((nvox,), np.uint8))
-        assert ctx.counters()["head_valu"] == 0
-    p.use_gather_head = True
-    np.testing.assert_array_equal(forms[0], forms[1])
-    assert len(np.unique(forms[0])) > 10
+    for tid, p in preds:       # (all five part models: 25 / 27 / 19 / 24 / 27 classes)
+        forms = []
+        for fused in (True, False):
+            p.use_gather_head = fused
+            ctx.counters(reset=True)
+            d_lab.zero()
+            p.predict_segmentation_device(d_vol, shape, d_lab, lut=label_maps.part_lut(tid), merge=False, work=work)
+            forms.append(d_lab.download((nvox,), np.uint8))
+            assert ctx.counters()["head_valu"] == 0
+        p.use_gather_head = True
+        np.testing.assert_array_equal(forms[0], forms[1], err_msg=f"part model {tid}")
+        assert len(np.unique(forms[0])) > 10
     for _, p in preds:
         p.close()
     for b in list(work.values()) + [d_ct, d_vol, d_lab]:
         b.free()
+
+
+def test_bca_folds_gather_equals_scatter_full_size(ctx):
+    """The multi-fold label path (BCA nets: fold sum / mean through the fp16 fold buffer, general epilogue of k_gather_head) at
+    the size the bench runs it -- 154 x 512 x 512 at 5 mm slices, patch 128^3, step 0.5, 98 tiles per fold, 3 folds -- against
+    the scatter form (accumulator planes + boa_finalize_labels)."""
+    from boa_hip import plans
+    from boa_hip.predictor import HipPredictor
+    shape = [154, 512, 512]
+    nvox = int(np.prod(shape))
+    pj, dj = plans.synthetic_plans(num_classes=7, spacing=(5.0, 1.5, 1.5))
+    cfg = plans.model_config_from_plans(pj, dj)
+    blobs = [plans.weight_blob_from_state_dict(cfg.geometry, plans.synthetic_state_dict(cfg.geometry, 543 + f)) for f in range(3)]
+    vol = np.random.default_rng(4).standard_normal([1] + shape).astype(np.float32)
+    d_vol, d_lab = ctx.from_numpy(vol), ctx.alloc(nvox)
+    p = HipPredictor(ctx, cfg.geometry, tile_step_size=0.5, max_batch=25)
+    p.set_parameters(blobs)
+    work = {}
+    forms = []
+    try:
+        for fused in (True, False):
+            p.use_gather_head = fused
+            ctx.counters(reset=True)
+            d_lab.zero()
+            p.predict_segmentation_device(d_vol, shape, d_lab, work=work)
+            forms.append(d_lab.download((nvox,), np.uint8))
+            assert ctx.counters()["head_valu"] == 0
+        np.testing.assert_array_equal(forms[0], forms[1])
+        assert len(np.unique(forms[0])) >= 5
+    finally:
+        p.close()
+        for b in list(work.values()) + [d_vol, d_lab]:
+            b.free()
