@@ -249,3 +249,39 @@ def test_bca_folds_gather_equals_scatter_full_size(ctx):
         p.close()
         for b in list(work.values()) + [d_vol, d_lab]:
             b.free()
+
+
+def test_ccl26_full_size_vs_scipy(ctx):
+    """boa_ccl26 on 256 x 512 x 512 (8 192 LDS tiles, every XCD takes part in the face unions) against scipy.ndimage.label:
+    number of components, root = smallest linear index of the component, sizes[root] = voxel count -- for a blobby mask (one giant
+    component + specks, the shape of a body mask) and for its inverse (what the hole filter labels)."""
+    import ctypes as C
+    from scipy import ndimage
+    from boa_hip._lib import check
+    shape = (256, 512, 512)
+    n = int(np.prod(shape))
+    rng = np.random.default_rng(17)
+    coarse = ndimage.gaussian_filter(rng.standard_normal((64, 128, 128)).astype(np.float32), 1.5)
+    sm = ndimage.zoom(coarse, 4, order=1)
+    sm += 0.02 * rng.standard_normal(shape).astype(np.float32)
+    d_r, d_s = ctx.alloc(n * 4), ctx.alloc(n * 4)
+    idx = np.arange(n, dtype=np.int64).reshape(shape)
+    try:
+        for m in (sm > 0.01, sm <= 0.01):
+            d_m = ctx.from_numpy(m.astype(np.uint8))
+            ncomp = C.c_int()
+            check(ctx.lib.boa_ccl26(ctx.h, d_m.vp, shape[0], shape[1], shape[2], d_r.vp, d_s.vp, C.byref(ncomp)), "boa_ccl26")
+            roots = d_r.download(shape, np.int32)
+            sizes = d_s.download((n,), np.uint32)
+            d_m.free()
+            lab, k = ndimage.label(m, structure=np.ones((3, 3, 3)))
+            assert ncomp.value == k and k > 100
+            assert (roots[~m] == -1).all()
+            first = ndimage.minimum(idx, lab, index=np.arange(1, k + 1)).astype(np.int64)
+            np.testing.assert_array_equal(roots[m], first[lab[m] - 1])
+            counts = np.bincount(lab.ravel(), minlength=k + 1)[1:]
+            np.testing.assert_array_equal(sizes[first], counts.astype(np.uint32))
+            assert int(sizes.astype(np.int64).sum()) == int(m.sum())      # nothing counted anywhere else
+    finally:
+        d_r.free()
+        d_s.free()
