@@ -285,3 +285,31 @@ def test_ccl26_full_size_vs_scipy(ctx):
     finally:
         d_r.free()
         d_s.free()
+
+
+def test_fill_holes_2d_full_size_vs_scipy(ctx):
+    """boa_fill_holes_2d on 96 slices of 512 x 512 (the slice size the LDS bit-flood kernel is built for) against
+    scipy.ndimage.binary_fill_holes per slice: blobby masks with enclosed holes, rings, noise, empty and full slices."""
+    from scipy import ndimage
+    from boa_hip._lib import check
+    shape = (96, 512, 512)
+    n = int(np.prod(shape))
+    rng = np.random.default_rng(23)
+    coarse = ndimage.gaussian_filter(rng.standard_normal((96, 128, 128)).astype(np.float32), (0.5, 2.0, 2.0))
+    sm = ndimage.zoom(coarse, (1, 4, 4), order=1)
+    m = np.abs(sm) > 0.08            # bands around the zero crossings removed: rings and enclosed lakes
+    m[3] = rng.random(shape[1:]) < 0.5
+    m[4] = False
+    m[5] = True
+    m[6] = True; m[6, 100:200, 0:50] = False; m[6, 300:320, 300:330] = False
+    d_m = ctx.from_numpy(m.astype(np.uint8))
+    d_i, d_t, d_o = ctx.alloc(n * 4), ctx.alloc(n), ctx.alloc(n)
+    try:
+        check(ctx.lib.boa_fill_holes_2d(ctx.h, d_m.vp, shape[0], shape[1], shape[2], d_i.vp, d_t.vp, d_o.vp))
+        out = d_o.download(shape, np.uint8).astype(bool)
+        ref = np.stack([ndimage.binary_fill_holes(m[i]) for i in range(shape[0])])
+        np.testing.assert_array_equal(out, ref)
+        assert ref.sum() > m.sum() + 10000
+    finally:
+        for b in (d_m, d_i, d_t, d_o):
+            b.free()
