@@ -313,3 +313,19 @@ def test_fill_holes_2d_full_size_vs_scipy(ctx):
     finally:
         for b in (d_m, d_i, d_t, d_o):
             b.free()
+
+
+def test_cubic_resampling_large_vs_scipy(ctx):
+    """The BCA nets' thickness resampling at volume scale (512 x 512 x 256 int16 @1.5 mm -> 512 x 512 x 77 @5 mm, order 3,
+    scipy's `zoom` semantics, TS/resampling.py:129-222): fp64 result bit-identical to scipy, and the int32 truncation the task
+    applies."""
+    from scipy import ndimage
+    from boa_hip import resample
+    from boa_hip.synthetic import ct_phantom
+    ct = ct_phantom((512, 512, 256), seed=9)
+    zoom = (1.0, 1.0, 1.5 / 5.0)
+    ref = ndimage.zoom(ct.astype(np.float64), zoom, order=3, mode="nearest")
+    out = resample.resample_img(ctx, ct, zoom, 3)
+    assert out.shape == ref.shape == (512, 512, 77)
+    np.testing.assert_array_equal(out.view(np.uint64), ref.view(np.uint64))
+    np.testing.assert_array_equal(out.astype(np.int32), ref.astype(np.int32))
