@@ -122,3 +122,39 @@ def test_lane_error_reaches_the_caller():
     finally:
         ctx_a.close()
         ctx_b.close()
+
+
+def test_two_lanes_equal_one_stream_at_bench_size():
+    """The configuration bench.py reports as `two_lanes` (512^3 @1.5 mm, five part models, both BCA nets with five folds): labels
+    and tables of the two-stream run equal the one-stream run's."""
+    from boa_hip import label_maps, synthetic
+    from boa_hip.devarray import DevArray
+    from boa_hip.device import Context
+    from boa_hip.lanes import TotalBcaRunner
+    from boa_hip.pipeline import BcaPipelineHip
+    from boa_hip.task import SegmentationTask
+    shape = (512, 512, 512)
+    ct = synthetic.ct_phantom(shape, seed=20260928)
+    aff = np.diag([-1.5, -1.5, 1.5, 1.0])
+    lm = label_maps.measurement_label_map("total")
+    ctx_a, ctx_b = Context(0), Context(0)
+    try:
+        parts = [(tid, cfg, [blob]) for tid, cfg, blob, _ in synthetic.total_part_models()]
+        total = SegmentationTask(ctx_a, "total", parts, resample=1.5, multimodel=True, max_batch=16)
+        bm = _bca_models(5)
+        pipe_a = BcaPipelineHip(ctx_a, bm["body_parts"], bm["body_regions"], fast_bca=False, max_batch=16)
+        pipe_b = BcaPipelineHip(ctx_b, bm["body_parts"], bm["body_regions"], fast_bca=False, max_batch=16)
+        d_ct = DevArray.from_numpy(ctx_a, ct)
+        ref = _collect(TotalBcaRunner(total, pipe_a, lm).run_resident(d_ct, aff))
+        got = _collect(TotalBcaRunner(total, pipe_b, lm).run_resident(d_ct, aff))
+        for k in ref[0]:
+            np.testing.assert_array_equal(got[0][k], ref[0][k], err_msg=k)
+        assert got[1] == ref[1] and got[2] == ref[2] and got[3] == ref[3]
+        assert len(np.unique(ref[0]["total"])) > 50
+        d_ct.free()
+        total.close()
+        pipe_a.close()
+        pipe_b.close()
+    finally:
+        ctx_a.close()
+        ctx_b.close()
