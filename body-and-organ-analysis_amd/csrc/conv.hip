@@ -998,10 +998,25 @@ __global__ __launch_bounds__(256) void k_norm_finalize(float* __restrict__ parti
     float* pq = partials + (((size_t)n * C + c) * 2 + 1) * nblk;
     __shared__ double red[8];
     double s = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) {
+    // (four slots per thread in flight: the loop was a chain of dependent global round trips -- 16 for the 4 096 slots of a 128^3
+    //  layer; the additions keep their order)
+    int i = threadIdx.x;
+    for (; i + 768 < nblk; i += 1024) {
+        const float a0 = ps[i], a1 = ps[i + 256], a2 = ps[i + 512], a3 = ps[i + 768];
+        const float b0 = pq[i], b1 = pq[i + 256], b2 = pq[i + 512], b3 = pq[i + 768];
+        s += (double)a0; q += (double)b0;
+        s += (double)a1; q += (double)b1;
+        s += (double)a2; q += (double)b2;
+        s += (double)a3; q += (double)b3;
+        if (clear) {  // k_conv_ws only writes the slots of waves that worked on (n, c): leave the table zeroed for the next launch
+            ps[i] = 0.f; ps[i + 256] = 0.f; ps[i + 512] = 0.f; ps[i + 768] = 0.f;
+            pq[i] = 0.f; pq[i + 256] = 0.f; pq[i + 512] = 0.f; pq[i + 768] = 0.f;
+        }
+    }
+    for (; i < nblk; i += 256) {
         s += (double)ps[i];
         q += (double)pq[i];
-        if (clear) {  // k_conv_ws only writes the slots of waves that worked on (n, c): leave the table zeroed for the next launch
+        if (clear) {
             ps[i] = 0.f;
             pq[i] = 0.f;
         }
