@@ -45,6 +45,16 @@ struct UpLayer {
 
 }  // namespace
 
+// The tile shapes of a network are chosen for a REFERENCE tile batch, not for the batch of a call or the net's max_batch: the shape
+// decides how the InstanceNorm partial sums are grouped, and results must not depend on how many tiles share a launch.
+// 16 = the product's default tile batch (with 8, the value of rounds 1-2, the 8^3 layers got half-size tiles -- 2 x 10 workgroups
+// per sample -- which at the batches actually run (16, 25) only doubled the weight streaming: 116 -> 82, 200 -> 134, 111 -> 73 us
+// per 25 tiles for the three 8^3 convs).  BOA_TILE_REF_N: experiment hook.
+static int tile_ref_batch() {
+    static const int v = getenv("BOA_TILE_REF_N") ? std::max(1, atoi(getenv("BOA_TILE_REF_N"))) : 16;
+    return v;
+}
+
 struct boa_net {
     boa_ctx* ctx = nullptr;
     boa_net_desc d{};
@@ -150,10 +160,10 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
         BOA_REQUIRE((cin0 % 16) == 0 && (cin1 % 16) == 0 && (cout % 32) == 0,
                     "conv %d+%d -> %d: channel counts must be multiples of 16 (in) / 32 (out)", cin0, cin1, cout);
         // the tile shape fixes the fp32 summation order inside the conv and the grouping of the InstanceNorm partial sums:
-        // it is chosen for a nominal batch (8 tiles, what the task drivers use), never for the actual max_batch, so that a
-        // tile's result does not depend on the batch size the network was created with
+        // it is chosen for a nominal batch (tile_ref_batch), never for the actual max_batch, so that a tile's result does not
+        // depend on the batch size the network was created with
         ConvGeom gref = L.g;
-        gref.N = 8;
+        gref.N = tile_ref_batch();
         BOA_REQUIRE(choose_conv_tile(gref, net->ctx->cu_count, &L.t), "no tile configuration fits conv %dx%dx%d", din[0],
                     din[1], din[2]);
         L.nblk = conv_nblk(L.t, net->ctx->cu_count, cout);
@@ -934,7 +944,7 @@ extern "C" int boa_conv_block_test(boa_ctx* ctx, const float* dev_in, int N, int
     g.Do = dout[0]; g.Ho = dout[1]; g.Wo = dout[2];
     ConvTile t;
     ConvGeom gref = g;
-    gref.N = 8;  // as the network does: the tile shape must not depend on the batch size
+    gref.N = tile_ref_batch();  // as the network does: the tile shape must not depend on the batch size
     BOA_REQUIRE(choose_conv_tile(gref, ctx->cu_count, &t), "conv test: no tile configuration");
     size_t vin = (size_t)dims[0] * dims[1] * dims[2], vout = (size_t)dout[0] * dout[1] * dout[2];
     __half *in16 = nullptr, *out16 = nullptr, *wpk = nullptr;

@@ -19,7 +19,8 @@ p.set_parameters([blob])
 vol = np.random.default_rng(0).standard_normal((1, 160, 160, 224)).astype(np.float32)
 if os.environ.get("LAYER_PROF_ZERO"):     # degenerate data: what the same instruction stream does when no operand bits toggle
     vol[:] = 0
-origins = np.array([[0, 0, 0], [32, 32, 96], [16, 8, 40], [32, 0, 64], [0, 32, 0], [8, 8, 8], [1, 2, 3], [30, 30, 90]][:batch], dtype=np.int32)
+base = [[0, 0, 0], [32, 32, 96], [16, 8, 40], [32, 0, 64], [0, 32, 0], [8, 8, 8], [1, 2, 3], [30, 30, 90]]
+origins = np.array([base[i % 8] for i in range(batch)], dtype=np.int32)     # (batches above 8 repeat the origins)
 for it in range(2):
     print(f"--- pass {it}", file=sys.stderr)
     p.network_forward(vol, origins)
