@@ -25,6 +25,8 @@ from .plans import NetGeometry
 
 
 class HipPredictor:
+    _PRECISIONS = {"fp16": 0, "fp32_ref": 1, "fp32": 2}
+
     def __init__(self, ctx: Context, geometry: NetGeometry, tile_step_size: float = 0.5, use_gaussian: bool = True,
                  use_mirroring: bool = False, max_batch: int = 4, verbose: bool = False, precision: Optional[str] = None,
                  allowed_mirroring_axes: Optional[Sequence[int]] = None):
@@ -45,12 +47,16 @@ class HipPredictor:
         self.verbose = verbose
         self.max_batch = int(max_batch)
         # "fp16" (default): fp16 weights / activations on the f16 matrix cores, fp32 accumulation = what the reference's CUDA
-        # path computes under autocast (predict_from_raw_data.py:648); "fp32": the exact mode = what its CPU path computes.
-        # $BOA_NET_PRECISION selects it for code that does not pass the argument (the compute/ drop-in surface).
+        # path computes under autocast (predict_from_raw_data.py:648); "fp32": what its CPU path computes -- fp32 weights,
+        # activations and accumulation -- evaluated in split precision on the matrix cores (every fp32 operand as two fp16 parts,
+        # csrc/net_x3.hip): the mode that reproduces the CPU labels; "fp32_ref": the same arithmetic on plain fp32 MFMAs straight
+        # from global memory (csrc/net_f32.hip: the slow cross-check of "fp32", and its fallback for kernel shapes the split-precision
+        # conv does not instantiate).  $BOA_NET_PRECISION selects it for code that does not pass the argument (the compute/ drop-in
+        # surface).
         import os
         precision = precision or os.environ.get("BOA_NET_PRECISION", "fp16")
-        if precision not in ("fp16", "fp32"):
-            raise ValueError(f"precision must be 'fp16' or 'fp32', got {precision!r}")
+        if precision not in self._PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self._PRECISIONS)}, got {precision!r}")
         self.precision = precision
         self.list_of_parameters: List[np.ndarray] = []
         self._desc = geometry.to_desc()
@@ -80,8 +86,16 @@ class HipPredictor:
         w = self.list_of_parameters[fold]
         if self._net is None:
             h = C.c_void_p()
-            check(self.lib.boa_net_create(self.ctx.h, C.byref(self._desc), w.ctypes.data_as(C.c_void_p), w.size,
-                                          self.max_batch, 1 if self.precision == "fp32" else 0, C.byref(h)), "boa_net_create")
+            rc = self.lib.boa_net_create(self.ctx.h, C.byref(self._desc), w.ctypes.data_as(C.c_void_p), w.size,
+                                         self.max_batch, self._PRECISIONS[self.precision], C.byref(h))
+            if rc != 0 and self.precision == "fp32":
+                # a kernel shape / channel count the split-precision kernels do not cover: the plain fp32 kernels take any
+                import warnings
+                warnings.warn("split-precision fp32 mode unavailable for this network (" + self.lib.boa_last_error().decode("utf-8", "replace") + "); using fp32_ref")
+                self.precision = "fp32_ref"
+                rc = self.lib.boa_net_create(self.ctx.h, C.byref(self._desc), w.ctypes.data_as(C.c_void_p), w.size,
+                                             self.max_batch, 1, C.byref(h))
+            check(rc, "boa_net_create")
             self._net = h
             self._loaded_fold = fold
             if self.use_mirroring and self.allowed_mirroring_axes:

@@ -33,12 +33,18 @@ struct ConvTile {
     size_t lds_bytes;
 };
 
-bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out);
+bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out, bool x3 = false);
 
 // packed weight sizes / packers (host side)
 size_t conv_wpk_halves(int Cin_total, int Cout, const int k[3]);
 void pack_conv_weights(const float* w /*[Cout][Cin][k0][k1][k2]*/, int Cin, int Cout, const int k[3], __half* dst);
 size_t convt_wpk_halves(int Cin, int Cout, const int s[3]);
+// split-precision mode (precision 2): hi / lo fp16 parts of w * scale, 8 real channels per MFMA K step
+float x3_weight_scale(const float* w, size_t n);
+size_t conv_wpk_halves_x3(int Cin_total, int Cout, const int k[3]);
+void pack_conv_weights_x3(const float* w, int Cin, int Cout, const int k[3], float scale, __half* dst);
+size_t convt_wpk_halves_x3(int Cin, int Cout, const int s[3]);
+void pack_convt_weights_x3(const float* w, int Cin, int Cout, const int s[3], float scale, __half* dst);
 void pack_convt_weights(const float* w /*[Cin][Cout][s0][s1][s2]*/, int Cin, int Cout, const int s[3], __half* dst);
 
 // Conv3d(k, stride, pad (k-1)/2) + bias over cat(src0, src1) -> out fp16 (pre-norm) and per-block partial
@@ -52,7 +58,11 @@ int conv_ws_nslots(int tiles_per_sample, int cu_count);
 // and outside the tile), fp32 VALU, stride 1.  w: dev fp32 [Cin][taps][Cout].
 int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins,
                       int N, int Cin, const int P[3], const int k[3], int Cout, const float* w, const float* bias,
-                      float* padded_scratch, __half* out, float* partials, int* nblk_out, int flip_mask = 0);
+                      float* padded_scratch, __half* out, float* partials, int* nblk_out, int flip_mask = 0, float* out32 = nullptr);
+// split-precision conv (k_conv_ws<..., X3>): fp32 octet-planar sources / output, fp32 (scale, shift) tables
+int launch_conv_x3(boa_ctx* ctx, const float* src0, const float* ss0, int C0, const float* src1, const float* ss1, int C1,
+                   const ConvGeom& g, const ConvTile& t, const __half* wpk, float wscale, const float* bias, float slope, float* out,
+                   float* partials);
 int conv_first_nblk(const int P[3], int cu_count);
 void conv_first_padded_dims(const int P[3], const int k[3], int out[3]);
 
@@ -100,6 +110,9 @@ struct ConvArgs {
     int vstep_n, vstep_j;       // k_conv_ws: grid size as (samples, virtual workgroups) = (G / vw, G % vw)
     const int* runs;            // k_conv_ws: [vw][8] = {count, cy, sp, ox0, oy0, oz0, -, -}: the run of virtual workgroup j
     unsigned long long* trace;  // debug (BOA_WS_TRACE): per-chunk s_memtime stamps of block 0, else nullptr
+    // split-precision mode (k_conv_ws<..., X3 = true>): the packed weights carry a power-of-two scale (hi / lo fp16 parts of
+    // w * wscale); the accumulators start at bias * wscale and the epilogue multiplies by winv = 1 / wscale
+    float wscale, winv;
 };
 
 __device__ __forceinline__ uint4 norm_act8(uint4 raw, const float* sc, const float* sh, float slope) {
@@ -117,7 +130,7 @@ __device__ __forceinline__ uint4 norm_act8(uint4 raw, const float* sc, const flo
     return x.u;
 }
 
-int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double flops, double bytes);
+int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double flops, double bytes, bool x3 = false);
 // fused gather head (head_gather.hip): all covering tiles of a voxel -> label, from the stash of last decoder activations
 int launch_pack_head_ss(boa_ctx* ctx, const float* ss, unsigned* out, int n_tiles);
 int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, const float* w, const float* bias, const uint16_t* gauss,
@@ -144,7 +157,11 @@ int launch_gather_tiles_f32(boa_ctx* ctx, const float* volume, const int V[3], c
 int launch_flip_accumulate(boa_ctx* ctx, const float* src, float* dst, int C, const int P[3], int flip_mask, int add, float scale);
 int launch_head_f32(boa_ctx* ctx, const float* act, const float* ss, int F0, const int P[3], int C, const float* w,
                     const float* bias, float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc, uint16_t* nacc,
-                    const int PV[3], const int start[3]);
+                    const int PV[3], const int start[3], size_t octet_stride = 0);
+// ---- split-precision mode (precision 2; net_x3.hip, k_conv_ws<..., X3>): fp32 octet planes [N][C/8][voxel][8] ---------
+int launch_convt_x3(boa_ctx* ctx, const float* src, const float* ss, int Cin, int N, const int din[3], const int s[3], int Cout,
+                    const __half* wpk, float wscale, const float* bias, float slope, float* out);
+int launch_octet_to_nchw_f32(boa_ctx* ctx, const float* in, const float* ss, float slope, int C, size_t vox, float* out);
 
 int launch_ndhwc32_to_nchw_f32(boa_ctx* ctx, const float* in, const float* ss, float slope, int C, size_t vox, float* out);
 

@@ -49,6 +49,53 @@ void pack_convt_weights(const float* w, int Cin, int Cout, const int s[3], __hal
             }
 }
 
+// ---- split-precision mode (precision 2) --------------------------------------------------------------
+// One K = 16 MFMA step covers 8 real input channels: conv [cc = Cin/8][tap][part: hi, lo][Cout][8], convT
+// [tap][cc = Cin/8][part][Cout][8]; every weight is scaled by `scale` (a power of two chosen per layer so that the largest
+// magnitude sits just below 2^14: the lo parts of typical weights then stay out of the fp16 subnormal range) and split as
+// hi = half(w s), lo = half(w s - hi).
+float x3_weight_scale(const float* w, size_t n) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(w[i]));
+    if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+    int e;
+    std::frexp(m, &e);               // m = f * 2^e, f in [0.5, 1)
+    return std::ldexp(1.f, std::max(-24, std::min(14 - e, 40)));   // m * scale in [2^13, 2^14)
+}
+
+static inline void x3_split(float v, __half* hi, __half* lo) {
+    const __half h = __float2half_rn(v);
+    *hi = h;
+    *lo = __float2half_rn(v - __half2float(h));
+}
+
+size_t conv_wpk_halves_x3(int Cin_total, int Cout, const int k[3]) { return (size_t)(Cin_total / 8) * k[0] * k[1] * k[2] * 2 * Cout * 8; }
+
+void pack_conv_weights_x3(const float* w, int Cin, int Cout, const int k[3], float scale, __half* dst) {
+    const int taps = k[0] * k[1] * k[2];
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < taps; ++t) {
+                const int cc = ci / 8, j = ci % 8;
+                const size_t o = ((((size_t)cc * taps + t) * 2 + 0) * Cout + co) * 8 + j;
+                x3_split(w[((size_t)co * Cin + ci) * taps + t] * scale, &dst[o], &dst[o + (size_t)Cout * 8]);
+            }
+}
+
+size_t convt_wpk_halves_x3(int Cin, int Cout, const int s[3]) { return (size_t)s[0] * s[1] * s[2] * Cin * Cout * 2; }
+
+void pack_convt_weights_x3(const float* w, int Cin, int Cout, const int s[3], float scale, __half* dst) {
+    const int taps = s[0] * s[1] * s[2];
+    const int ncc = Cin / 8;
+    for (int ci = 0; ci < Cin; ++ci)
+        for (int co = 0; co < Cout; ++co)
+            for (int t = 0; t < taps; ++t) {
+                const int cc = ci / 8, j = ci % 8;
+                const size_t o = ((((size_t)t * ncc + cc) * 2 + 0) * Cout + co) * 8 + j;
+                x3_split(w[((size_t)ci * Cout + co) * taps + t] * scale, &dst[o], &dst[o + (size_t)Cout * 8]);
+            }
+}
+
 // ======================================================================================================
 // tile selection
 static int next_pow2(int v) {
@@ -77,14 +124,14 @@ static int conv_variant_override() {
 // Pick the wave M-tile shape, the block tile and the kernel variant.  Cost model (cycles per 32-voxel M-tile):
 //   variant 1 (k_conv_ws): chunk time = max(MFMA time of the consumers, staging time of the producers) + barrier;
 //   variant 0 (k_conv_mfma): MFMA and staging serialised inside a block, partly hidden by the second block on the CU.
-bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
+bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out, bool x3) {
     const int dims[3] = {g.Do, g.Ho, g.Wo};
     const int taps = g.k[0] * g.k[1] * g.k[2];
-    const int ncc = g.Cin / 16;
+    const int ncc = x3 ? g.Cin / 8 : g.Cin / 16;   // split-precision mode: 8 real channels per staged chunk, two MFMAs per tap
     double best_cost = 1e30;
     bool found = false;
-    const int force = conv_variant_override();
-    if (force < 0 && conv_ns_applicable(g)) {  // N-split kernel (conv_ns.hip): stride-2 and deep layers, fixed tile shape
+    const int force = x3 ? 1 : conv_variant_override();
+    if (!x3 && force < 0 && conv_ns_applicable(g)) {  // N-split kernel (conv_ns.hip): stride-2 and deep layers, fixed tile shape
         conv_ns_tile(g, out);
         return true;
     }
@@ -135,7 +182,7 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out) {
                             // (measured: an 8x8x8 block tile of 4x1x8 wave tiles stages 26 % fewer halo voxels than 4x4x32 of 1x1x32 wave
                             // tiles and is still 2-4 % slower: rows shorter than 32 lanes cost fragment-read conflicts)
                             const double lds_pen = (g.s[2] > 1 ? 1.25 : 1.0) * (w2 < 16 ? 1.3 : (w2 < 32 ? 1.15 : 1.0));
-                            const double t_mfma = (double)taps * R * 32.0 * lds_pen;
+                            const double t_mfma = (double)taps * R * 32.0 * lds_pen * (x3 ? 2.0 : 1.0);
                             double t_chunk;
                             const double slots = cu_count;
                             if (variant == 1) {
@@ -433,6 +480,33 @@ int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const Con
     return BOA_OK;
 }
 
+// split-precision conv (precision 2): k_conv_ws<..., X3>.  Sources / output are fp32 octet planes [N][C/8][voxel][8]; `ss` the
+// producer's fp32 (scale, shift) table [N][C][2] or nullptr (raw source).  The kernel sees 2-byte channel units (2 C).
+int launch_conv_x3(boa_ctx* ctx, const float* src0, const float* ss0, int C0, const float* src1, const float* ss1, int C1,
+                   const ConvGeom& g, const ConvTile& t, const __half* wpk, float wscale, const float* bias, float slope, float* out,
+                   float* partials) {
+    BOA_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && C0 > 0, "conv_x3: input channels (%d,%d) must be multiples of 8", C0, C1);
+    BOA_REQUIRE(g.Cout % 32 == 0, "conv_x3: Cout=%d must be a multiple of 32", g.Cout);
+    BOA_REQUIRE(t.variant == 1, "conv_x3: tile variant %d", t.variant);
+    ConvArgs a;
+    a.src0 = (const __half*)src0; a.src1 = (const __half*)src1; a.ss0 = ss0; a.ss1 = ss1; a.C0 = 2 * C0; a.C1 = 2 * C1;
+    a.ss16_0 = (const unsigned*)ss0; a.ss16_1 = (const unsigned*)ss1;   // read as 16 fp32 words per 8-channel chunk
+    a.N = g.N; a.Di = g.Di; a.Hi = g.Hi; a.Wi = g.Wi; a.Do = g.Do; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Cout;
+    a.k0 = g.k[0]; a.k1 = g.k[1]; a.k2 = g.k[2]; a.s0 = g.s[0]; a.s1 = g.s[1]; a.s2 = g.s[2];
+    a.p0 = (g.k[0] - 1) / 2; a.p1 = (g.k[1] - 1) / 2; a.p2 = (g.k[2] - 1) / 2;
+    a.w0 = t.w[0]; a.w1 = t.w[1]; a.w2 = t.w[2]; a.b0 = t.b[0]; a.b1 = t.b[1]; a.b2 = t.b[2];
+    a.h0 = t.h[0]; a.h1 = t.h[1]; a.h2 = t.h[2]; a.t0 = t.tiles[0]; a.t1 = t.tiles[1]; a.t2 = t.tiles[2];
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    a.lw1 = ilog2(t.w[1]); a.lw2 = ilog2(t.w[2]); a.lb1 = ilog2(t.b[1]); a.lb2 = ilog2(t.b[2]);
+    a.wpk = wpk; a.bias = bias; a.out = (__half*)out; a.partials = partials; a.slope = slope;
+    a.wscale = wscale; a.winv = 1.0f / wscale;
+    const int taps = g.k[0] * g.k[1] * g.k[2];
+    const double vox = (double)g.N * g.Do * g.Ho * g.Wo;
+    const double flops = 2.0 * vox * taps * (C0 + C1) * g.Cout;
+    const double bytes = 4.0 * ((double)g.N * g.Di * g.Hi * g.Wi * (C0 + C1) + vox * g.Cout);
+    return launch_conv_ws(ctx, a, t, flops, bytes, true);
+}
+
 // ======================================================================================================
 // first conv: fp32 VALU, tiles gathered from the resident volume
 // Stage 1: k_gather_patches copies the N tiles out of the resident volume into a zero-padded dense fp32 buffer
@@ -477,9 +551,10 @@ struct FirstArgs {
     float* partials;
     int t0, t1, t2;
     int nblk;  // stride of the partials table (>= number of entries a launch writes)
+    float* out32;  // F32OUT: fp32 octet planes [N][Cout/8][voxel][8] (split-precision mode)
 };
 
-template <int K0, int K1, int K2>
+template <int K0, int K1, int K2, bool F32OUT>
 __global__ __launch_bounds__(256) void k_conv_first(FirstArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -561,7 +636,19 @@ __global__ __launch_bounds__(256) void k_conv_first(FirstArgs p) {
     for (int c = 0; c < 32; ++c) s[c] = q[c] = 0.f;
 #pragma unroll
     for (int v = 0; v < FV; ++v) {
-        if (ox < p.P0 && oy < p.P1 && oz + v < p.P2) {
+        if (F32OUT && ox < p.P0 && oy < p.P1 && oz + v < p.P2) {
+            // split-precision mode: the fp32 sums are stored as they are (statistics of the stored values)
+            const size_t pvox = (size_t)p.P0 * p.P1 * p.P2;
+            float* op = p.out32 + ((size_t)n * p.Cout + cout0) * pvox + ((((size_t)ox) * p.P1 + oy) * (size_t)p.P2 + (oz + v)) * 8;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                s[c] += acc[v][c];
+                q[c] = __builtin_fmaf(acc[v][c], acc[v][c], q[c]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *(float4*)(op + (size_t)(j >> 1) * 8 * pvox + 4 * (j & 1)) = make_float4(acc[v][4 * j], acc[v][4 * j + 1], acc[v][4 * j + 2], acc[v][4 * j + 3]);
+        } else if (!F32OUT && ox < p.P0 && oy < p.P1 && oz + v < p.P2) {
             const size_t pvox = (size_t)p.P0 * p.P1 * p.P2;
             __half* op = p.out + ((size_t)n * p.Cout + cout0) * pvox + ((((size_t)ox) * p.P1 + oy) * (size_t)p.P2 + (oz + v)) * 16;
             union {
@@ -929,7 +1016,7 @@ void conv_first_padded_dims(const int P[3], const int k[3], int out[3]) {
 
 int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const int vol_off[3], const int* dev_origins,
                       int N, int Cin, const int P[3], const int k[3], int Cout, const float* w, const float* bias,
-                      float* padded_scratch, __half* out, float* partials, int* nblk_out, int flip_mask) {
+                      float* padded_scratch, __half* out, float* partials, int* nblk_out, int flip_mask, float* out32) {
     BOA_REQUIRE(Cout % 32 == 0, "first conv: Cout=%d must be a multiple of 32", Cout);
     BOA_REQUIRE(Cin >= 1 && Cin <= 4, "first conv: Cin=%d unsupported (1..4)", Cin);
     const bool k333 = k[0] == 3 && k[1] == 3 && k[2] == 3, k133 = k[0] == 1 && k[1] == 3 && k[2] == 3;
@@ -940,7 +1027,7 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
     const double vox = (double)N * P[0] * P[1] * P[2];
     KernelTimer tm(ctx, BOA_K_CONV_FIRST, 2.0 * vox * k[0] * k[1] * k[2] * Cin * Cout, vox * (4.0 * Cin + 2.0 * Cout));
     static const bool fuse_gather = !(getenv("BOA_FIRST_GATHER") && atoi(getenv("BOA_FIRST_GATHER")) == 1);  // 1: separate gather kernel
-    const bool fused = fuse_gather && first_mfma_ok(Cin, P, k, Cout);
+    const bool fused = !out32 && fuse_gather && first_mfma_ok(Cin, P, k, Cout);
     if (!fused)
     hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)((pvol + 255) / 256), Cin, N), dim3(256), 0, ctx->stream, volume,
                        dev_origins, V[0], V[1], V[2], vol_off ? vol_off[0] : 0, vol_off ? vol_off[1] : 0,
@@ -948,7 +1035,7 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
                        PD[1], PD[2], flip_mask, padded_scratch);
     const int nblk_tab = conv_first_nblk(P, ctx->cu_count);
     if (nblk_out) *nblk_out = nblk_tab;
-    if (first_mfma_ok(Cin, P, k, Cout)) {
+    if (!out32 && first_mfma_ok(Cin, P, k, Cout)) {
         FirstMfmaArgs m;
         m.padded = padded_scratch; m.PX = PD[0]; m.PY = PD[1]; m.PZ = PD[2];
         m.vol = fused ? volume : nullptr; m.origins = dev_origins; m.flip = flip_mask;
@@ -972,16 +1059,24 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
     a.nblk = nblk_tab;
     a.padded = padded_scratch; a.PX = PD[0]; a.PY = PD[1]; a.PZ = PD[2];
     a.N = N; a.Cin = Cin; a.P0 = P[0]; a.P1 = P[1]; a.P2 = P[2]; a.Cout = Cout;
-    a.w = w; a.bias = bias; a.out = out; a.partials = partials;
+    a.w = w; a.bias = bias; a.out = out; a.partials = partials; a.out32 = out32;
     a.t0 = ceil_div(P[0], FT0); a.t1 = ceil_div(P[1], FT1); a.t2 = ceil_div(P[2], FT2);
     const int nblk = a.t0 * a.t1 * a.t2;
     const int HV = (FT0 + k[0] - 1) * (FT1 + k[1] - 1) * (FT2 + k[2] - 1);
     const size_t lds = ((size_t)Cin * k[0] * k[1] * k[2] * 32 + (((size_t)Cin * HV + 3) & ~(size_t)3)) * 4 + 1024;
-    if (k333)
-        hipLaunchKernelGGL((k_conv_first<3, 3, 3>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((k_conv_first<1, 3, 3>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
-    ctx->counters[BOA_CNT_FIRST_VALU]++;
+    if (out32) {
+        if (k333)
+            hipLaunchKernelGGL((k_conv_first<3, 3, 3, true>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_conv_first<1, 3, 3, true>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
+        ctx->counters[BOA_CNT_X3]++;
+    } else {
+        if (k333)
+            hipLaunchKernelGGL((k_conv_first<3, 3, 3, false>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_conv_first<1, 3, 3, false>), dim3(nblk, Cout / 32, N), dim3(256), lds, ctx->stream, a);
+        ctx->counters[BOA_CNT_FIRST_VALU]++;
+    }
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

@@ -36,7 +36,11 @@
 #define WS_PF 1  // fragment prefetch distance in taps (2 measured slower: 610 vs 664 TFLOP/s on 32->32 @128^3, batch 8)
 #endif
 
-template <int R, int K0, int K1, int K2, bool FIRST>
+// X3 (split-precision mode, conv_x3 notes below): the chunk holds 8 fp32 channels as [hi plane | lo plane] fp16, the B fragment of a
+// lane is the hi (k-half 0) or lo (k-half 1) part of its voxel's 8 channels, and a tap is TWO MFMAs: [Wh | Wh] x [Xh ; Xl] and
+// [Wl | Wl] x [Xh ; Xl] -- all four cross terms of (Wh + Wl)(Xh + Xl) in fp32 accumulators.  Both k-halves of a lane pair read the
+// same weight fragment (hi at ap + tap KiB, lo 512 B behind it).
+template <int R, int K0, int K1, int K2, bool FIRST, bool X3>
 __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R], const unsigned char* ap, int h1, int h2,
                                               f32x16 (&acc)[R], const f32x16& c0) {
     // Software pipeline over the (compile-time) taps: the A/B fragments of tap t + WS_PF are read while the MFMAs of
@@ -46,18 +50,21 @@ __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R
     constexpr int T = K0 * K1 * K2;
     constexpr int NS = WS_PF + 1;
     f16x8 a[NS];
+    f16x8 al[X3 ? NS : 1];
     f16x8 b[NS][R];
+    constexpr int NRD = R + (X3 ? 2 : 1);   // LDS reads per tap
     auto fetch = [&](int tn, int slot) {
         const int dzn = tn % K2, dyn = (tn / K2) % K1, dxn = tn / (K2 * K1);
         const int off = ((dxn * h1 + dyn) * h2 + dzn) * 16;
         a[slot] = *(const f16x8*)(ap + tn * 1024);
+        if constexpr (X3) al[slot] = *(const f16x8*)(ap + tn * 1024 + 512);
 #pragma unroll
         for (int r = 0; r < R; ++r) b[slot][r] = *(const f16x8*)(bp[r] + off);
     };
 #pragma unroll
     for (int t = 0; t < WS_PF && t < T; ++t) {
         fetch(t, t % NS);
-        __builtin_amdgcn_sched_group_barrier(0x100, R + 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -72,8 +79,12 @@ __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb], b[cb][r], acc[r], 0, 0, 0);
         }
-        if (t + WS_PF < T) __builtin_amdgcn_sched_group_barrier(0x100, R + 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, R, 0);
+        if constexpr (X3) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], b[cb][r], acc[r], 0, 0, 0);
+        }
+        if (t + WS_PF < T) __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, X3 ? 2 * R : R, 0);
     }
 }
 
@@ -82,7 +93,7 @@ __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R
 // 3 weight fragments once and feeds 3 R MFMAs -- (R + 5) KiB of LDS reads per 3 R MFMAs instead of 3 (R + 1) KiB.
 // The per-tap form asks the LDS for 160 B/clk per CU at the full MFMA rate with R = 4 (4 waves x 5 KiB per 4 MFMAs of
 // 32 clk), more than the 128 B/clk it has; this form needs 96 B/clk.
-template <int R, int K0, int K2, bool FIRST>
+template <int R, int K0, int K2, bool FIRST, bool X3>
 __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const unsigned char* ap, int h1, int h2,
                                                 f32x16 (&acc)[R], const f32x16& c0) {
     // MFMAs run in input-row order (row j feeds the pairs r + dy = j), so row j's registers are dead after its last
@@ -91,11 +102,17 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
     constexpr int G = K0 * K2;
     constexpr int NB = R + 2;
     f16x8 a[2][3];
+    f16x8 al[X3 ? 2 : 1][3];
     f16x8 b[NB];
+    constexpr int NA = X3 ? 6 : 3;   // weight fragment reads per (dx, dz) group
+    constexpr int MM = X3 ? 2 : 1;   // MFMAs per (row, dy) pair
     auto fetch_a = [&](int g, int slot) {
         const int dz = g % K2, dx = g / K2;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) a[slot][dy] = *(const f16x8*)(ap + ((dx * 3 + dy) * K2 + dz) * 1024);
+        for (int dy = 0; dy < 3; ++dy) {
+            a[slot][dy] = *(const f16x8*)(ap + ((dx * 3 + dy) * K2 + dz) * 1024);
+            if constexpr (X3) al[slot][dy] = *(const f16x8*)(ap + ((dx * 3 + dy) * K2 + dz) * 1024 + 512);
+        }
     };
     auto fetch_b = [&](int g, int jj) {
         const int dz = g % K2, dx = g / K2;
@@ -104,13 +121,13 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
     fetch_a(0, 0);
 #pragma unroll
     for (int jj = 0; jj < NB; ++jj) fetch_b(0, jj);
-    __builtin_amdgcn_sched_group_barrier(0x100, NB + 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NB + NA, 0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const int cb = g & 1;
         if (g + 1 < G) {
             fetch_a(g + 1, cb ^ 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
         }
 #pragma unroll
         for (int jj = 0; jj < NB; ++jj) {
@@ -126,13 +143,21 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cb][dy], b[jj], acc[r], 0, 0, 0);
                 }
             }
+            if constexpr (X3) {   // the lo weight parts of the same (row, dy) pairs
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = jj - dy;
+                    if (r < 0 || r >= R) continue;
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][dy], b[jj], acc[r], 0, 0, 0);
+                }
+            }
             // row jj is used by min(jj, R - 1) - max(jj - 2, 0) + 1 MFMAs (compile-time per unrolled iteration)
             if (jj == 0 || jj == NB - 1)
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MM, 0);
             else if (jj == 1 || jj == NB - 2)
-                __builtin_amdgcn_sched_group_barrier(0x008, R >= 2 ? 2 : 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, (R >= 2 ? 2 : 1) * MM, 0);
             else
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MM, 0);
             (void)cnt;
             if (g + 1 < G) {
                 fetch_b(g + 1, jj);
@@ -142,7 +167,13 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
     }
 }
 
-template <int R, int K0, int K1, int K2, bool YR>
+// X3 = split-precision mode (boa_net precision 2, the label-contract mode): activations are fp32 in OCTET planes
+// [N][C/8][voxel][8 floats] -- byte for byte the geometry of the fp16 chunk planes, so p.C0 / p.C1 count 2-byte units (2 x the real
+// channels), p.src* / p.ss16_* point at fp32 data and everything that only moves bytes (tile walk, halo addressing, weight DMA) is
+// shared; the producers normalise in fp32 and split into hi / lo fp16 LDS planes, the consumers issue two MFMAs per tap
+// (consume_chunk), the epilogue un-scales the accumulators and stores fp32.  Measured against an fp32 FMA chain the product of
+// split operands is the more accurate of the two (tools/x3_probe.hip: rms error 3.2e-7 vs 5.3e-7 of the output rms at K = 864).
+template <int R, int K0, int K1, int K2, bool YR, bool X3>
 __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_tiles, int resident_w, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -233,7 +264,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     WS_STAMP(7);
                 }
                 if (want_w) dma_weights(p, w_cc, w_cy, nxt + 2 * plane, q, taps);
-                prod_commit(p, rg, nxt, q, HV, plane, dbg);
+                if constexpr (X3)
+                    prod_commit_x3(p, rg, nxt, q, HV, plane, dbg);
+                else
+                    prod_commit(p, rg, nxt, q, HV, plane, dbg);
                 // the DMA was issued before the commit's ~2 000 cycles of work and nothing else of ours is in flight here.
                 // (Waiting at the end of the interval instead, with vmcnt(number of halo loads issued since), measured 6 %
                 // slower.)
@@ -386,7 +420,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             const float dm = ok ? 1.f : 0.f;
             float v[16];  // conv + bias: the accumulators were started at the bias
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = acc[r][i];
+            for (int i = 0; i < 16; ++i) v[i] = X3 ? acc[r][i] * p.winv : acc[r][i];
             if (TWO_SETS && two && tc.cy != 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -401,6 +435,24 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     stA.s[i] += vm;
                     stA.q[i] = __builtin_fmaf(vm, vm, stA.q[i]);
                 }
+            }
+            if constexpr (X3) {
+                // fp32 octet planes [N][Cout/8][voxel][8]: this lane's entries 4 gq .. 4 gq + 3 are couts 8 gq + 4 kh .. + 3 of its
+                // voxel = 16 contiguous bytes of plane cout0 / 8 + gq; the two k-halves of a voxel fill its 32-byte record
+                if (ok && !(dbg & 4)) {
+                    // (wave-uniform by construction; the explicit readfirstlane keeps hipcc's divergence analysis from rejecting the
+                    //  SGPR pin inside this branch: "illegal VGPR to SGPR copy")
+                    const size_t doff = ((size_t)tc.n * p.Cout + cout0) * out_vox * 4 + ((((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) + (size_t)mrel) * 32;
+                    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)doff), dhi = __builtin_amdgcn_readfirstlane((unsigned)(doff >> 32));
+                    WS_GLOBAL unsigned char* dst = sgpr_ptr((const unsigned char*)p.out + (((size_t)dhi << 32) | dlo));
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        unsigned ol = ((unsigned)srel0 * 32u + (unsigned)kh * 16u) + (unsigned)gq * ((unsigned)out_vox * 32u);
+                        asm volatile("" : "+v"(ol));
+                        *(WS_GLOBAL f32x4_t*)(dst + ol) = f32x4_t{v[gq * 4 + 0], v[gq * 4 + 1], v[gq * 4 + 2], v[gq * 4 + 3]};
+                    }
+                }
+                continue;
             }
             // (the statistics read v before the swaps below destroy it: without this fence hipcc hoists the swaps and pays 16
             //  register copies per M-tile to keep v alive)
@@ -468,6 +520,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 const f32x4_t bv = *(const WS_GLOBAL f32x4_t*)(bbase + bl + 32 * gq);
                 biasv[gq * 4 + 0] = bv[0]; biasv[gq * 4 + 1] = bv[1]; biasv[gq * 4 + 2] = bv[2]; biasv[gq * 4 + 3] = bv[3];
             }
+            if constexpr (X3) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) biasv[i] *= p.wscale;
+            }
         }
         for (int cc = 0; cc < ncc; ++cc) {
             const int g = k * ncc + cc;
@@ -480,17 +536,17 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 asm volatile("" : "+v"(ho));
                 bp[r] = cur + ho;
             }
-            const unsigned char* ap = (resident_w ? smem + cc * taps * 1024 : cur + 2 * plane) + (kh * 32 + l31) * 16;
+            const unsigned char* ap = (resident_w ? smem + cc * taps * 1024 : cur + 2 * plane) + (X3 ? l31 : kh * 32 + l31) * 16;
             WS_STAMP(4);
             if constexpr (YR) {
                 if (cc == 0)
-                    consume_chunk_y<R, K0, K2, true>(bp[0], ap, p.h1, p.h2, acc, biasv);
+                    consume_chunk_y<R, K0, K2, true, X3>(bp[0], ap, p.h1, p.h2, acc, biasv);
                 else
-                    consume_chunk_y<R, K0, K2, false>(bp[0], ap, p.h1, p.h2, acc, biasv);
+                    consume_chunk_y<R, K0, K2, false, X3>(bp[0], ap, p.h1, p.h2, acc, biasv);
             } else if (cc == 0)
-                consume_chunk<R, K0, K1, K2, true>(bp, ap, p.h1, p.h2, acc, biasv);
+                consume_chunk<R, K0, K1, K2, true, X3>(bp, ap, p.h1, p.h2, acc, biasv);
             else
-                consume_chunk<R, K0, K1, K2, false>(bp, ap, p.h1, p.h2, acc, biasv);
+                consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.h1, p.h2, acc, biasv);
             WS_STAMP(5);
 #if !WS_DEFER_EPILOGUE
             if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc);
@@ -541,32 +597,32 @@ bool conv_ws_supported(const int k[3], int HV) {
     return (k333 || k133) && 2 * HV <= WS_PROD * WS_MAXV;
 }
 
-template <int R, int K0, int K1, int K2, bool YR>
+template <int R, int K0, int K1, int K2, bool YR, bool X3>
 static void launch_ws_y(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
-    static bool once = (hipFuncSetAttribute((const void*)k_conv_ws<R, K0, K1, K2, YR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    static bool once = (hipFuncSetAttribute((const void*)k_conv_ws<R, K0, K1, K2, YR, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR>), dim3(grid), dim3(WS_THREADS), t.lds_bytes, ctx->stream, a, total, resident,
+    hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR, X3>), dim3(grid), dim3(WS_THREADS), t.lds_bytes, ctx->stream, a, total, resident,
                        getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0);
 }
 
-template <int R, int K0, int K1, int K2>
+template <int R, int K0, int K1, int K2, bool X3>
 static void launch_ws_t(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
     // row reuse: the R M-tiles of a wave are consecutive output rows (m = cw * R + r, my = m & (b1 - 1) when b2 == 1),
     // one voxel high, stride 1 along y
     static const bool off = getenv("BOA_WS_NO_YREUSE") != nullptr;
     const bool yr = R > 1 && K1 == 3 && a.s1 == 1 && a.w1 == 1 && a.b2 == 1 && a.b1 % R == 0 && !off;
     if (R > 1 && yr)
-        launch_ws_y<R, K0, K1, K2, (R > 1)>(ctx, a, t, total, grid, resident);
+        launch_ws_y<R, K0, K1, K2, (R > 1), X3>(ctx, a, t, total, grid, resident);
     else
-        launch_ws_y<R, K0, K1, K2, false>(ctx, a, t, total, grid, resident);
+        launch_ws_y<R, K0, K1, K2, false, X3>(ctx, a, t, total, grid, resident);
 }
 
-template <int R>
+template <int R, bool X3>
 static int launch_ws_r(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
     if (a.k0 == 3 && a.k1 == 3 && a.k2 == 3)
-        launch_ws_t<R, 3, 3, 3>(ctx, a, t, total, grid, resident);
+        launch_ws_t<R, 3, 3, 3, X3>(ctx, a, t, total, grid, resident);
     else if (a.k0 == 1 && a.k1 == 3 && a.k2 == 3)
-        launch_ws_t<R, 1, 3, 3>(ctx, a, t, total, grid, resident);
+        launch_ws_t<R, 1, 3, 3, X3>(ctx, a, t, total, grid, resident);
     else {
         boa_set_error("conv_ws: kernel %dx%dx%d not instantiated", a.k0, a.k1, a.k2);
         return BOA_EINVAL;
@@ -622,7 +678,7 @@ const int* ws_run_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, i
     return (const int*)dev;
 }
 
-int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes) {
+int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes, bool x3) {
     const ConvArgs& a0 = a_in;
     // tiles of one sample; its virtual workgroups (batch-invariant statistics, see tile_walk); physical grid
     const int total = t.tiles[0] * t.tiles[1] * t.tiles[2] * (a0.Cout / 32);
@@ -654,12 +710,15 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
         hipMemsetAsync(a.trace, 0, WS_TRACE_SLOTS * 8, ctx->stream);
     }
     KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);
-    ctx->counters[BOA_CNT_CONV_WS]++;
+    ctx->counters[x3 ? BOA_CNT_CONV_X3 : BOA_CNT_CONV_WS]++;
     int rc;
-    switch (t.R) {
-        case 4: rc = launch_ws_r<4>(ctx, a, t, total, grid, resident); break;
-        case 2: rc = launch_ws_r<2>(ctx, a, t, total, grid, resident); break;
-        case 1: rc = launch_ws_r<1>(ctx, a, t, total, grid, resident); break;
+    switch (t.R + (x3 ? 8 : 0)) {
+        case 4: rc = launch_ws_r<4, false>(ctx, a, t, total, grid, resident); break;
+        case 2: rc = launch_ws_r<2, false>(ctx, a, t, total, grid, resident); break;
+        case 1: rc = launch_ws_r<1, false>(ctx, a, t, total, grid, resident); break;
+        case 12: rc = launch_ws_r<4, true>(ctx, a, t, total, grid, resident); break;
+        case 10: rc = launch_ws_r<2, true>(ctx, a, t, total, grid, resident); break;
+        case 9: rc = launch_ws_r<1, true>(ctx, a, t, total, grid, resident); break;
         default:
             boa_set_error("conv_ws: unsupported R=%d", t.R);
             rc = BOA_EINVAL;

@@ -414,3 +414,65 @@ __device__ __forceinline__ void prod_commit(const ConvArgs& p, ChunkRegs& rg, un
     }
 }
 
+// ---- split-precision ("x3") producers ------------------------------------------------------------------
+// The chunk is 8 fp32 channels of the raw activation ([N][C/8][voxel][8] floats: the same 32 bytes per voxel and plane as a
+// 16-channel fp16 chunk, so prod_issue / prod_setup / the run tables are shared byte for byte: lane q holds channels 4 (q & 1) ..
+// + 3 of its halo voxels and their (scale, shift) as 8 fp32 words).  Commit: y = lrelu(fma(x, scale, shift)) in fp32 -- the
+// reference's CPU arithmetic -- then y = hi + lo with hi = half(y), lo = half(y - hi) (y - hi is exact in fp32; |lo| <= ulp(hi) / 2,
+// so hi + lo carries 22 significant bits + sign of lo).  hi goes to LDS plane 0, lo to plane 1 (the consumers' k-half 0 / 1).
+__device__ __forceinline__ void x3_split4(const float (&y)[4], uint2& hi, uint2& lo) {
+    union {
+        h2_t v;
+        unsigned u;
+    } h01, h23;
+    h01.v = __builtin_convertvector(f2_t{y[0], y[1]}, h2_t);
+    h23.v = __builtin_convertvector(f2_t{y[2], y[3]}, h2_t);
+    const float r0 = y[0] - (float)h01.v[0], r1 = y[1] - (float)h01.v[1], r2 = y[2] - (float)h23.v[0], r3 = y[3] - (float)h23.v[1];
+    hi = make_uint2(h01.u, h23.u);
+    lo = make_uint2(cvt_pk_h2(r0, r1), cvt_pk_h2(r2, r3));
+}
+
+template <bool SS, bool EDGE>
+__device__ __forceinline__ void commit_items_x3(const ChunkRegs& rg, unsigned char* d0, int plane, int nv, float slope) {
+    if (EDGE)
+        asm volatile("; commit x3: edge tile");
+    else
+        asm volatile("; commit x3: interior tile");
+#pragma unroll
+    for (int j = 0; j < WS_MAXV; ++j) {
+        if (j < nv) {
+            float y[4] = {__uint_as_float(rg.d[j].x), __uint_as_float(rg.d[j].y), __uint_as_float(rg.d[j].z), __uint_as_float(rg.d[j].w)};
+            if (SS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float f = __builtin_fmaf(y[i], __uint_as_float(rg.ssw[2 * i]), __uint_as_float(rg.ssw[2 * i + 1]));
+                    y[i] = f > 0.f ? f : f * slope;
+                }
+            }
+            uint2 hi, lo;
+            x3_split4(y, hi, lo);
+            if (EDGE && !((rg.ok >> j) & 1u)) hi = lo = make_uint2(0, 0);
+            *(uint2*)(d0 + j * (WS_PROD / 2 * 16)) = hi;
+            *(uint2*)(d0 + plane + j * (WS_PROD / 2 * 16)) = lo;
+        }
+    }
+}
+
+__device__ __forceinline__ void prod_commit_x3(const ConvArgs& p, ChunkRegs& rg, unsigned char* dst_in, int q, int HV, int plane, int dbg) {
+    const int nv = (dbg & 32) ? 0 : (HV + WS_PROD / 2 - 1) / (WS_PROD / 2);
+    if (rg.skip_halo) return;
+    unsigned char* d0 = dst_in + (q >> 1) * 16 + (q & 1) * 8;
+    const bool edge = __builtin_amdgcn_ballot_w64(rg.ok != rg.live) != 0;
+    if (rg.has_ss) {
+        if (edge)
+            commit_items_x3<true, true>(rg, d0, plane, nv, p.slope);
+        else
+            commit_items_x3<true, false>(rg, d0, plane, nv, p.slope);
+    } else {
+        if (edge)
+            commit_items_x3<false, true>(rg, d0, plane, nv, p.slope);
+        else
+            commit_items_x3<false, false>(rg, d0, plane, nv, p.slope);
+    }
+}
+

@@ -22,7 +22,8 @@ struct ConvLayer {
     __half* wpk = nullptr;   // MFMA layers
     float* wfirst = nullptr; // first layer [Cin][taps][Cout]
     float* w32 = nullptr;    // fp32 mode: [taps][Cin][Cout]
-    float* out32 = nullptr;  // fp32 mode: raw conv output [N][vox][Cout]
+    float* out32 = nullptr;  // fp32 mode: raw conv output [N][vox][Cout]; split-precision mode: octet planes [N][Cout/8][vox][8]
+    float wscale = 1.f;      // split-precision mode: power-of-two scale of the packed weights (per weight set)
     float *bias = nullptr, *gamma = nullptr, *beta = nullptr;
     __half* out = nullptr;
     float* partials = nullptr;
@@ -40,7 +41,8 @@ struct UpLayer {
     float* w32 = nullptr;    // fp32 mode: [taps][Cin][Cout]
     float* bias = nullptr;
     __half* out = nullptr;
-    float* out32 = nullptr;  // fp32 mode
+    float* out32 = nullptr;  // fp32 / split-precision mode
+    float wscale = 1.f;      // split-precision mode
 };
 
 }  // namespace
@@ -59,7 +61,8 @@ struct boa_net {
     boa_ctx* ctx = nullptr;
     boa_net_desc d{};
     int maxN = 1;
-    int precision = 0;         // 0: fp16 storage + f16 MFMA (production); 1: fp32 "exact" mode (net_f32.hip)
+    int precision = 0;         // 0: fp16 storage + f16 MFMA (production); 1: fp32 reference mode (net_f32.hip); 2: split-precision
+                               // mode (fp32 storage, hi / lo fp16 operands on the matrix cores: k_conv_ws<X3>, net_x3.hip)
     int mirror_mask = 0;       // test-time mirroring axes (bit a = array axis a), predict_from_raw_data.py:541-557
     float* mirror_tmp = nullptr;  // [maxN][C][P] fp32 logits of one mirror variant
     float* mirror_sum = nullptr;  // [maxN][C][P] running sum / mean
@@ -78,6 +81,7 @@ struct boa_net {
         size_t n;
         unsigned long long sample_hash;  // FNV-1a over ~4096 evenly spaced floats: guards against a recycled host address
         unsigned char* arena;
+        std::vector<float> scales;       // split-precision mode: weight scale of every conv / transposed conv, blob order
     };
     std::vector<WeightSet> wsets;
 };
@@ -153,6 +157,27 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
         BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * sizeof(float), (void**)&L.ss));
         return BOA_OK;
     }
+    if (net->precision == 2) {
+        size_t vox2 = (size_t)dout[0] * dout[1] * dout[2];
+        if (first) {
+            BOA_REQUIRE(s[0] == 1 && s[1] == 1 && s[2] == 1, "first conv must have stride 1");
+            BOA_REQUIRE(cout % 32 == 0 && cin0 >= 1 && cin0 <= 4, "first conv %d -> %d unsupported", cin0, cout);
+            L.nblk = conv_first_nblk(dout, net->ctx->cu_count);
+        } else {
+            BOA_REQUIRE((cin0 % 8) == 0 && (cin1 % 8) == 0 && (cout % 32) == 0,
+                        "conv %d+%d -> %d: channel counts must be multiples of 8 (in) / 32 (out)", cin0, cin1, cout);
+            ConvGeom gref = L.g;
+            gref.N = tile_ref_batch();
+            BOA_REQUIRE(choose_conv_tile(gref, net->ctx->cu_count, &L.t, true), "no split-precision tile configuration fits conv %dx%dx%d k=%dx%dx%d",
+                        din[0], din[1], din[2], k[0], k[1], k[2]);
+            L.nblk = conv_nblk(L.t, net->ctx->cu_count, cout);
+        }
+        BOA_TRY(net_alloc(net, (size_t)N * vox2 * cout * sizeof(float), (void**)&L.out32));
+        BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * L.nblk * sizeof(float), (void**)&L.partials));
+        BOA_HIP_TRY(hipMemsetAsync(L.partials, 0, (size_t)N * cout * 2 * L.nblk * sizeof(float), net->ctx->stream));
+        BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * sizeof(float), (void**)&L.ss));
+        return BOA_OK;
+    }
     if (first) {
         BOA_REQUIRE(s[0] == 1 && s[1] == 1 && s[2] == 1, "first conv must have stride 1");
         L.nblk = conv_first_nblk(dout, net->ctx->cu_count);
@@ -188,6 +213,8 @@ static void for_each_weight_piece(boa_net* net, F&& f) {
         const int cin = L.Cin0 + L.Cin1, cout = L.g.Cout;
         if (net->precision == 1)
             f(9, &L, nullptr, L.w_elems * sizeof(float));
+        else if (net->precision == 2 && !L.first)
+            f(11, &L, nullptr, conv_wpk_halves_x3(cin, cout, L.g.k) * sizeof(__half));
         else
         f(L.first ? 0 : 1, &L, nullptr, L.first ? L.w_elems * sizeof(float) : conv_wpk_halves(cin, cout, L.g.k) * sizeof(__half));
         f(2, &L, nullptr, cout * sizeof(float));  // bias
@@ -200,6 +227,8 @@ static void for_each_weight_piece(boa_net* net, F&& f) {
         UpLayer& U = net->up[k];
         if (net->precision == 1)
             f(10, nullptr, &U, (size_t)U.Cin * U.Cout * U.s[0] * U.s[1] * U.s[2] * sizeof(float));
+        else if (net->precision == 2)
+            f(12, nullptr, &U, convt_wpk_halves_x3(U.Cin, U.Cout, U.s) * sizeof(__half));
         else
             f(5, nullptr, &U, convt_wpk_halves(U.Cin, U.Cout, U.s) * sizeof(__half));
         f(6, nullptr, &U, U.Cout * sizeof(float));
@@ -209,11 +238,13 @@ static void for_each_weight_piece(boa_net* net, F&& f) {
     f(8, nullptr, nullptr, net->d.num_classes * sizeof(float));
 }
 
-static void point_layers_at(boa_net* net, unsigned char* arena) {
-    size_t off = 0;
+static void point_layers_at(boa_net* net, unsigned char* arena, const std::vector<float>& scales) {
+    size_t off = 0, si = 0;
     for_each_weight_piece(net, [&](int kind, ConvLayer* L, UpLayer* U, size_t bytes) {
         void* p = arena + off;
         switch (kind) {
+            case 11: L->wpk = (__half*)p; L->wscale = scales[si++]; break;
+            case 12: U->wpk = (__half*)p; U->wscale = scales[si++]; break;
             case 0: L->wfirst = (float*)p; break;
             case 1: L->wpk = (__half*)p; break;
             case 2: L->bias = (float*)p; break;
@@ -247,13 +278,14 @@ extern "C" int boa_net_load_weights(boa_net* net, const float* w, size_t n_float
     }
     for (auto& ws : net->wsets)
         if (ws.key == w && ws.n == n_floats && ws.sample_hash == hsh) {
-            point_layers_at(net, ws.arena);  // (host-side pointers of later launches only: queued work keeps its own)
+            point_layers_at(net, ws.arena, ws.scales);  // (host-side pointers of later launches only: queued work keeps its own)
             return BOA_OK;
         }
     BOA_HIP_TRY(hipStreamSynchronize(c->stream));
     size_t total = 0;
     for_each_weight_piece(net, [&](int, ConvLayer*, UpLayer*, size_t bytes) { total += align256(bytes); });
     std::vector<unsigned char> stage(total, 0);
+    std::vector<float> scales;
     const float* p = w;
     size_t off = 0;
     for_each_weight_piece(net, [&](int kind, ConvLayer* L, UpLayer* U, size_t bytes) {
@@ -276,6 +308,21 @@ extern "C" int boa_net_load_weights(boa_net* net, const float* w, size_t n_float
                 pack_convt_weights(p, U->Cin, U->Cout, U->s, (__half*)dst);
                 p += (size_t)U->Cin * U->Cout * U->s[0] * U->s[1] * U->s[2];
                 break;
+            case 11: {  // split-precision conv: hi / lo fp16 parts of w * 2^e
+                const float sc = x3_weight_scale(p, L->w_elems);
+                scales.push_back(sc);
+                pack_conv_weights_x3(p, L->Cin0 + L->Cin1, L->g.Cout, L->g.k, sc, (__half*)dst);
+                p += L->w_elems;
+                break;
+            }
+            case 12: {
+                const size_t ne = (size_t)U->Cin * U->Cout * U->s[0] * U->s[1] * U->s[2];
+                const float sc = x3_weight_scale(p, ne);
+                scales.push_back(sc);
+                pack_convt_weights_x3(p, U->Cin, U->Cout, U->s, sc, (__half*)dst);
+                p += ne;
+                break;
+            }
             case 9: {  // fp32 mode conv: [cout][cin][taps] -> [tap][cin][cout]
                 const int cin = L->Cin0 + L->Cin1, cout = L->g.Cout, taps = L->g.k[0] * L->g.k[1] * L->g.k[2];
                 float* wf = (float*)dst;
@@ -313,8 +360,8 @@ extern "C" int boa_net_load_weights(boa_net* net, const float* w, size_t n_float
         hipFree(arena);
         BOA_HIP_TRY(e);
     }
-    net->wsets.push_back({w, n_floats, hsh, arena});
-    point_layers_at(net, arena);
+    net->wsets.push_back({w, n_floats, hsh, arena, scales});
+    point_layers_at(net, arena, scales);
     return BOA_OK;
 }
 
@@ -330,8 +377,9 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
                               int max_batch, int precision, boa_net** out) {
     BOA_REQUIRE(ctx && desc && out, "boa_net_create: NULL argument");
     BOA_REQUIRE(desc_ok(desc), "boa_net_create: invalid network geometry");
-    BOA_REQUIRE(precision == 0 || precision == 1,
-                "boa_net_create: precision %d not supported (0 = f16 MFMA / fp32 accumulate, 1 = fp32 exact mode)", precision);
+    BOA_REQUIRE(precision >= 0 && precision <= 2,
+                "boa_net_create: precision %d not supported (0 = f16 MFMA / fp32 accumulate, 1 = fp32 reference mode, 2 = split-precision fp32)",
+                precision);
     BOA_REQUIRE(max_batch >= 1 && max_batch <= 64, "boa_net_create: max_batch %d out of range", max_batch);
     BOA_HIP_TRY(hipSetDevice(ctx->device));
     boa_net* net = new boa_net();
@@ -384,12 +432,12 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
                               dup[a], net->dims[sb - 1][a]);
                 return fail(BOA_EINVAL);
             }
-        if ((precision == 0 && U.Cin % 16) || U.Cout % 32) {
+        if ((precision == 0 && U.Cin % 16) || (precision == 2 && U.Cin % 8) || U.Cout % 32) {
             boa_set_error("transposed conv %d -> %d: unsupported channel counts", U.Cin, U.Cout);
             return fail(BOA_EINVAL);
         }
         size_t vox = (size_t)dup[0] * dup[1] * dup[2];
-        if (precision == 1) {
+        if (precision >= 1) {
             if ((rc = net_alloc(net, (size_t)max_batch * vox * U.Cout * sizeof(float), (void**)&U.out32))) return fail(rc);
         } else if ((rc = net_alloc(net, (size_t)max_batch * vox * U.Cout * sizeof(__half), (void**)&U.out)))
             return fail(rc);
@@ -470,6 +518,86 @@ static int net_forward_stack_f32(boa_net* net, const float* volume, const int V[
     return BOA_OK;
 }
 
+// split-precision mode: first conv on the fp32 VALU (k_conv_first<F32OUT>), 3x3x3 convs on k_conv_ws<X3>, transposed convs on
+// k_convt_x3; InstanceNorm statistics from the conv epilogues (fp32 partial sums, fp64 finalize).  Leaves the last decoder
+// activation (octet planes) in dec.back().back().out32.
+static int net_forward_stack_x3(boa_net* net, const float* volume, const int V[3], const int vol_off[3], const int* host_origins,
+                                int N, int flip_mask) {
+    boa_ctx* c = net->ctx;
+    const boa_net_desc& d = net->d;
+    BOA_REQUIRE(N >= 1 && N <= net->maxN, "forward: batch %d exceeds max_batch %d", N, net->maxN);
+    BOA_HIP_TRY(hipMemcpyAsync(net->dev_origins, host_origins, (size_t)N * 3 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->prof_break = true;
+    static const bool layer_prof = getenv("BOA_LAYER_PROF") != nullptr;
+    auto prof_begin = [&]() {
+        if (layer_prof) hipEventRecord(c->t0[7], c->stream);
+    };
+    auto prof_end = [&](const char* what, const int* din, int cin, int cout, const int* k, const int* s, double flops, const ConvTile* t) {
+        if (!layer_prof) return;
+        hipEventRecord(c->t1[7], c->stream);
+        hipEventSynchronize(c->t1[7]);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, c->t0[7], c->t1[7]);
+        fprintf(stderr, "[layer] x3 %-6s N=%d in=%dx%dx%d cin=%d cout=%d k=%d%d%d s=%d%d%d ", what, N, din[0], din[1], din[2], cin, cout, k[0], k[1],
+                k[2], s[0], s[1], s[2]);
+        if (t)
+            fprintf(stderr, "R=%d w=%d,%d,%d b=%d,%d,%d tiles=%d lds=%zu ", t->R, t->w[0], t->w[1], t->w[2], t->b[0], t->b[1], t->b[2],
+                    t->tiles[0] * t->tiles[1] * t->tiles[2], t->lds_bytes);
+        fprintf(stderr, "%.1f us %.1f TFLOP/s\n", ms * 1e3, flops / (ms * 1e-3) / 1e12);
+    };
+    struct Src {
+        const float* data = nullptr;
+        const float* ss = nullptr;
+        int C = 0;
+    };
+    auto run_conv = [&](ConvLayer& L, const Src& a, const Src& b) -> int {
+        ConvGeom g = L.g;
+        g.N = N;
+        prof_begin();
+        if (L.first) {
+            int nblk = 0;
+            BOA_TRY(launch_conv_first(c, volume, V, vol_off, net->dev_origins, N, d.in_channels, d.patch, L.g.k, L.g.Cout, L.wfirst, L.bias,
+                                      net->first_padded, nullptr, L.partials, &nblk, flip_mask, L.out32));
+        } else {
+            BOA_TRY(launch_conv_x3(c, a.data, a.ss, a.C, b.data, b.ss, b.C, g, L.t, L.wpk, L.wscale, L.bias, d.lrelu_slope, L.out32, L.partials));
+        }
+        {
+            const int din[3] = {g.Di, g.Hi, g.Wi};
+            const double fl = 2.0 * N * (double)g.Do * g.Ho * g.Wo * g.k[0] * g.k[1] * g.k[2] * (L.Cin0 + L.Cin1) * g.Cout;
+            prof_end(L.first ? "first" : "conv", din, L.Cin0 + L.Cin1, g.Cout, g.k, g.s, fl, L.first ? nullptr : &L.t);
+        }
+        return launch_norm_finalize(c, L.partials, L.nblk, N, g.Cout, (double)g.Do * g.Ho * g.Wo, L.gamma, L.beta, d.norm_eps, L.ss, nullptr, 1);
+    };
+    Src cur, none;
+    for (int s = 0; s < d.n_stages; ++s)
+        for (size_t i = 0; i < net->enc[s].size(); ++i) {
+            ConvLayer& L = net->enc[s][i];
+            BOA_TRY(run_conv(L, cur, none));
+            cur.data = L.out32; cur.ss = L.ss; cur.C = L.g.Cout;
+        }
+    for (int k = 0; k < d.n_stages - 1; ++k) {
+        int sb = d.n_stages - 1 - k;
+        UpLayer& U = net->up[k];
+        prof_begin();
+        BOA_TRY(launch_convt_x3(c, cur.data, cur.ss, U.Cin, N, U.din, U.s, U.Cout, U.wpk, U.wscale, U.bias, d.lrelu_slope, U.out32));
+        prof_end("convT", U.din, U.Cin, U.Cout, U.s, U.s, 2.0 * N * (double)U.din[0] * U.din[1] * U.din[2] * U.s[0] * U.s[1] * U.s[2] * U.Cin * U.Cout,
+                 nullptr);
+        ConvLayer& SK = net->enc[sb - 1].back();
+        Src upsrc, skip;
+        upsrc.data = U.out32; upsrc.C = U.Cout;
+        skip.data = SK.out32; skip.ss = SK.ss; skip.C = SK.g.Cout;
+        for (size_t i = 0; i < net->dec[k].size(); ++i) {
+            ConvLayer& L = net->dec[k][i];
+            if (i == 0)
+                BOA_TRY(run_conv(L, upsrc, skip));
+            else
+                BOA_TRY(run_conv(L, cur, none));
+            cur.data = L.out32; cur.ss = L.ss; cur.C = L.g.Cout;
+        }
+    }
+    return BOA_OK;
+}
+
 // head of tile i of the current batch (either precision)
 static int net_head(boa_net* net, int i, const int P[3], int plane_skip, float* logits_out, const uint16_t* gauss, uint16_t* acc,
                     uint16_t* nacc, const int PV[3], const int start[3]) {
@@ -481,6 +609,10 @@ static int net_head(boa_net* net, int i, const int P[3], int plane_skip, float* 
         return launch_head_f32(net->ctx, last.out32 + (size_t)i * pv * d.features[0] + (size_t)plane_skip * d.patch[1] * d.patch[2] * d.features[0],
                                ss, d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc,
                                nacc, PV, start);
+    if (net->precision == 2)   // split-precision mode: fp32 octet planes; skipped axis-0 planes are an offset inside every plane
+        return launch_head_f32(net->ctx, last.out32 + (size_t)i * pv * d.features[0] + (size_t)plane_skip * d.patch[1] * d.patch[2] * 8, ss,
+                               d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc, PV,
+                               start, pv);
     // chunk-planar fp16: skipping leading axis-0 planes is an offset inside every 16-channel plane; plane stride = whole tile
     return launch_head(net->ctx, last.out + (size_t)i * pv * d.features[0] + (size_t)plane_skip * d.patch[1] * d.patch[2] * 16, ss,
                        d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc, PV,
@@ -491,6 +623,7 @@ static int net_head(boa_net* net, int i, const int P[3], int plane_skip, float* 
 static int net_forward_stack(boa_net* net, const float* volume, const int V[3], const int vol_off[3],
                              const int* host_origins, int N, int flip_mask = 0) {
     if (net->precision == 1) return net_forward_stack_f32(net, volume, V, vol_off, host_origins, N, flip_mask);
+    if (net->precision == 2) return net_forward_stack_x3(net, volume, V, vol_off, host_origins, N, flip_mask);
     boa_ctx* c = net->ctx;
     const boa_net_desc& d = net->d;
     BOA_REQUIRE(N >= 1 && N <= net->maxN, "forward: batch %d exceeds max_batch %d", N, net->maxN);
@@ -836,8 +969,9 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
     const int F = d.features[0];
     const size_t plane = (size_t)d.patch[1] * d.patch[2];
     const size_t pv = (size_t)d.patch[0] * plane;
-    const bool f32 = net->precision == 1;   // exact mode: channels-last fp32 records, the first dp planes are a contiguous prefix
-    const size_t esz = f32 ? 4 : 2;
+    const bool f32 = net->precision == 1;   // fp32 reference mode: channels-last fp32 records, the first dp planes are a contiguous prefix
+    const bool x3 = net->precision == 2;    // split-precision mode: fp32 octet planes (F / 8 planes of 32 bytes per voxel)
+    const size_t esz = (f32 || x3) ? 4 : 2;
     boa_stash* st = new boa_stash;
     st->ctx = net->ctx;
     size_t bytes = 0;
@@ -869,7 +1003,7 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
         ConvLayer& last = net->dec.back().back();
         for (int i = 0; i < nb && rc == BOA_OK; ++i) {
             const int* stt = host_origins + (size_t)(t0 + i) * 3;
-            const __half* act = f32 ? nullptr : last.out + (size_t)i * pv * F;
+            const __half* act = (f32 || x3) ? nullptr : last.out + (size_t)i * pv * F;
             const float* ss = last.ss + (size_t)i * F * 2;
             int dp = host_defer_planes[t0 + i];
             if (dp > 0) {
@@ -880,7 +1014,10 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
                 if (f32)
                     ok_copy = hipMemcpyAsync(st->arena + it.act_off, last.out32 + (size_t)i * pv * F, (size_t)dp * plane * F * 4,
                                              hipMemcpyDeviceToDevice, net->ctx->stream) == hipSuccess;
-                for (int k = 0; !f32 && k < F / 16 && ok_copy; ++k)
+                for (int k = 0; x3 && k < F / 8 && ok_copy; ++k)
+                    ok_copy = hipMemcpyAsync(st->arena + it.act_off + (size_t)k * dp * plane * 32, last.out32 + (size_t)i * pv * F + (size_t)k * pv * 8,
+                                             (size_t)dp * plane * 32, hipMemcpyDeviceToDevice, net->ctx->stream) == hipSuccess;
+                for (int k = 0; !f32 && !x3 && k < F / 16 && ok_copy; ++k)
                     ok_copy = hipMemcpyAsync(st->arena + it.act_off + (size_t)k * dp * plane * 32, act + (size_t)k * pv * 16,
                                              (size_t)dp * plane * 32, hipMemcpyDeviceToDevice, net->ctx->stream) == hipSuccess;
                 if (!ok_copy ||
@@ -917,6 +1054,10 @@ extern "C" int boa_net_apply_deferred(boa_net* net, const boa_stash* st, const u
             BOA_TRY(launch_head_f32(net->ctx, (const float*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
                                     d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
                                     dev_acc, dev_n, PV, it.start));
+        else if (net->precision == 2)
+            BOA_TRY(launch_head_f32(net->ctx, (const float*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
+                                    d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
+                                    dev_acc, dev_n, PV, it.start, (size_t)it.planes * d.patch[1] * d.patch[2]));
         else
             BOA_TRY(launch_head(net->ctx, (const __half*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
                                 d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
@@ -1013,6 +1154,8 @@ extern "C" int boa_net_debug_activation(boa_net* net, int kind, int stage, int c
     const size_t vox = (size_t)dm[0] * dm[1] * dm[2];
     if (net->precision == 1)
         return launch_ndhwc32_to_nchw_f32(net->ctx, a32 + (size_t)tile * vox * Cc, ss, net->d.lrelu_slope, Cc, vox, dev_out);
+    if (net->precision == 2)
+        return launch_octet_to_nchw_f32(net->ctx, a32 + (size_t)tile * vox * Cc, ss, net->d.lrelu_slope, Cc, vox, dev_out);
     return launch_ndhwc_to_nchw_f32(net->ctx, a16 + (size_t)tile * vox * Cc, ss, net->d.lrelu_slope, 1, Cc, vox, dev_out);
 }
 

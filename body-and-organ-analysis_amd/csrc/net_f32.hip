@@ -211,6 +211,7 @@ struct F32HeadArgs {
     unsigned short* acc;
     unsigned short* nacc;
     int V0, V1, V2, s0, s1, s2;
+    size_t octet_stride;  // 0: channels-last records [voxel][F0]; else octet planes [F0/8][octet_stride voxels][8] (precision 2)
 };
 
 // 1x1x1 head in fp32 (fma chain over the features in index order) + the reference's accumulate step
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256) void k_head_f32(F32HeadArgs p) {
     const float* a = p.act + i * p.F0;
     float y[64];
     for (int k = 0; k < p.F0; ++k) {
-        float f = __builtin_fmaf(a[k], p.ss[2 * k], p.ss[2 * k + 1]);
+        const float x = p.octet_stride ? p.act[((size_t)(k >> 3) * p.octet_stride + i) * 8 + (k & 7)] : a[k];
+        float f = __builtin_fmaf(x, p.ss[2 * k], p.ss[2 * k + 1]);
         y[k] = f > 0.f ? f : f * p.slope;
     }
     size_t vi = 0;
@@ -353,11 +355,12 @@ int launch_gather_tiles_f32(boa_ctx* ctx, const float* volume, const int V[3], c
 
 int launch_head_f32(boa_ctx* ctx, const float* act, const float* ss, int F0, const int P[3], int C, const float* w,
                     const float* bias, float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc, uint16_t* nacc,
-                    const int PV[3], const int start[3]) {
+                    const int PV[3], const int start[3], size_t octet_stride) {
     BOA_REQUIRE(F0 <= 64, "head_f32: features[0]=%d unsupported (<= 64)", F0);
     F32HeadArgs a;
     a.act = act; a.ss = ss; a.F0 = F0; a.C = C; a.pv = (size_t)P[0] * P[1] * P[2]; a.P1 = P[1]; a.P2 = P[2];
     a.w = w; a.bias = bias; a.slope = slope; a.logits = logits_out; a.gauss = gauss; a.acc = acc; a.nacc = nacc;
+    a.octet_stride = octet_stride;
     if (!logits_out) {
         for (int d = 0; d < 3; ++d)
             BOA_REQUIRE(start[d] >= 0 && start[d] + P[d] <= PV[d], "head_f32: tile [%d,%d) outside accumulator dim %d (%d)", start[d],
@@ -368,7 +371,7 @@ int launch_head_f32(boa_ctx* ctx, const float* act, const float* ss, int F0, con
     }
     KernelTimer tm(ctx, BOA_K_HEAD_ACCUM, 2.0 * a.pv * F0 * C, (double)a.pv * (4.0 * F0 + (logits_out ? 4.0 * C : (4.0 * (C + 1) + 2.0))));
     hipLaunchKernelGGL(k_head_f32, dim3((unsigned)((a.pv + 255) / 256)), dim3(256), 0, ctx->stream, a);
-    ctx->counters[BOA_CNT_F32]++;
+    ctx->counters[octet_stride ? BOA_CNT_X3 : BOA_CNT_F32]++;
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

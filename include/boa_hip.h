@@ -103,8 +103,10 @@ int boa_prof_get(boa_ctx* ctx, int kclass, double* total_ms, long long* launches
 #define BOA_CNT_CONV_SIMPLE 3     /* k_conv_mfma (fallback for kernel shapes k_conv_ws lacks)          */
 #define BOA_CNT_FIRST_MFMA 4      /* k_conv_first_mfma                                                 */
 #define BOA_CNT_FIRST_VALU 5      /* k_conv_first<K> fallback                                          */
-#define BOA_CNT_F32 6             /* any kernel of the fp32 "exact" network mode (precision = 1)       */
-#define BOA_CNT_COUNT 8
+#define BOA_CNT_F32 6             /* any kernel of the fp32 reference network mode (precision = 1)     */
+#define BOA_CNT_CONV_X3 7         /* k_conv_ws<..., X3>: split-precision conv (precision = 2)          */
+#define BOA_CNT_X3 8              /* the other kernels of the split-precision mode (first conv, transposed conv, head) */
+#define BOA_CNT_COUNT 10
 long long boa_debug_counter(boa_ctx* ctx, int which, int reset);
 
 /* ------------------------------------------------------------------ sliding-window arithmetic seams -- */

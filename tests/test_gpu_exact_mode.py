@@ -1,6 +1,8 @@
-"""fp32 "exact" network mode (boa_net_create precision = 1, HipPredictor(precision="fp32")): what the reference's CPU path
-computes (fp32 weights / activations / accumulation; autocast is CUDA-only, predict_from_raw_data.py:648), against the
-torch-CPU fp32 oracle.  SURVEY 8c: "end-to-end label mismatch fraction: target 0 in fp32-MFMA mode on fixtures".
+"""fp32 network modes: what the reference's CPU path computes (fp32 weights / activations / accumulation; autocast is CUDA-only,
+predict_from_raw_data.py:648), against the torch-CPU fp32 oracle.  HipPredictor(precision="fp32") = boa_net_create precision 2,
+the split-precision mode on the f16 matrix cores (k_conv_ws<X3>, csrc/net_x3.hip: the product's label-contract mode);
+precision="fp32_ref" = precision 1, plain fp32 MFMAs from global memory (csrc/net_f32.hip).  SURVEY 8c: "end-to-end label mismatch
+fraction: target 0 in fp32-MFMA mode on fixtures".
 
 Two fp32 implementations of a 20-layer conv stack cannot agree bit for bit (the summation order inside a convolution
 differs between oneDNN and the MFMA K-loop), so the stated tolerances are: logits within 2e-4 of the logit range (measured
@@ -44,19 +46,24 @@ def _small_net(patch=(32, 32, 32), features=(32, 64, 128), classes=5, seed=0, ke
     ((16, 48, 40), (32, 64, 128, 256), [[1, 3, 3], [3, 3, 3], [3, 3, 3], [3, 3, 3]],
      [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2]]),
 ])
-def test_fp32_tile_forward_vs_oracle(ctx, patch, features, kernels, strides):
+@pytest.mark.parametrize("prec", ["fp32", "fp32_ref"])
+def test_fp32_tile_forward_vs_oracle(ctx, patch, features, kernels, strides, prec):
     from boa_hip.predictor import HipPredictor
     from oracle.network import network_fn_from_module
     geom, blob, net = _small_net(patch, features, 5, 0, kernels, strides)
     rng = np.random.default_rng(5)
     vol = rng.standard_normal((1, patch[0] + 9, patch[1] + 5, patch[2] + 11)).astype(np.float32)
     origins = np.array([[0, 0, 0], [9, 5, 11], [-3, 2, 7]], dtype=np.int32)     # the last one overhangs: pad_nd_image zeros
-    p32 = HipPredictor(ctx, geom, max_batch=2, precision="fp32")
+    p32 = HipPredictor(ctx, geom, max_batch=2, precision=prec)
     p32.set_parameters([blob])
     ctx.counters(reset=True)
     got = p32.network_forward(vol, origins)
     cnt = ctx.counters()
-    assert cnt["f32"] > 0 and cnt["conv_ws"] == 0 and cnt["head_mfma"] == 0, cnt      # only exact-mode kernels ran
+    assert p32.precision == prec
+    if prec == "fp32":      # only split-precision kernels ran
+        assert cnt["conv_x3"] > 0 and cnt["x3"] > 0 and cnt["f32"] == 0 and cnt["conv_ws"] == 0 and cnt["head_mfma"] == 0, cnt
+    else:                   # only fp32 reference kernels ran
+        assert cnt["f32"] > 0 and cnt["conv_x3"] == 0 and cnt["conv_ws"] == 0 and cnt["head_mfma"] == 0, cnt
     p16 = HipPredictor(ctx, geom, max_batch=2, precision="fp16")
     p16.set_parameters([blob])
     got16 = p16.network_forward(vol, origins)

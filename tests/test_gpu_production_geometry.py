@@ -56,13 +56,15 @@ def _compare(ctx, cfg, blob, net, vol, origins, tag):
     for o in origins:
         refs.append(fn(vol[:, o[0]:o[0] + PATCH[0], o[1]:o[1] + PATCH[1], o[2]:o[2] + PATCH[2]][None])[0])
     out = {}
-    for prec, err_bar, flip_bar in (("fp32", 2e-5, 2e-5), ("fp16", 5e-3, 8e-3)):
+    for prec, err_bar, flip_bar in (("fp32", 2e-5, 2e-5), ("fp32_ref", 2e-5, 2e-5), ("fp16", 5e-3, 8e-3)):
         ctx.counters(reset=True)
         p = HipPredictor(ctx, cfg.geometry, max_batch=len(origins), precision=prec)
         p.set_parameters([blob])
         got = p.network_forward(vol, np.asarray(origins, dtype=np.int32))
         p.close()
         cnt = ctx.counters()
+        if prec == "fp32":   # the split-precision kernels (k_conv_ws<X3> etc.), not the fp32 reference mode
+            assert cnt["conv_x3"] > 0 and cnt["x3"] > 0 and cnt["f32"] == 0 and cnt["conv_ws"] == 0, cnt
         if prec == "fp16":   # the production kernels, not their fallbacks
             assert cnt["conv_ws"] > 0 and cnt["first_mfma"] > 0 and cnt["head_mfma"] > 0, cnt
             assert cnt["conv_simple"] == 0 and cnt["head_valu"] == 0 and cnt["first_valu"] == 0, cnt

@@ -14,7 +14,7 @@ from boa_hip.predictor import HipPredictor  # noqa: E402
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ctx = Context(0)
 tid, cfg, blob, _ = synthetic.total_part_models()[0]
-p = HipPredictor(ctx, cfg.geometry, tile_step_size=0.8, max_batch=batch)
+p = HipPredictor(ctx, cfg.geometry, tile_step_size=0.8, max_batch=batch, precision=os.environ.get("LAYER_PROF_PRECISION"))
 p.set_parameters([blob])
 vol = np.random.default_rng(0).standard_normal((1, 160, 160, 224)).astype(np.float32)
 if os.environ.get("LAYER_PROF_ZERO"):     # degenerate data: what the same instruction stream does when no operand bits toggle
