@@ -83,7 +83,7 @@ int boa_malloc_raw(boa_ctx* c, size_t bytes, void** dev_out) {
     BOA_HIP_TRY(hipSetDevice(c->device));
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-    if (e != hipSuccess && c->pool_bytes) {  // give the parked blocks back and try once more
+    if (e != hipSuccess && (c->pool_bytes || (c->stash && !c->stash_busy))) {  // give the parked blocks (and an idle tile stash) back and try once more
         (void)hipGetLastError();
         boa_trim(c);
         e = hipMalloc(&p, bytes ? bytes : 1);
@@ -170,11 +170,20 @@ extern "C" int boa_bind_thread(boa_ctx* c) {
 }
 
 static int trim_locked(boa_ctx* c) {
-    if (c->pool_free.empty()) return BOA_OK;
+    // the gather head's tile stash (up to tens of GB, grow-only between trims) goes back too: a trim means somebody needs room --
+    // the other lane's context, torch / RCCL buffers, a post-processing volume whose hipMalloc failed -- and the next volume's
+    // tile loop re-allocates it (or falls back to the scatter form if it no longer fits)
+    const bool drop_stash = c->stash && !c->stash_busy;
+    if (c->pool_free.empty() && !drop_stash) return BOA_OK;
     BOA_HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto& b : c->pool_free) hipFree(b.second);
     c->pool_free.clear();
     c->pool_bytes = 0;
+    if (drop_stash) {
+        hipFree(c->stash);
+        c->stash = nullptr;
+        c->stash_bytes = 0;
+    }
     return BOA_OK;
 }
 

@@ -77,6 +77,7 @@ struct boa_ctx {
     // current volume; grow-only, shared by the context's networks (they run one after the other on the stream)
     void* stash = nullptr;
     size_t stash_bytes = 0;
+    bool stash_busy = false;        // a tile loop is filling it (boa_trim leaves it alone)
 };
 int boa_malloc_raw(boa_ctx* c, size_t bytes, void** dev_out);
 

@@ -136,7 +136,7 @@ int launch_pack_head_ss(boa_ctx* ctx, const float* ss, unsigned* out, int n_tile
 int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, const float* w, const float* bias, const uint16_t* gauss,
                        int C, const int P[3], const int PV[3], const int ntile[3], const int* dev_tab, uint16_t* fold, int fold_mode,
                        int n_folds, const uint8_t* host_lut, int merge, uint8_t* labels, const int* crop_off, const int* crop_dims,
-                       int* inf_flag, float slope, int tiles_total);
+                       int* inf_flag, float slope, int tiles_total, bool x3 = false);
 // k_conv_ns (conv_ns.hip): consumer waves split the cout axis, weights straight from L2 (stride-2 / deep 3x3x3 layers)
 bool conv_ns_applicable(const ConvGeom& g);
 void conv_ns_tile(const ConvGeom& g, ConvTile* t);
@@ -161,6 +161,12 @@ int launch_head_f32(boa_ctx* ctx, const float* act, const float* ss, int F0, con
 // ---- split-precision mode (precision 2; net_x3.hip, k_conv_ws<..., X3>): fp32 octet planes [N][C/8][voxel][8] ---------
 int launch_convt_x3(boa_ctx* ctx, const float* src, const float* ss, int Cin, int N, const int din[3], const int s[3], int Cout,
                     const __half* wpk, float wscale, const float* bias, float slope, float* out);
+// head weights are O(0.1 .. 1): this power of two keeps the lo parts of their split out of the fp16 subnormal range (shared by the
+// scatter and the gather head: both must split the weights identically)
+#define X3_HEAD_WSCALE 1024.f
+int launch_head_x3(boa_ctx* ctx, const float* act, const float* ss, int F0, const int P[3], int C, const float* w, const float* bias,
+                   float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc, uint16_t* nacc, const int PV[3], const int start[3],
+                   size_t plane_stride);
 int launch_octet_to_nchw_f32(boa_ctx* ctx, const float* in, const float* ss, float slope, int C, size_t vox, float* out);
 
 int launch_ndhwc32_to_nchw_f32(boa_ctx* ctx, const float* in, const float* ss, float slope, int C, size_t vox, float* out);

@@ -40,6 +40,9 @@ struct GatherArgs {
     int* inf_flag;
     float slope;
     int ss_in_lds;                // the packed (scale, shift) table of all tiles fits the dynamic LDS allocation
+    // split-precision mode (X3): act = fp32 octet planes [tile][4 planes][pv][8 floats], ssp = fp32 (scale, shift) [tile][32][2],
+    // head weights split in the kernel as hi / lo parts of w * wscale (winv = 1 / wscale)
+    float wscale, winv;
     unsigned char lut[256];
 };
 
@@ -69,8 +72,12 @@ __global__ void k_pack_head_ss(const float* __restrict__ ss, unsigned* __restric
 
 // MULTI: several folds (fold buffer read-modify-write, general epilogue); the single-fold instantiation carries none of that code
 // (its 16 per-class plane pointers were the registers that spilled at six waves per SIMD)
-template <bool GAUSS, bool SSLDS, bool MULTI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8))) void k_gather_head(GatherArgs p) {
+// X3: the split-precision mode's head (precision 2): the stash holds fp32; a lane loads channels 8 c + 4 kh .. + 3 of its voxel for the
+// four octets c, normalises in fp32, splits into hi / lo fp16 parts, and two v_permlane32_swap per octet hand the k-half-0 lane
+// the hi parts of all 8 channels and the k-half-1 lane the lo parts: the B operand of [Wh | Wh] x [Xh ; Xl] + [Wl | Wl] x [Xh ; Xl]
+// (8 MFMAs per covering tile instead of 2).  Everything after the logits is the same code.
+template <bool GAUSS, bool SSLDS, bool MULTI, bool X3>
+__device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
     const int fold_mode = MULTI ? p.fold_mode : 0;
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
     const int* __restrict__ sx = p.tab;
@@ -80,10 +87,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
     const int* __restrict__ cvy = cvx + p.V0;
     const int* __restrict__ cvz = cvy + p.V1;
     f16x8 a0, a1;
+    f16x8 xah[X3 ? 4 : 1], xal[X3 ? 4 : 1];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         a0[i] = l31 < p.C ? (_Float16)p.w[l31 * 32 + 8 * kh + i] : (_Float16)0.f;
         a1[i] = l31 < p.C ? (_Float16)p.w[l31 * 32 + 16 + 8 * kh + i] : (_Float16)0.f;
+    }
+    if constexpr (X3) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float wv = l31 < p.C ? p.w[l31 * 32 + 8 * c + i] * p.wscale : 0.f;
+                const _Float16 h = (_Float16)wv;
+                xah[c][i] = h;
+                xal[c][i] = (_Float16)(wv - (float)h);
+            }
     }
     // this lane's 16 biases (D-fragment rows 8 gq + 4 kh + e) live in LDS, re-read per tile pair: the kernel waits on HBM round
     // trips, so VGPRs (waves in flight) matter more than four ds_read_b128 per pair
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
     extern __shared__ __attribute__((aligned(16))) unsigned s_ssp[];
     if (SSLDS) {
         const int n_tiles = p.n0 * p.n1 * p.n2;
-        for (int i = threadIdx.x; i < n_tiles * 8; i += 256) ((uint4*)s_ssp)[i] = ((const uint4*)p.ssp)[i];
+        for (int i = threadIdx.x; i < n_tiles * (X3 ? 16 : 8); i += 256) ((uint4*)s_ssp)[i] = ((const uint4*)p.ssp)[i];
         __syncthreads();
     }
     typedef __attribute__((address_space(1))) const unsigned char* gptr_t;
@@ -160,6 +179,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
                     const bool in = zvalid && z >= tz0 && z < tz0 + p.P2;
                     const unsigned tile = tile0 + (unsigned)iz;
                     const unsigned tvl = rowoff + (unsigned)(in ? z - tz0 : 0);
+                    f32x16 d;
+                    float g = 1.0f;
+                    if constexpr (X3) {
+                        gptr_t ab = (gptr_t)p.act + (size_t)tile * 4 * pv * 32;
+                        asm volatile("" : "+s"(ab));
+                        uint4 raw[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            unsigned oc = tvl * 32u + (unsigned)kh * 16u + (unsigned)c * ((unsigned)pv * 32u);
+                            asm volatile("" : "+v"(oc));
+                            raw[c] = gload4(ab, oc);
+                        }
+                        if (GAUSS) {
+                            gptr_t gb = (gptr_t)p.gauss;
+                            asm volatile("" : "+s"(gb));
+                            unsigned og = tvl * 2u;
+                            asm volatile("" : "+v"(og));
+                            g = us2f(*(const __attribute__((address_space(1))) unsigned short*)(gb + og));
+                        }
+                        d = zero;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            // (scale, shift) of channels 8 c + 4 kh .. + 3: 8 floats
+                            uint4 s01, s23;
+                            if (SSLDS) {
+                                const uint4* sw = (const uint4*)(s_ssp + tile * 64 + (8 * c + 4 * kh) * 2);
+                                s01 = sw[0]; s23 = sw[1];
+                            } else {
+                                const uint4* sw = (const uint4*)(p.ssp + (size_t)tile * 64 + (8 * c + 4 * kh) * 2);
+                                s01 = sw[0]; s23 = sw[1];
+                            }
+                            const float xs[4] = {__uint_as_float(raw[c].x), __uint_as_float(raw[c].y), __uint_as_float(raw[c].z), __uint_as_float(raw[c].w)};
+                            const float sc[4] = {__uint_as_float(s01.x), __uint_as_float(s01.z), __uint_as_float(s23.x), __uint_as_float(s23.z)};
+                            const float sh[4] = {__uint_as_float(s01.y), __uint_as_float(s01.w), __uint_as_float(s23.y), __uint_as_float(s23.w)};
+                            float y[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float f = __builtin_fmaf(xs[e], sc[e], sh[e]);
+                                y[e] = f > 0.f ? f : f * p.slope;
+                            }
+                            union {
+                                gh2_t v;
+                                unsigned u;
+                            } h01, h23, l01, l23;
+                            typedef float ghf2_t __attribute__((ext_vector_type(2)));
+                            h01.v = __builtin_convertvector(ghf2_t{y[0], y[1]}, gh2_t);
+                            h23.v = __builtin_convertvector(ghf2_t{y[2], y[3]}, gh2_t);
+                            l01.v = __builtin_convertvector(ghf2_t{y[0] - (float)h01.v[0], y[1] - (float)h01.v[1]}, gh2_t);
+                            l23.v = __builtin_convertvector(ghf2_t{y[2] - (float)h23.v[0], y[3] - (float)h23.v[1]}, gh2_t);
+                            // A = hi words, B = lo words: the swap exchanges A's upper lanes with B's lower lanes ->
+                            // k-half 0: (A, B) = (own hi ch 0-3, partner's hi ch 4-7); k-half 1: (partner's lo ch 0-3, own lo ch 4-7)
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(h01.u, l01.u, false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(h23.u, l23.u, false, false);
+                            union {
+                                unsigned u[4];
+                                f16x8 f;
+                            } b;
+                            b.u[0] = s0[0]; b.u[1] = s1[0]; b.u[2] = s0[1]; b.u[3] = s1[1];
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah[c], b.f, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal[c], b.f, d, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) d[i] *= p.winv;
+                    } else {
                     // wave-uniform 64-bit base + 32-bit lane offset (scalar-base global loads)
                     gptr_t ab = (gptr_t)p.act + (size_t)tile * 2 * pv * 32;
                     asm volatile("" : "+s"(ab));
@@ -171,7 +254,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
                     unsigned o1 = o0;
                     asm volatile("" : "+v"(o1));
                     const uint4 r1 = gload4(ab1, o1);
-                    float g = 1.0f;
                     if (GAUSS) {
                         gptr_t gb = (gptr_t)p.gauss;
                         asm volatile("" : "+s"(gb));
@@ -187,8 +269,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
                         const uint4* sw = (const uint4*)(p.ssp + ((size_t)tile * 2 + kh) * 16);
                         sc0 = sw[0]; sh0 = sw[1]; sc1 = sw[2]; sh1 = sw[3];
                     }
-                    f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xform(r0, sc0, sh0), zero, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xform(r0, sc0, sh0), zero, 0, 0, 0);
                     d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xform(r1, sc1, sh1), d, 0, 0, 0);
+                    }
                     if (in) {
                         // two entries per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_cvt_pk_f16_f32): the same fp32 operations
                         // and RTNE roundings per entry -- the kernel is VALU-bound (~700 wave instructions per 32-voxel run)
@@ -355,6 +438,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
     if (any_inf) atomicOr(p.inf_flag, 1);
 }
 
+template <bool GAUSS, bool SSLDS, bool MULTI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8))) void k_gather_head(GatherArgs p) {
+    gather_head_body<GAUSS, SSLDS, MULTI, false>(p);
+}
+
+// (32 + 16 more registers for the split weights and the four fp32 octets: four waves per SIMD)
+template <bool GAUSS, bool SSLDS, bool MULTI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_gather_head_x3(GatherArgs p) {
+    gather_head_body<GAUSS, SSLDS, MULTI, true>(p);
+}
+
 int launch_pack_head_ss(boa_ctx* ctx, const float* ss, unsigned* out, int n_tiles) {
     hipLaunchKernelGGL(k_pack_head_ss, dim3((unsigned)((n_tiles * 2 + 63) / 64)), dim3(64), 0, ctx->stream, ss, out, n_tiles);
     BOA_HIP_TRY(hipGetLastError());
@@ -364,7 +458,7 @@ int launch_pack_head_ss(boa_ctx* ctx, const float* ss, unsigned* out, int n_tile
 int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, const float* w, const float* bias, const uint16_t* gauss,
                        int C, const int P[3], const int PV[3], const int ntile[3], const int* dev_tab, uint16_t* fold, int fold_mode,
                        int n_folds, const uint8_t* host_lut, int merge, uint8_t* labels, const int* crop_off, const int* crop_dims,
-                       int* inf_flag, float slope, int tiles_total) {
+                       int* inf_flag, float slope, int tiles_total, bool x3) {
     BOA_REQUIRE(C >= 1 && C <= 32 && ntile[0] < 256 && ntile[1] < 256 && ntile[2] < 256, "gather head: C=%d / %d+%d+%d tiles per axis unsupported", C,
                 ntile[0], ntile[1], ntile[2]);
     GatherArgs a;
@@ -380,6 +474,8 @@ int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, con
         a.c0 = crop_dims[0]; a.c1 = crop_dims[1]; a.c2 = crop_dims[2];
     }
     a.inf_flag = inf_flag; a.slope = slope;
+    a.wscale = X3_HEAD_WSCALE;
+    a.winv = 1.0f / a.wscale;
     for (int i = 0; i < 256; ++i) a.lut[i] = host_lut ? host_lut[i] : (unsigned char)i;
     const long long n_mt = (long long)PV[0] * PV[1] * ((PV[2] + 31) / 32);
     BOA_REQUIRE(n_mt < (1ll << 31), "gather head: volume too large for 32-bit run indices");
@@ -387,17 +483,27 @@ int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, con
     // algorithmic bytes: every tile's stash is read once (64 B activation + 2 B Gaussian per voxel), one label byte per voxel
     // (+ the fold buffer's read-modify-write)
     const double pvd = (double)P[0] * P[1] * P[2], vvd = (double)PV[0] * PV[1] * PV[2];
-    const double bytes = (double)tiles_total * pvd * 66.0 + vvd * (fold_mode == 0 ? 1.0 : (fold_mode == 1 ? 2.0 * C : 4.0 * C));
-    const size_t ss_bytes = (size_t)tiles_total * 128;
+    const double bytes = (double)tiles_total * pvd * (x3 ? 130.0 : 66.0) + vvd * (fold_mode == 0 ? 1.0 : (fold_mode == 1 ? 2.0 * C : 4.0 * C));
+    const size_t ss_bytes = (size_t)tiles_total * (x3 ? 256 : 128);
     a.ss_in_lds = ss_bytes <= 96 * 1024 ? 1 : 0;
     static bool once = (hipFuncSetAttribute((const void*)k_gather_head<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
                         hipFuncSetAttribute((const void*)k_gather_head<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
                         hipFuncSetAttribute((const void*)k_gather_head<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
-                        hipFuncSetAttribute((const void*)k_gather_head<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
+                        hipFuncSetAttribute((const void*)k_gather_head<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head_x3<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head_x3<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head_x3<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head_x3<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024), true);
     (void)once;
     KernelTimer tm(ctx, BOA_K_HEAD_ACCUM, 2.0 * (double)tiles_total * pvd * 32 * C, bytes);
     const size_t lds = a.ss_in_lds ? ss_bytes : 0;
-#define GH_LAUNCH(G, S, M) hipLaunchKernelGGL((k_gather_head<G, S, M>), dim3(grid), dim3(256), lds, ctx->stream, a)
+#define GH_LAUNCH(G, S, M)                                                                               \
+    do {                                                                                                 \
+        if (x3)                                                                                          \
+            hipLaunchKernelGGL((k_gather_head_x3<G, S, M>), dim3(grid), dim3(256), lds, ctx->stream, a); \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_gather_head<G, S, M>), dim3(grid), dim3(256), lds, ctx->stream, a);    \
+    } while (0)
     const bool multi = fold_mode != 0;
     if (gauss && a.ss_in_lds) {
         if (multi) GH_LAUNCH(true, true, true); else GH_LAUNCH(true, true, false);
@@ -409,6 +515,7 @@ int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, con
         if (multi) GH_LAUNCH(false, false, true); else GH_LAUNCH(false, false, false);
     }
 #undef GH_LAUNCH
+    if (x3) ctx->counters[BOA_CNT_X3]++;
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

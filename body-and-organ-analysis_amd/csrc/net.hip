@@ -609,10 +609,14 @@ static int net_head(boa_net* net, int i, const int P[3], int plane_skip, float* 
         return launch_head_f32(net->ctx, last.out32 + (size_t)i * pv * d.features[0] + (size_t)plane_skip * d.patch[1] * d.patch[2] * d.features[0],
                                ss, d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc,
                                nacc, PV, start);
-    if (net->precision == 2)   // split-precision mode: fp32 octet planes; skipped axis-0 planes are an offset inside every plane
-        return launch_head_f32(net->ctx, last.out32 + (size_t)i * pv * d.features[0] + (size_t)plane_skip * d.patch[1] * d.patch[2] * 8, ss,
-                               d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc, PV,
-                               start, pv);
+    if (net->precision == 2) {  // split-precision mode: fp32 octet planes; skipped axis-0 planes are an offset inside every plane
+        const float* a32 = last.out32 + (size_t)i * pv * d.features[0] + (size_t)plane_skip * d.patch[1] * d.patch[2] * 8;
+        if (d.features[0] == 32 && d.num_classes <= 32)   // the gather head's arithmetic (label path == logits API, bit for bit)
+            return launch_head_x3(net->ctx, a32, ss, d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc,
+                                  nacc, PV, start, pv);
+        return launch_head_f32(net->ctx, a32, ss, d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc,
+                               PV, start, pv);
+    }
     // chunk-planar fp16: skipping leading axis-0 planes is an offset inside every 16-channel plane; plane stride = whole tile
     return launch_head(net->ctx, last.out + (size_t)i * pv * d.features[0] + (size_t)plane_skip * d.patch[1] * d.patch[2] * 16, ss,
                        d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, logits_out, gauss, acc, nacc, PV,
@@ -803,7 +807,7 @@ extern "C" int boa_net_predict_sliding_window(boa_net* net, const float* dev_vol
 // ------------------------------------------------------------------------------------------------------
 // Fused sliding window -> labels (head_gather.hip): the conv stack writes the last decoder activation of EVERY tile of the
 // volume into the context's stash, then one gather pass per fold walks the volume.  Conditions (else the caller uses
-// boa_net_predict_sliding_window + boa_finalize_labels): production precision, no test-time mirroring, features[0] == 32,
+// boa_net_predict_sliding_window + boa_finalize_labels): production or split-precision mode, no test-time mirroring, features[0] == 32,
 // <= 32 classes, tile origins = the full cartesian grid of per-axis steps in canonical (x outer, z inner) order.
 static bool grid_origins(const int* o, int n, std::vector<int> (&steps)[3]) {
     for (int a = 0; a < 3; ++a) steps[a].clear();
@@ -836,7 +840,7 @@ extern "C" int boa_net_labels_supported(boa_net* net, const int* host_origins, i
     static const bool off = getenv("BOA_NO_GATHER_HEAD") != nullptr;
     // (patch z extent a multiple of 32 and <= 31 classes: the shapes for which the scatter loop's head runs on the matrix cores too,
     //  so that the label path and the logits API share one head arithmetic)
-    if (off || net->precision != 0 || net->mirror_mask != 0 || net->d.features[0] != 32 || net->d.num_classes > 31 || net->d.patch[2] % 32 != 0) return 0;
+    if (off || net->precision == 1 || net->mirror_mask != 0 || net->d.features[0] != 32 || net->d.num_classes > 31 || net->d.patch[2] % 32 != 0) return 0;
     std::vector<int> steps[3];
     return grid_origins(host_origins, n_tiles, steps) ? 1 : 0;
 }
@@ -862,7 +866,8 @@ extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume
     const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2];
     // stash layout: [activations][fp32 ss][packed ss16 of the conv stack][head ss table][steps]
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_act = 0, o_ss = align((size_t)n_tiles * pv * F0 * sizeof(__half)), o_ss16 = align(o_ss + (size_t)n_tiles * F0 * 2 * sizeof(float)),
+    const bool x3 = net->precision == 2;   // split-precision mode: the stash holds the fp32 octet planes, the head reads the fp32 (scale, shift)
+    const size_t o_act = 0, o_ss = align((size_t)n_tiles * pv * F0 * (x3 ? sizeof(float) : sizeof(__half))), o_ss16 = align(o_ss + (size_t)n_tiles * F0 * 2 * sizeof(float)),
                  o_ssp = align(o_ss16 + (size_t)n_tiles * F0 * sizeof(unsigned)), o_steps = align(o_ssp + (size_t)n_tiles * 32 * sizeof(unsigned)),
                  need = align(o_steps + ((size_t)n_tiles + PV[0] + PV[1] + PV[2] + 64) * sizeof(int));
     if (c->stash_bytes < need) {
@@ -871,6 +876,18 @@ extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume
         c->stash = nullptr;
         c->stash_bytes = 0;
         boa_trim(c);
+        // The stash may take a bounded share of what is free NOW ($BOA_STASH_FRAC, default 0.6): what follows the network on this
+        // context and on the GPU's other contexts -- fold buffers, post-processing volumes, the second lane, RCCL buffers -- has no
+        // fallback of its own, the tile loop has one (BOA_ENOMEM here sends the caller to the scatter form, which needs
+        // (C + 1) fp16 planes instead of a tile stash).
+        {
+            static const double frac = getenv("BOA_STASH_FRAC") ? atof(getenv("BOA_STASH_FRAC")) : 0.6;
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)need > frac * (double)fr) {
+                boa_set_error("fused sliding window: stash of %zu bytes exceeds %.2f of the %zu free bytes", need, frac, fr);
+                return BOA_ENOMEM;
+            }
+        }
         if (hipMalloc(&c->stash, need) != hipSuccess) {
             (void)hipGetLastError();
             c->stash = nullptr;
@@ -887,22 +904,29 @@ extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume
     int* s_steps = (int*)(base + o_steps);
     ConvLayer& last = net->dec.back().back();
     __half* keep_out = last.out;
+    float* keep_out32 = last.out32;
     float* keep_ss = last.ss;
     unsigned* keep_ss16 = last.ss16;
     int rc = BOA_OK;
+    c->stash_busy = true;   // (boa_trim must not release the stash while tiles are being written into it)
     for (int t0 = 0; t0 < n_tiles && rc == BOA_OK; t0 += net->maxN) {
         const int nb = std::min(net->maxN, n_tiles - t0);
         // the last decoder conv of this batch writes straight into the stash slots of its tiles
-        last.out = s_act + (size_t)t0 * pv * F0;
+        if (x3)
+            last.out32 = (float*)s_act + (size_t)t0 * pv * F0;
+        else
+            last.out = s_act + (size_t)t0 * pv * F0;
         last.ss = s_ss + (size_t)t0 * F0 * 2;
         last.ss16 = s_ss16 + (size_t)t0 * F0;
         rc = net_forward_stack(net, dev_volume, V, off, host_origins + (size_t)t0 * 3, nb);
     }
     last.out = keep_out;
+    last.out32 = keep_out32;
     last.ss = keep_ss;
     last.ss16 = keep_ss16;
+    c->stash_busy = false;   // (everything that uses it from here on is queued on the stream: a trim synchronises first)
     if (rc) return rc;
-    BOA_TRY(launch_pack_head_ss(c, s_ss, s_ssp, n_tiles));
+    if (!x3) BOA_TRY(launch_pack_head_ss(c, s_ss, s_ssp, n_tiles));
     // walk table: tile origins per axis, then per coordinate the first covering tile and the count (x, y), per 32-voxel z run the
     // tiles that intersect the run
     std::vector<int> tab;
@@ -925,8 +949,9 @@ extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume
     c->prof_break = true;
     const int ntile[3] = {(int)steps[0].size(), (int)steps[1].size(), (int)steps[2].size()};
     const int mode = n_folds == 1 ? 0 : (fold_index == 0 ? 1 : (fold_index + 1 == n_folds ? 3 : 2));
-    return launch_gather_head(c, s_act, s_ssp, net->head_w, net->head_b, dev_gauss, d.num_classes, d.patch, PV, ntile, s_steps, dev_fold, mode,
-                              n_folds, host_lut, merge, dev_labels_out, crop_off, crop_dims, dev_inf_flag, d.lrelu_slope, n_tiles);
+    return launch_gather_head(c, s_act, x3 ? (const unsigned*)s_ss : s_ssp, net->head_w, net->head_b, dev_gauss, d.num_classes, d.patch, PV, ntile,
+                              s_steps, dev_fold, mode, n_folds, host_lut, merge, dev_labels_out, crop_off, crop_dims, dev_inf_flag, d.lrelu_slope,
+                              n_tiles, x3);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1054,6 +1079,10 @@ extern "C" int boa_net_apply_deferred(boa_net* net, const boa_stash* st, const u
             BOA_TRY(launch_head_f32(net->ctx, (const float*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
                                     d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
                                     dev_acc, dev_n, PV, it.start));
+        else if (net->precision == 2 && d.features[0] == 32 && d.num_classes <= 32)
+            BOA_TRY(launch_head_x3(net->ctx, (const float*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
+                                   d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
+                                   dev_acc, dev_n, PV, it.start, (size_t)it.planes * d.patch[1] * d.patch[2]));
         else if (net->precision == 2)
             BOA_TRY(launch_head_f32(net->ctx, (const float*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
                                     d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,

@@ -131,6 +131,92 @@ __global__ __launch_bounds__(256) void k_convt_x3(X3ConvTArgs p) {
     }
 }
 
+struct X3HeadArgs {
+    const float* act;  // octet planes [F0/8 = 4][plane_stride voxels][8] of one tile (raw output of the last decoder conv)
+    const float* ss;   // [32][2]
+    size_t plane_stride, pv;
+    int P1, P2, C;
+    const float* w;    // [C][32]
+    const float* bias;
+    float slope, wscale, winv;
+    float* logits;     // [C][pv] or nullptr
+    const unsigned short* gauss;
+    unsigned short* acc;
+    unsigned short* nacc;
+    int V0, V1, V2, s0, s1, s2;
+};
+
+// 1x1x1 head of the split-precision mode, scatter form (logits API, mirrored / sharded / deferred paths): one wave = 32 consecutive
+// voxels of the tile.  The logits are computed EXACTLY as k_gather_head_x3 computes them (same operand split, same MFMA sequence
+// from a zero accumulator, * winv, + bias), so the label path and the logits API agree bit for bit; then either the fp32 logits
+// are stored, or the reference's accumulate step runs (predict_from_raw_data.py:611-614: pred * gauss in fp32, fp16 += ).
+__global__ __launch_bounds__(256) void k_head_x3(X3HeadArgs p) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+    const size_t i = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + l31;
+    const bool valid = i < p.pv;
+    const size_t ii = valid ? i : 0;
+    f32x16 d;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f16x8 ah, al;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float wv = l31 < p.C ? p.w[l31 * 32 + 8 * c + k] * p.wscale : 0.f;
+            const _Float16 h = (_Float16)wv;
+            ah[k] = h;
+            al[k] = (_Float16)(wv - (float)h);
+        }
+        const float4 x = *(const float4*)(p.act + ((size_t)c * p.plane_stride + ii) * 8 + 4 * kh);
+        const float* ss = p.ss + (8 * c + 4 * kh) * 2;
+        const float4 s01 = *(const float4*)ss, s23 = *(const float4*)(ss + 4);
+        const float xs[4] = {x.x, x.y, x.z, x.w}, sc[4] = {s01.x, s01.z, s23.x, s23.z}, sh[4] = {s01.y, s01.w, s23.y, s23.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f = __builtin_fmaf(xs[e], sc[e], sh[e]);
+            y[e] = f > 0.f ? f : f * p.slope;
+        }
+        uint2 hi, lo;
+        x3_split4(y, hi, lo);
+        // k-half 0 ends up with the hi parts of all 8 channels, k-half 1 with the lo parts (see k_gather_head_x3)
+        const auto s0 = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
+        union {
+            unsigned u[4];
+            f16x8 f;
+        } b;
+        b.u[0] = s0[0]; b.u[1] = s1[0]; b.u[2] = s0[1]; b.u[3] = s1[1];
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.f, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.f, d, 0, 0, 0);
+    }
+    if (!valid) return;
+    size_t vi = 0;
+    float g = 1.f;
+    if (!p.logits) {
+        const unsigned u = (unsigned)i, r = u / (unsigned)p.P2;
+        const int p2 = (int)(u - r * (unsigned)p.P2), p0 = (int)(r / (unsigned)p.P1), p1 = (int)(r - (unsigned)p0 * (unsigned)p.P1);
+        vi = ((size_t)(p.s0 + p0) * p.V1 + (p.s1 + p1)) * p.V2 + (p.s2 + p2);
+        if (p.gauss) g = us2f(p.gauss[i]);
+    }
+    const size_t vv = (size_t)p.V0 * p.V1 * p.V2;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = 8 * (k >> 2) + 4 * kh + (k & 3);
+        if (c >= p.C) continue;
+        const float sum = d[k] * p.winv + p.bias[c];
+        if (p.logits) {
+            p.logits[(size_t)c * p.pv + i] = sum;
+        } else {
+            const float pr = p.gauss ? sum * g : sum;
+            unsigned short* ap = p.acc + (size_t)c * vv + vi;
+            *ap = f2us(us2f(*ap) + pr);
+        }
+    }
+    if (!p.logits && kh == 0) p.nacc[vi] = f2us(us2f(p.nacc[vi]) + g);
+}
+
 // octet planes [C/8][vox][8] (+ deferred norm) -> [C][vox] fp32 (debug read-back)
 __global__ void k_octet_to_nchw_f32(const float* __restrict__ in, const float* __restrict__ ss, float slope, int C, size_t vox,
                                     float* __restrict__ out) {
@@ -170,6 +256,31 @@ int launch_convt_x3(boa_ctx* ctx, const float* src, const float* ss, int Cin, in
         hipLaunchKernelGGL(k_convt_x3<2>, grid, dim3(256), lds, ctx->stream, a);
     else
         hipLaunchKernelGGL(k_convt_x3<1>, grid, dim3(256), lds, ctx->stream, a);
+    ctx->counters[BOA_CNT_X3]++;
+    tm.stop();
+    BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+int launch_head_x3(boa_ctx* ctx, const float* act, const float* ss, int F0, const int P[3], int C, const float* w, const float* bias,
+                   float slope, float* logits_out, const uint16_t* gauss, uint16_t* acc, uint16_t* nacc, const int PV[3], const int start[3],
+                   size_t plane_stride) {
+    BOA_REQUIRE(F0 == 32 && C >= 1 && C <= 32, "head_x3: features[0]=%d / %d classes unsupported (32 features, <= 32 classes)", F0, C);
+    X3HeadArgs a;
+    a.act = act; a.ss = ss; a.plane_stride = plane_stride; a.pv = (size_t)P[0] * P[1] * P[2]; a.P1 = P[1]; a.P2 = P[2]; a.C = C;
+    a.w = w; a.bias = bias; a.slope = slope; a.wscale = X3_HEAD_WSCALE; a.winv = 1.0f / X3_HEAD_WSCALE;
+    a.logits = logits_out; a.gauss = gauss; a.acc = acc; a.nacc = nacc;
+    BOA_REQUIRE(a.pv < (1ull << 32), "head_x3: tile too large");
+    if (!logits_out) {
+        for (int d = 0; d < 3; ++d)
+            BOA_REQUIRE(start[d] >= 0 && start[d] + P[d] <= PV[d], "head_x3: tile [%d,%d) outside accumulator dim %d (%d)", start[d], start[d] + P[d],
+                        d, PV[d]);
+        a.V0 = PV[0]; a.V1 = PV[1]; a.V2 = PV[2]; a.s0 = start[0]; a.s1 = start[1]; a.s2 = start[2];
+    } else {
+        a.V0 = a.V1 = a.V2 = a.s0 = a.s1 = a.s2 = 0;
+    }
+    KernelTimer tm(ctx, BOA_K_HEAD_ACCUM, 2.0 * a.pv * F0 * C, (double)a.pv * (4.0 * F0 + (logits_out ? 4.0 * C : (4.0 * (C + 1) + 2.0))));
+    hipLaunchKernelGGL(k_head_x3, dim3((unsigned)((a.pv + 127) / 128)), dim3(256), 0, ctx->stream, a);
     ctx->counters[BOA_CNT_X3]++;
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());

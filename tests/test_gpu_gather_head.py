@@ -19,12 +19,12 @@ def ctx():
     c.close()
 
 
-def _pred(ctx, patch, nc, folds, step, gaussian=True, features=(32, 64), batch=3):
+def _pred(ctx, patch, nc, folds, step, gaussian=True, features=(32, 64), batch=3, precision=None):
     from boa_hip import plans
     from boa_hip.predictor import HipPredictor
     pj, dj = plans.synthetic_plans(patch=patch, features=features, num_classes=nc)
     geom = plans.model_config_from_plans(pj, dj).geometry
-    p = HipPredictor(ctx, geom, tile_step_size=step, max_batch=batch, use_gaussian=gaussian)
+    p = HipPredictor(ctx, geom, tile_step_size=step, max_batch=batch, use_gaussian=gaussian, precision=precision)
     p.set_parameters([plans.weight_blob_from_state_dict(geom, plans.synthetic_state_dict(geom, 40 + f)) for f in range(folds)])
     return p
 
@@ -36,16 +36,18 @@ def _pred(ctx, patch, nc, folds, step, gaussian=True, features=(32, 64), batch=3
     ((32, 32, 32), (20, 40, 45), 4, 2, 0.5, True),        # volume smaller than the patch on axis 0: pad_nd_image + crop
     ((32, 64, 32), (64, 64, 64), 12, 1, 0.5, False),      # use_gaussian=False (weight 1)
 ])
-def test_gather_labels_equal_scatter_labels(ctx, patch, shape, nc, folds, step, gaussian):
+@pytest.mark.parametrize("precision", ["fp16", "fp32"])
+def test_gather_labels_equal_scatter_labels(ctx, patch, shape, nc, folds, step, gaussian, precision):
     """Three results must coincide: (a) the gather form; (b) the ORACLE's tile loop (oracle.sliding_window: accumulate_tile /
     finalize_logits / ensemble_folds / argmax, pinned to the reference by golden G3 / G3b / G6) fed with the device's own per-tile
     fp32 logits (k_head_mfma's logits mode: the same MFMA / bias arithmetic); (c) the scatter form whenever it ran the MFMA head
     (tile origins 8-aligned along z) -- with unaligned origins the scatter loop falls back to an fp32 VALU head whose logits
-    differ in the last bits, so (c) is then only required to agree on >= 99.9 % of the voxels."""
+    differ in the last bits, so (c) is then only required to agree on >= 99.9 % of the voxels.
+    precision "fp32" = the split-precision mode: k_gather_head_x3 against k_head_x3 (one arithmetic for every tile origin)."""
     from oracle import labels as olab
     from oracle import sliding_window as osw
     from boa_hip import sliding_window as sw
-    p = _pred(ctx, patch, nc, folds, step, gaussian)
+    p = _pred(ctx, patch, nc, folds, step, gaussian, precision=precision)
     x = np.random.default_rng(sum(shape)).standard_normal((1, *shape)).astype(np.float32)
     lut = (np.arange(nc) * 3 % 251).astype(np.uint8)
     lut[0] = 0
@@ -54,7 +56,9 @@ def test_gather_labels_equal_scatter_labels(ctx, patch, shape, nc, folds, step, 
     want = p.predict_segmentation(x)
     want_lut = p.predict_segmentation(x, lut=lut)
     cs = ctx.counters(reset=True)
-    scatter_heads = cs["head_mfma"] + cs["head_valu"]
+    scatter_heads = cs["head_mfma"] + cs["head_valu"] if precision == "fp16" else cs["x3"]
+    if precision == "fp32":
+        assert cs["conv_x3"] > 0 and cs["conv_ws"] == 0 and cs["f32"] == 0, cs
     p.use_gather_head = True
     got = p.predict_segmentation(x)
     got_lut = p.predict_segmentation(x, lut=lut)
@@ -161,8 +165,9 @@ def test_total_pipeline_same_labels_both_forms(ctx):
 
 
 
+@pytest.mark.parametrize("precision", ["fp16", "fp32"])
 @pytest.mark.parametrize("nc", [2, 4, 5, 13])
-def test_gather_ties_and_small_class_counts(ctx, nc):
+def test_gather_ties_and_small_class_counts(ctx, nc, precision):
     """Single-fold fast path of the gather epilogue (argmax from the extremes of the running sums + exact quotients of the
     near-maximum classes): head rows duplicated so that classes TIE exactly -- across the two lanes that hold a voxel's classes and
     within one -- and class counts for which the second lane holds no class at all (nc <= 4).  Labels must equal numpy's argmax
@@ -181,7 +186,7 @@ def test_gather_ties_and_small_class_counts(ctx, nc):
     for dst, src in dup:           # class dst := class src (exact ties wherever src wins)
         sd[kw][dst] = sd[kw][src]
         sd[kb][dst] = sd[kb][src]
-    p = HipPredictor(ctx, geom, tile_step_size=step, max_batch=3)
+    p = HipPredictor(ctx, geom, tile_step_size=step, max_batch=3, precision=precision)
     p.set_parameters([plans.weight_blob_from_state_dict(geom, sd)])
     x = np.random.default_rng(nc).standard_normal((1, *shape)).astype(np.float32)
     got = p.predict_segmentation(x)
