@@ -57,9 +57,14 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host (PCIe-inclusive) extra")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp16-vs-exact-mode label flip sample")
+    ap.add_argument("--no-exact", action="store_true", help="skip the measured whole-volume run of the fp32 (split-precision) mode")
+    ap.add_argument("--exact-batch", type=int, default=8, help="tile batch of the fp32-mode volume (2 GB of fp32 activations per tile and net)")
     ap.add_argument("--cpu-tiles", type=int, default=8)
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="cpu_baseline: also time one tile forward on every host core (oversubscribed hosts: ~30 s; off by default)")
     ap.add_argument("--lanes", type=int, default=2, choices=[2, 3],
                     help="streams of the overlap extra: 2 = `total` | both BCA nets, 3 = `total` | body_parts | body_regions")
+    ap.add_argument("--no-c3", action="store_true", help="skip the configs[2] extra (one 512x512x768 volume, total+bca)")
     ap.add_argument("--no-lanes", action="store_true", help="skip the two-lane extra (`total` and the BCA nets on two streams)")
     ap.add_argument("--no-prof", action="store_true", help="no per-launch events (measures their overhead; roofline fields become 0)")
     ap.add_argument("--shard", choices=["volumes", "tiles", "models"], default="volumes",
@@ -143,7 +148,7 @@ def cpu_baseline(part_model, n_tiles_sample, work, log, device_tiles=None):
         # the same forward with every host core (SURVEY 8d asks for both settings): 2 tiles
         allc = os.cpu_count() or 1
         t_tile_all = None
-        if allc > threads:
+        if allc > threads and work.get("all_cores"):
             torch.set_num_threads(allc)
             t0 = time.perf_counter()
             net(tiles[0])                       # one forward (oversubscribed hosts take ~10x the 8-thread time: keep the leg bounded)
@@ -168,34 +173,59 @@ def cpu_baseline(part_model, n_tiles_sample, work, log, device_tiles=None):
     t0 = time.perf_counter()
     olab.merge_parts([seg] * 5, [label_maps.CLASS_MAP_PARTS[t] for t in label_maps.PART_TASK_IDS], label_maps.CLASS_MAP_TOTAL_INV)
     t_merge = (time.perf_counter() - t0) / pv                  # per voxel (all five parts)
+    # aggregation / post-processing / resampling stages on slabs with the volume's full in-plane extent (a quarter of its slices
+    # for the voxel passes, half of the 5 mm grid for the connected-component stages), blocky label phantoms (32^3 blocks) so that
+    # the statistics and the labelling see regions, not noise; extrapolated by voxel counts
+    from oracle import resample as ores
     rng = np.random.default_rng(0)
-    ct = rng.integers(-1000, 1500, size=patch).astype(np.int16)
-    regions = rng.integers(0, 12, size=patch).astype(np.uint8)
-    parts = rng.integers(0, 7, size=patch).astype(np.uint8)
-    total = rng.integers(0, 118, size=patch).astype(np.uint8)
+    vx, vy, vz = work["shape"]
+
+    def blocky(n, sh, b=32):
+        small = rng.integers(0, n, size=[(v + b - 1) // b for v in sh]).astype(np.uint8)
+        return np.kron(small, np.ones((b, b, b), np.uint8))[:sh[0], :sh[1], :sh[2]]
+
+    slab = (max(vz // 4, 32), vy, vx)                          # SimpleITK order (z, y, x), a quarter of the slices
+    ct = rng.integers(-1000, 1500, size=slab).astype(np.int16)
+    regions, parts, total = blocky(12, slab), blocky(7, slab), blocky(118, slab)
     t0 = time.perf_counter()
     tis = obca.subclassify_tissues(ct, regions)
     obca.slicewise_measurements(tis, parts, (1.5, 1.5, 1.5))
     omeas.metrics_for_each_region(ct, total, {f"l{i}": i for i in range(1, 118)}, None, None, (1.5, 1.5, 1.5))
-    t_agg = (time.perf_counter() - t0) / pv                    # per voxel
+    t_agg = (time.perf_counter() - t0) / float(np.prod(slab))  # per voxel
+    s_post = s_res = 0.0
+    if work["with_bca"]:
+        z5 = int(round(vz * 1.5 / 5.0))
+        half5 = (max(z5 // 2, 8), vy, vx)
+        t0 = time.perf_counter()
+        obca.postprocess_region_segmentation(blocky(12, half5))     # four 26-connected labelings (BCA/body_regions/postprocess.py)
+        obca.remove_small_labeled_objects(blocky(7, half5))         # slice-wise contour fill + small objects / holes (body_parts)
+        s_post = (time.perf_counter() - t0) * (z5 * vy * vx) / float(np.prod(half5))
+        t0 = time.perf_counter()
+        small, _ = ores.change_spacing_array(ct, (1.5, 1.5, 1.5), (5.0, 1.5, 1.5), order=3)       # cubic to the 5 mm grid (TS/resampling.py)
+        ores.change_spacing_array(regions[:small.shape[0]], (5.0, 1.5, 1.5), target_shape=slab, order=0)  # nearest back
+        s_res = (time.perf_counter() - t0) * work["voxels"] / float(np.prod(slab)) * 1.5   # one cubic in, two label volumes back
     s_net = t_tile * work["tile_forwards"]
     s_arg = t_argmax * work["class_voxels"]
     s_merge = t_merge * work["voxels"]
     s_agg = t_agg * work["voxels"] * (1.0 if work["with_bca"] else 0.5)
-    total_s = s_net + s_arg + s_merge + s_agg
+    total_s = s_net + s_arg + s_merge + s_agg + s_post + s_res
     log(f"cpu_baseline: {t_tile:.3f} s per tile forward+accumulate on {threads} threads"
         + (f" ({t_tile_all:.3f} s per forward on all {allc} cores)" if t_tile_all else "")
-        + f"; per volume: nets {s_net:.0f} s, normalise+argmax {s_arg:.0f} s, merge {s_merge:.0f} s, aggregation {s_agg:.0f} s")
+        + f"; per volume: nets {s_net:.0f} s, normalise+argmax {s_arg:.0f} s, merge {s_merge:.0f} s, aggregation {s_agg:.0f} s, "
+          f"CC / contour-fill post-processing {s_post:.0f} s, resampling {s_res:.0f} s")
     out = {"value": 1.0 / total_s, "unit": "volumes/s", "cores": threads, "kind": "port",
            "sample": f"{len(tiles)} x 128^3 tile forward (torch-CPU fp32 PlainConvUNet, 31M params, {threads} threads = the reference's own cap, "
                      f"predict_from_raw_data.py:479-480) + fp16 Gaussian "
-                     f"accumulation; normalise + argmax, the reference's 117-pass part merge, tissue map + slice tables + per-label HU "
-                     f"statistics on one 128^3 block each (numpy, 1 thread); extrapolated by unit counts to {work['tile_forwards']} tile "
-                     f"forwards, {work['class_voxels']:.3g} class-voxels, {work['voxels']:.3g} voxels per volume",
-           "s_per_tile": t_tile, "s_per_volume": {"nets": s_net, "argmax": s_arg, "merge": s_merge, "aggregation": s_agg},
+                     f"accumulation; normalise + argmax and the reference's 117-pass part merge on one 128^3 block; tissue map + slice tables "
+                     f"+ per-label HU statistics on a {slab[2]}x{slab[1]}x{slab[0]} slab (a quarter of the slices); 26-connected labelings + slice-wise "
+                     f"contour fill on half of the 5 mm grid; cubic resampling to 5 mm + nearest back on the slab (numpy / scipy, 1 thread); "
+                     f"extrapolated by unit counts to {work['tile_forwards']} tile forwards, {work['class_voxels']:.3g} class-voxels, "
+                     f"{work['voxels']:.3g} voxels per volume",
+           "s_per_tile": t_tile, "s_per_volume": {"nets": s_net, "argmax": s_arg, "merge": s_merge, "aggregation": s_agg,
+                                                  "cc_postprocessing": s_post, "resampling": s_res},
            "host_cpus": os.cpu_count()}
     if t_tile_all:
-        s_all = t_tile_all * work["tile_forwards"] + s_arg + s_merge + s_agg
+        s_all = t_tile_all * work["tile_forwards"] + s_arg + s_merge + s_agg + s_post + s_res
         out["all_cores"] = {"cores": allc, "s_per_tile_forward": t_tile_all, "value": 1.0 / s_all,
                             "note": "same extrapolation with the network forward on every host core (1 tile timed); the numpy stages are single-threaded either way"}
     return out, vs_oracle
@@ -225,18 +255,13 @@ def parity_sample(ctx, part_model_cfg, blob, batch, log, tile_forwards, step_s):
         t_mode[prec] = (time.perf_counter() - t0) / len(origins)
         preds[prec] = p
     flips = float((labs["fp16"] != labs["fp32"]).mean())
-    # exact mode for a whole volume: its per-tile time in place of the production mode's, everything else as measured
-    s_exact = step_s + (t_mode["fp32"] - t_mode["fp16"]) * tile_forwards
     log(f"parity sample: fp16 vs exact-mode label flip fraction {flips:.3g} on {labs['fp16'].size} voxels; per tile {t_mode['fp16'] * 1e3:.2f} ms (fp16) / "
-        f"{t_mode['fp32'] * 1e3:.2f} ms (exact) -> exact mode ~{1.0 / s_exact:.4f} volumes/s (extrapolated)")
+        f"{t_mode['fp32'] * 1e3:.2f} ms (exact)")
     out = {"fp16_vs_exact_mode_label_flip_fraction": flips, "voxels": int(labs["fp16"].size),
            "sample": "part model 291 (synthetic weights) on a 160x160x192 phantom crop, 8 tiles, step 0.8; exact mode = fp32 "
-                     "weights/activations/accumulation (net_f32.hip)",
-           "exact_mode": {"ms_per_tile": t_mode["fp32"] * 1e3, "production_ms_per_tile_same_sample": t_mode["fp16"] * 1e3,
-                          "volumes_per_s_extrapolated": 1.0 / s_exact,
-                          "note": f"measured on the 8-tile sample (sliding window incl. accumulate + argmax), extrapolated to the {tile_forwards} tile "
-                                  "forwards of a volume with every non-network stage at its measured production time; the label-matching mode "
-                                  "(tests: <= 2e-5 flips vs the torch-CPU oracle at this geometry)"}}
+                     "weights/activations/accumulation in split precision on the matrix cores (net_x3.hip, k_conv_ws<X3>)",
+           "exact_mode_sample": {"ms_per_tile": t_mode["fp32"] * 1e3, "production_ms_per_tile_same_sample": t_mode["fp16"] * 1e3,
+                                 "note": "8-tile sample (sliding window incl. head + argmax); the whole-volume number is parity.exact_mode"}}
 
     def dev_fn(prec, origin):
         return preds[prec].network_forward(x, np.asarray([origin], dtype=np.int32))[0]
@@ -410,6 +435,16 @@ def main():
             print(f"bench.py: {ranks_seen} ranks answered the all-reduce, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(2)
 
+    # the same loop without the per-launch HIP events (~33 k event records per step): what the events cost the headline
+    no_events = None
+    if rank == 0 and args.gpus == 1 and not args.no_prof:
+        ctx.sync()
+        tb = time.perf_counter()
+        for _ in range(2):
+            step(d_ct)
+        ctx.sync()
+        no_events = {"value": 2.0 / (time.perf_counter() - tb), "unit": "volumes/s", "steps": 2,
+                     "note": "same one-stream loop with event profiling off (the headline keeps the events: `roofline` is measured over the timed region)"}
     # what the matrix cores of this very GPU sustain with no memory traffic at all (outside the timed region, ~50 ms): the part
     # is power-limited under matrix load and the clock it holds depends on the operand bits
     attainable = None
@@ -457,6 +492,29 @@ def main():
         except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
             h2h = {"error": f"{type(e).__name__}: {e}"}
 
+    configs2 = None
+    if rank == 0 and with_bca and args.gpus == 1 and not args.no_c3 and list(shape) == [512, 512, 512]:
+        # configs[2] of BASELINE.json (the largest single-GPU configuration): one 512x512x768 whole-body volume, `total+bca`, same
+        # predictors, same one-stream runner; 1 warm-up + 2 timed volumes, CT resident
+        try:
+            shape3 = [512, 512, 768]
+            d3 = DevArray.from_numpy(ctx, synthetic.ct_phantom(shape3, seed=20260930))
+            step(d3)
+            ctx.sync()
+            t3 = []
+            for _ in range(2):
+                tb = time.perf_counter()
+                m3, b3, _ = step(d3)
+                ctx.sync()
+                t3.append(time.perf_counter() - tb)
+            d3.free()
+            configs2 = {"workload": "configs[2]: 512x512x768 @1.5 mm, total+bca, 1 x MI355X", "value": 1.0 / float(np.mean(t3)), "unit": "volumes/s",
+                        "s_per_volume": t3, "steps": len(t3),
+                        "total_labels_present": int(sum(1 for v in m3["segmentations"]["total"].values() if v.get("present"))) if m3 else None,
+                        "bca_aggregated_groups": len(b3.get("aggregated", {})) if b3 else None}
+        except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
+            configs2 = {"error": f"{type(e).__name__}: {e}"}
+        log(f"configs[2]: {configs2}")
     two_lanes = None
     if rank == 0 and with_bca and args.gpus == 1 and not args.no_lanes:
         # the product's two-lane mode (boa_hip/lanes.py): `total` + its measurements on this context's stream, both BCA nets +
@@ -552,7 +610,13 @@ def main():
             #  finalize pass; its algorithmic bytes are 66 B per voxel and covering tile, a third of the scatter form's)
             "kernel_variants": counters,
             "median_ms_per_step": float(np.median(step_s)) * 1e3,
+            # the PCIe-inclusive rate of the same workload, stated at top level next to `value` (host CT in, label volumes + tables out;
+            # details in `host_to_host`); `value` itself starts with the CT resident in HBM as the bench contract prescribes
+            "value_host_to_host": (h2h or {}).get("value"),
+            "value_without_event_profiling": (no_events or {}).get("value"),
+            "no_event_profiling": no_events,
             "total_only": total_only,
+            "configs2": configs2,
             "two_lanes": two_lanes,
             "host_to_host": h2h,
             "tables": {"total_labels_present": int(sum(1 for v in meas["segmentations"]["total"].values() if v.get("present"))) if meas else None,
@@ -581,13 +645,67 @@ def main():
         if not args.no_cpu and args.gpus == 1:
             res["cpu_baseline"], vs_oracle = cpu_baseline(part_models[0][3], args.cpu_tiles,
                                                           {"tile_forwards": tile_forwards, "class_voxels": class_voxels, "voxels": float(nvox),
-                                                           "with_bca": with_bca}, log, device_tiles=dev_tiles)
+                                                           "with_bca": with_bca, "shape": list(shape), "all_cores": args.cpu_all_cores}, log,
+                                                          device_tiles=dev_tiles)
             if vs_oracle is not None:
                 res["parity"]["vs_oracle"] = vs_oracle
         else:
             res["cpu_baseline"] = None
         if close_parity is not None:
             close_parity()
+        if not args.no_exact and args.gpus == 1:
+            # The label-contract mode, MEASURED: one whole volume of the same workload with every network in the fp32 mode
+            # (split precision on the matrix cores, csrc/net_x3.hip; labels of the CPU path: tests/test_gpu_production_geometry.py).
+            # The production predictors are closed first (fp32 activations are 2 GB per tile and net).
+            try:
+                for t in tasks:
+                    t.close()
+                tasks.clear()
+                ctx.lib.boa_trim(ctx.h)
+                te0 = time.perf_counter()
+                x_total = SegmentationTask(ctx, "total", [(tid, cfg, [blob]) for tid, cfg, blob, _ in part_models], resample=1.5,
+                                           multimodel=True, max_batch=args.exact_batch, precision="fp32")
+                x_pipe = BcaPipelineHip(ctx, bm["body_parts"], bm["body_regions"], fast_bca=False, max_batch=args.exact_batch,
+                                        precision="fp32") if with_bca else None
+                x_run = TotalBcaRunner(x_total, x_pipe, label_map, cnr_adjustment=True)
+                step(d_ct, run=x_run)                           # warm-up: weight split / packing, first touch of the fp32 activations
+                ctx.sync()
+                t_setup = time.perf_counter() - te0
+                ctx.counters(reset=True)
+                ctx.prof_reset()
+                ctx.prof_enable(True)
+                tx = []
+                for _ in range(2):
+                    tb = time.perf_counter()
+                    x_meas, _, _ = step(d_ct, run=x_run)
+                    ctx.sync()
+                    tx.append(time.perf_counter() - tb)
+                ctx.prof_enable(False)
+                xprof = ctx.prof_get()
+                xc = xprof["conv_mfma"]
+                xcnt = ctx.counters()
+                res.setdefault("parity", {})
+                res["parity"]["exact_mode"] = {
+                    "value": 1.0 / float(np.mean(tx)), "unit": "volumes/s", "s_per_volume": tx, "steps": len(tx), "measured": True,
+                    "tile_batch": args.exact_batch, "tile_forwards_per_volume": tile_forwards,
+                    "ms_per_tile_forward": float(np.mean(tx)) * 1e3 / tile_forwards,
+                    "conv_TFLOPs_fp32_equivalent": xc["flops"] / max(xc["ms"], 1e-9) / 1e9,
+                    "conv_mfma_issue_TFLOPs": 4.0 * xc["flops"] / max(xc["ms"], 1e-9) / 1e9,
+                    "conv_frac_of_f16_peak_at_4_mfma_flops_per_flop": 4.0 * xc["flops"] / max(xc["ms"], 1e-9) / 1e9 / MFMA_F16_DENSE_PEAK_TFLOPS,
+                    "kernel_ms_per_volume": {k: v["ms"] / len(tx) for k, v in xprof.items() if v["launches"]},
+                    "kernel_variants": xcnt, "setup_and_warmup_s": t_setup,
+                    "total_labels_present": int(sum(1 for v in x_meas["segmentations"]["total"].values() if v.get("present"))) if x_meas else None,
+                    "note": "the same total+bca volume with every network in the fp32 mode: fp32 weights / activations / accumulation as the "
+                            "reference's CPU path (predict_from_raw_data.py:648), every operand split into two fp16 parts on the matrix cores "
+                            "(2 MFMAs per 8 input channels and tap = 4 MFMA flops per fp32 flop); whole volumes timed, nothing extrapolated"}
+                log(f"exact (fp32 split-precision) mode: {tx} s per volume -> {1.0 / float(np.mean(tx)):.4f} volumes/s; conv "
+                    f"{xc['flops'] / max(xc['ms'], 1e-9) / 1e9:.0f} TFLOP/s fp32-equivalent; variants {xcnt}")
+                x_total.close()
+                if x_pipe is not None:
+                    x_pipe.close()
+            except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
+                res.setdefault("parity", {})
+                res["parity"]["exact_mode"] = {"error": f"{type(e).__name__}: {e}"}
         if args.dump:
             os.makedirs(os.path.dirname(os.path.abspath(args.dump)), exist_ok=True)
             with open(args.dump, "w") as f:

@@ -81,7 +81,7 @@ class BcaPipelineHip:
 
     def __init__(self, ctx: Context, parts_model: Tuple[ModelConfig, Sequence[np.ndarray]],
                  regions_model: Tuple[ModelConfig, Sequence[np.ndarray]], fast_bca: bool = False, max_batch: int = 16,
-                 parts_ctx: Optional[Context] = None):
+                 parts_ctx: Optional[Context] = None, precision: Optional[str] = None):
         """`parts_ctx`: a second Context of the same GPU (own stream and pool).  The body_parts net and its post-processing
         then run on it, driven by a worker thread, while body_regions runs on `ctx` (the two only meet in the tissue stage;
         with `crop_body` the second net needs the first one's output and the pipeline stays on one stream).  Same kernels on
@@ -101,7 +101,7 @@ class BcaPipelineHip:
                 raise ValueError(f"{name}: {len(info['folds'])} folds expected, {len(blobs)} weight sets given")
             tctx = self.parts_ctx if (name == "body_parts" and self.parts_ctx is not None) else ctx
             self.tasks[name] = SegmentationTask(tctx, name, [(info["task_id"], cfg, blobs)], resample=info["resample"],
-                                                resample_only_thickness=True, multimodel=False, max_batch=max_batch)
+                                                resample_only_thickness=True, multimodel=False, max_batch=max_batch, precision=precision)
 
         # (agg_shard.AggComm, tile_shard.ShardComm): several ranks share every volume also in the aggregation half -- CC
         # filters of body_regions, tissue pass and per-slice tables run per z-slab; None = whole volumes here
