@@ -27,6 +27,17 @@ def compute_measurements(ct_path: pathlib.Path, segmentation_folder: pathlib.Pat
         from .inference import get_context
         ctx = get_context(None)
     segmentation_folder = pathlib.Path(segmentation_folder)
+
+    def path_of(model_name):
+        return segmentation_folder / f"{'total' if model_name == 'total' else label_maps.output_name(model_name)}.nii.gz"
+
+    # every segmentation file of the run is read and inflated on worker threads while the CT is uploaded and the earlier models
+    # are measured (the reference reads them one after the other, measurements.py:257-270)
+    from concurrent.futures import ThreadPoolExecutor
+    ordered = sorted(models, key=lambda m: m != "total")
+    pool = ThreadPoolExecutor(max_workers=max(1, min(4, len(ordered))))
+    pending = {m: pool.submit(nifti.load, path_of(m)) for m in ordered if path_of(m).exists()}
+    pool.shutdown(wait=False)
     data, _, hdr = nifti.load(ct_path)
     # SimpleITK view (z,y,x) of the file, int16 HU, made on the device (a 512^3 host transpose costs ~0.5 s)
     from .util import require_int16_exact
@@ -36,13 +47,12 @@ def compute_measurements(ct_path: pathlib.Path, segmentation_folder: pathlib.Pat
     d_file.free()
     spacing = tuple(float(v) for v in hdr.get_zooms())
     am = asd = None
-    for model_name in sorted(models, key=lambda m: m != "total"):
+    for model_name in ordered:
         # (the reference looks for ADDITIONAL_MODELS_OUTPUT_NAME[model] while inference writes <model>.nii.gz, so e.g.
         #  lung_vessels -> lung_vessels_airways.nii.gz is never found and silently skipped: kept as is, :263-270)
-        model_path = segmentation_folder / f"{'total' if model_name == 'total' else label_maps.output_name(model_name)}.nii.gz"
-        if not model_path.exists():
+        if model_name not in pending:
             continue
-        seg, saff, shdr = nifti.load(model_path)
+        seg, saff, shdr = pending.pop(model_name).result()
         if not np.isclose(spacing, tuple(float(v) for v in shdr.get_zooms())).all():
             raise ValueError("The spacing of the image and of the segmentation should be the same")
         label_map = label_maps.measurement_label_map(model_name)

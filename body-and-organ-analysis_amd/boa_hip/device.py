@@ -13,10 +13,13 @@ from ._lib import check
 
 
 _LIVE = weakref.WeakSet()
+_SHUTDOWN = [False]            # set at interpreter exit: page-locked blocks are no longer handed back to a runtime that may be gone
 
 
 @atexit.register
 def _close_all():
+    # (atexit runs handlers in reverse registration order: this one is registered first and therefore runs LAST -- after
+    #  _pinned_atexit below has given the cached page-locked blocks back while the HIP runtime is still up)
     for c in list(_LIVE):
         try:
             c.close()
@@ -27,7 +30,9 @@ def _close_all():
 PINNED_MIN_BYTES = 1 << 20     # downloads of at least this many bytes land in page-locked memory (PCIe at link speed)
 
 
-PINNED_CACHE_BYTES = 8 << 30   # page-locking costs more than the copy it speeds up: released blocks are kept for reuse up to this
+# page-locking costs more than the copy it speeds up: released blocks are kept for reuse, up to $BOA_PINNED_CACHE_GB per process
+# (default 2: four 512^3 label volumes in flight; page-locked memory cannot be swapped, and a node runs one process per GPU)
+PINNED_CACHE_BYTES = int(float(__import__("os").environ.get("BOA_PINNED_CACHE_GB", "2")) * (1 << 30))
 _PINNED_FREE: dict = {}        # rounded size -> [host pointers]
 _PINNED_CACHED = [0]
 _PINNED_LOCK = threading.Lock()
@@ -47,6 +52,8 @@ class _PinnedBlock:
 
     def __del__(self):
         try:
+            if _SHUTDOWN[0]:      # interpreter teardown: the HIP runtime may already be gone (the OS reclaims the pages)
+                return
             with _PINNED_LOCK:
                 if _PINNED_CACHED[0] + self._size <= PINNED_CACHE_BYTES:
                     _PINNED_FREE.setdefault(self._size, []).append(self._ptr)
@@ -75,6 +82,15 @@ def pinned_trim(lib=None):
                 lib.boa_host_free(None, C.c_void_p(ptr))
         _PINNED_FREE.clear()
         _PINNED_CACHED[0] = 0
+
+
+@atexit.register
+def _pinned_atexit():
+    try:
+        pinned_trim()
+    except Exception:
+        pass
+    _SHUTDOWN[0] = True
 
 
 class DeviceBuffer:

@@ -81,12 +81,21 @@ class TotalBcaRunner:
                 return out
             # the order statistics on a worker thread under the BCA nets' kernels, joined before the volume is handed back
             box = {}
-            th = threading.Thread(target=lambda: box.update(meas=fin()))
+
+            def stats():
+                try:
+                    box["meas"] = fin()
+                except BaseException as e:  # noqa: BLE001  (re-raised on the calling thread after the join)
+                    box["error"] = e
+
+            th = threading.Thread(target=stats, name="boa-total-measurements")
             th.start()
             try:
                 out.update(self.pipe.run_resident(d_ct, affine, d_total))
             finally:
                 th.join()
+            if "error" in box:
+                raise box["error"]
             out["total_measurements"] = box["meas"]
             on_stage("bca")
             return out

@@ -192,6 +192,11 @@ class BcaPipelineHip:
             crop = d_parts.download() if crop_body else None
             d_regions = self._inference_device("body_regions", d_ct, affine, force_split, crop, raw_regions, done_regions)
             keep.append(d_regions)
+        except BaseException:
+            th.join()
+            if "parts" in box:             # the lane finished but this thread failed: its result must not outlive the call
+                box.pop("parts").free()
+            raise
         finally:
             th.join()
             ct_p.free()

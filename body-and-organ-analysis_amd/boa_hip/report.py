@@ -37,11 +37,14 @@ def apply_hu_window(image: np.ndarray, hu_min: float = -150.0, hu_max: float = 4
 def blend_overlay(gray_image: np.ndarray, color_rgb: np.ndarray, mask: np.ndarray, opacity: float) -> np.ndarray:
     """overlay.py:5-13: grey slice [Y][X] + per-pixel colour [Y][X][3]; pixels under `mask` are the opacity mix, the others
     the grey value on all three channels.  Only the masked pixels are mixed (the figure is mostly background)."""
-    out = np.repeat(np.asarray(gray_image, dtype=np.float64)[:, :, None], 3, axis=2)
+    gray = np.asarray(gray_image)
+    out = np.repeat(gray.astype(np.float64)[:, :, None], 3, axis=2)
     sel = np.asarray(mask, dtype=bool)
     if sel.any():
         keep = 1 - opacity
-        out[sel] = out[sel] * keep + np.asarray(color_rgb)[sel].astype(np.float64) * opacity
+        # `gray * (1 - opacity)` is evaluated in the grey image's own dtype there (a float32 slice stays float32 for this product)
+        # before the float64 colour term is added
+        out[sel] = (gray[sel] * keep)[:, None] + np.asarray(color_rgb)[sel].astype(np.float64) * opacity
     return out
 
 

@@ -351,15 +351,21 @@ def all_reduce_logit_planes(ctx, comm: ShardComm, buf, C_: int, PV, lo: int, hi:
             check(ctx.lib.boa_memset(ctx.h, C.c_void_p(base + 2 * hi * plane), 0, 2 * (int(PV[0]) - hi) * plane), "boa_memset")
     n = C_ * vox
     if comm.on_device:
-        t = comm.empty((n,), torch.float16)
-        one = (C.c_int * 3)(1, 1, n)
+        # one class plane set at a time: boa_copy3 takes 32-bit extents (25 classes x a 333 x 333 x 1000 volume would wrap), and the
+        # staging tensor is one class, not the whole logit volume
+        if vox >= 2 ** 31:
+            raise ValueError(f"all_reduce_logit_planes: {vox} voxels per class exceed the 32-bit copy extent")
+        comm.make_room(ctx)
+        t = comm.empty((vox,), torch.float16)
+        one = (C.c_int * 3)(1, 1, vox)
         st = (C.c_longlong * 3)(0, 0, 1)
         f = _Foreign(t)
-        check(ctx.lib.boa_copy3(ctx.h, buf.vp, 1, 0, st, one, f.vp, 1, 0, st), "boa_copy3")   # dtype 1 = 16-bit words
-        ctx.sync()
-        comm.all_reduce_sum(t)
-        check(ctx.lib.boa_copy3(ctx.h, f.vp, 1, 0, st, one, buf.vp, 1, 0, st), "boa_copy3")
-        ctx.sync()
+        for c in range(C_):
+            check(ctx.lib.boa_copy3(ctx.h, buf.vp, 1, c * vox, st, one, f.vp, 1, 0, st), "boa_copy3")   # dtype 1 = 16-bit words
+            ctx.sync()
+            comm.all_reduce_sum(t)
+            check(ctx.lib.boa_copy3(ctx.h, f.vp, 1, 0, st, one, buf.vp, 1, c * vox, st), "boa_copy3")
+            ctx.sync()
     else:
         t = torch.from_numpy(buf.download((n,), np.uint16).view(np.float16).copy())
         comm.all_reduce_sum(t)

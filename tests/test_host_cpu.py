@@ -358,3 +358,46 @@ def test_nifti_parallel_gzip_members(tmp_path):
     b, baff, hdr = nifti.load(p4)
     assert np.array_equal(a, b) and np.allclose(aff, baff)
     assert nifti.parse_label_xml(hdr.extensions[0][1]) == {1: "one", 2: "two"}
+
+
+def test_nifti_indexed_gzip_members_parallel_read(tmp_path):
+    """nifti.save writes gzip members that carry their own length in a FEXTRA subfield; nifti.load inflates them in parallel.
+    The file stays an ordinary gzip stream (python's gzip module and `gzip -t` read it), a foreign single-stream file takes the
+    sequential path, and a damaged member is detected by its CRC."""
+    import gzip
+    import subprocess
+    from boa_hip import nifti
+    rng = np.random.default_rng(3)
+    vol = rng.integers(0, 118, size=(96, 100, 110)).astype(np.uint8)            # ~1 MB raw: several members at block 256 KiB
+    path = tmp_path / "v.nii.gz"
+    with open(path, "wb") as f:
+        payload = vol.tobytes(order="F")
+        nifti.write_gzip_members(f, payload, 1, threads=4, block=256 << 10)
+    raw = open(path, "rb").read()
+    tab = nifti._member_table(raw)
+    assert tab is not None and len(tab) == -(-len(payload) // (256 << 10)) and sum(t[2] for t in tab) == len(payload)
+    assert gzip.decompress(raw) == payload                                       # one standard stream
+    assert subprocess.run(["gzip", "-t", str(path)]).returncode == 0
+    for th in (1, 2, 8):
+        assert bytes(nifti.read_bytes(path, threads=th)) == payload
+    # through save / load, with a header + extension in front of the data
+    aff = np.diag([1.5, 1.5, 3.0, 1.0])
+    nifti.save(tmp_path / "w.nii.gz", vol, aff, extensions=[(0, nifti.label_xml({1: "a"}))], threads=3)
+    for th in (1, 4):
+        got, a2, h = nifti.load(tmp_path / "w.nii.gz", threads=th)
+        np.testing.assert_array_equal(got, vol)
+        np.testing.assert_allclose(a2, aff)
+        assert nifti.parse_label_xml(h.extensions[0][1]) == {1: "a"}
+    # a foreign writer's single stream
+    with open(tmp_path / "f.nii.gz", "wb") as f:
+        f.write(gzip.compress(gzip.decompress(open(tmp_path / "w.nii.gz", "rb").read()), 6))
+    assert nifti._member_table(open(tmp_path / "f.nii.gz", "rb").read()) is None
+    np.testing.assert_array_equal(nifti.load(tmp_path / "f.nii.gz")[0], vol)
+    many = nifti.load_many([tmp_path / "w.nii.gz", tmp_path / "f.nii.gz", tmp_path / "w.nii.gz"], threads=4)
+    assert all(np.array_equal(m[0], vol) for m in many)
+    # corruption inside the second member's deflate data
+    bad = bytearray(raw)
+    bad[tab[1][0] + 40] ^= 0x5A
+    open(tmp_path / "bad.gz", "wb").write(bytes(bad))
+    with pytest.raises(Exception):
+        nifti.read_bytes(tmp_path / "bad.gz", threads=4)
