@@ -215,6 +215,7 @@ def weight_blob_from_state_dict(geom: NetGeometry, sd: Dict[str, np.ndarray]) ->
     keys raise KeyError / ValueError (the loader must fail loudly on unexpected checkpoints)."""
     sd = {k[len("_orig_mod."):] if k.startswith("_orig_mod.") else k: v for k, v in sd.items()}
     out = []
+    used = set()
 
     def take(key, shape):
         if key not in sd:
@@ -222,6 +223,7 @@ def weight_blob_from_state_dict(geom: NetGeometry, sd: Dict[str, np.ndarray]) ->
         a = np.asarray(sd[key], dtype=np.float32)
         if tuple(a.shape) != tuple(shape):
             raise ValueError(f"{key}: shape {a.shape}, expected {tuple(shape)}")
+        used.add(key)
         out.append(a.reshape(-1))
 
     cin = geom.in_channels
@@ -250,7 +252,42 @@ def weight_blob_from_state_dict(geom: NetGeometry, sd: Dict[str, np.ndarray]) ->
     last = geom.n_stages - 2
     take(f"decoder.seg_layers.{last}.weight", (geom.num_classes, geom.features[0], 1, 1, 1))
     take(f"decoder.seg_layers.{last}.bias", (geom.num_classes,))
+    _check_leftover_keys(sd, used, last)
     return np.ascontiguousarray(np.concatenate(out), dtype=np.float32)
+
+
+def _check_leftover_keys(sd: Dict[str, np.ndarray], used: set, last_seg: int) -> None:
+    """Every key the blob did not consume must be one the upstream PlainConvUNet is known to save IN ADDITION (module aliases of
+    the same tensors, the deep-supervision heads of the coarser decoder levels) -- and an alias must hold the same numbers as the
+    tensor it aliases.  Anything else means the checkpoint is not the architecture the plans describe: fail loudly
+    (the key names are upstream knowledge, unpinned in the reference tree).
+      encoder.stages.S.0.convs.I.all_modules.{0,1}.*   = ...convs.I.{conv,norm}.*   (nn.Sequential view of ConvDropoutNormReLU)
+      decoder.stages.K.convs.I.all_modules.{0,1}.*     likewise
+      decoder.encoder.*                                = encoder.*                  (the decoder keeps a reference to the encoder)
+      decoder.seg_layers.K.* for K != last             deep-supervision heads, unused at inference
+      *.num_batches_tracked / running_mean / running_var  never present for InstanceNorm(track_running_stats=False): rejected"""
+    import re
+
+    def same(a, b):
+        return a in sd and b in sd and np.asarray(sd[a]).shape == np.asarray(sd[b]).shape and np.array_equal(sd[a], sd[b])
+
+    for key in sd:
+        if key in used:
+            continue
+        base = key[len("decoder."):] if key.startswith("decoder.encoder.") else key
+        m = re.match(r"^(.*\.convs\.\d+)\.all_modules\.([01])\.(weight|bias)$", base)
+        if m:
+            base = f"{m.group(1)}.{'conv' if m.group(2) == '0' else 'norm'}.{m.group(3)}"
+        if base != key:
+            if base not in used:
+                raise ValueError(f"unexpected checkpoint key {key!r} (aliases {base!r}, which the architecture does not have)")
+            if base not in sd or not same(key, base):
+                raise ValueError(f"checkpoint key {key!r} should alias {base!r} but holds different values")
+            continue
+        m = re.match(r"^decoder\.seg_layers\.(\d+)\.(weight|bias)$", key)
+        if m and int(m.group(1)) != last_seg:
+            continue
+        raise ValueError(f"unexpected checkpoint key {key!r}: not part of the PlainConvUNet the plans describe")
 
 
 def synthetic_plans(patch=(128, 128, 128), features=(32, 64, 128, 256, 320, 320), num_classes=25, in_channels=1,
@@ -288,6 +325,33 @@ def synthetic_plans(patch=(128, 128, 128), features=(32, 64, 128, 256, 320, 320)
                "labels": {"background": 0, **{f"class_{i}": i for i in range(1, num_classes)}},
                "file_ending": ".nii.gz", "numTraining": 0}
     return plans, dataset
+
+
+def legacy_plans_from(plans: dict, dataset_json: dict, configuration: str = "3d_fullres"):
+    """The same model in the OLDER nnU-Net plans / dataset.json format (tests, model-folder fixtures): the keys
+    plans_handler.py:36-97 reconstructs the architecture from (`UNet_class_name`, `UNet_base_num_features`,
+    `unet_max_num_features`, `n_conv_per_stage_encoder` / `_decoder`, `conv_kernel_sizes`, `pool_op_kernel_sizes`,
+    `num_pool_per_axis`), `foreground_intensity_properties_by_modality` and dataset.json's `modality`
+    (plans_handler.py:275-283, label_handling / predict_from_raw_data.py:76).  Only geometries whose feature counts follow
+    min(base * 2^i, max) can be written that way."""
+    import copy
+    pj, dj = copy.deepcopy(plans), copy.deepcopy(dataset_json)
+    cfg = pj["configurations"][configuration]
+    kw = cfg.pop("architecture")["arch_kwargs"]
+    feats = list(kw["features_per_stage"])
+    base, cap = feats[0], max(feats)
+    if feats != [min(base * 2 ** i, cap) for i in range(len(feats))]:
+        raise ValueError(f"features {feats} cannot be expressed in the legacy plans format")
+    strides = [list(s) for s in kw["strides"]]
+    cfg.update({"UNet_class_name": "PlainConvUNet", "UNet_base_num_features": base, "unet_max_num_features": cap,
+                "n_conv_per_stage_encoder": list(kw["n_conv_per_stage"]), "n_conv_per_stage_decoder": list(kw["n_conv_per_stage_decoder"]),
+                "conv_kernel_sizes": [list(k) for k in kw["kernel_sizes"]], "pool_op_kernel_sizes": strides,
+                "num_pool_per_axis": [sum(1 for s in strides if s[a] > 1) for a in range(3)]})
+    if "foreground_intensity_properties_per_channel" in pj:
+        pj["foreground_intensity_properties_by_modality"] = pj.pop("foreground_intensity_properties_per_channel")
+    if "channel_names" in dj:
+        dj["modality"] = dj.pop("channel_names")
+    return pj, dj
 
 
 def synthetic_state_dict(geom: NetGeometry, seed: int = 0) -> Dict[str, np.ndarray]:

@@ -215,3 +215,44 @@ def test_remove_outside_of_mask_vs_scipy():
         want = seg.copy()
         want[ndimage.binary_dilation(mask, iterations=addon) == 0] = 0
         np.testing.assert_array_equal(remove_outside_of_mask(get_context("gpu"), seg, mask, addon), want)
+
+
+def test_compute_all_models_with_legacy_plans_and_upstream_checkpoint_keys(tmp_path, monkeypatch):
+    """model folders as the real weight archives ship them -- plans.json in the OLD nnU-Net format
+    (`UNet_class_name`, `conv_kernel_sizes`, `pool_op_kernel_sizes`, ...: plans_handler.py:36-97), dataset.json with `modality`,
+    checkpoints that carry upstream's alias keys (`...all_modules.N.*`, `decoder.encoder.*`), the deep-supervision heads and a
+    torch.compile prefix -- through `compute_all_models(["total"])`: the label file must equal the one computed from plain
+    folders holding the same weights."""
+    from test_host_cpu import _upstream_checkpoint_keys
+    from boa_hip import label_maps, model_store, nifti, plans
+    from boa_hip.compute.inference import compute_all_models
+    from boa_hip.synthetic import ct_phantom
+    roots = {"plain": tmp_path / "plain", "upstream": tmp_path / "upstream"}
+    for tid, nc in zip(label_maps.PART_TASK_IDS, (25, 27, 19, 24, 27)):
+        pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64, 128), num_classes=nc)
+        geom = plans.model_config_from_plans(pj, dj).geometry
+        sd = plans.synthetic_state_dict(geom, seed=tid)
+        model_store.write_model_folder(str(roots["plain"]), tid, f"TotalSegmentator_part{tid - 290}", "nnUNetTrainerNoMirroring", pj, dj, [sd])
+        lj, ldj = plans.legacy_plans_from(pj, dj)
+        model_store.write_model_folder(str(roots["upstream"]), tid, f"TotalSegmentator_part{tid - 290}", "nnUNetTrainerNoMirroring", lj, ldj,
+                                       [_upstream_checkpoint_keys(sd, geom.n_stages)])
+    ct = ct_phantom((44, 40, 52), seed=8)
+    aff = np.diag([1.5, 1.5, 1.5, 1.0])
+    nifti.save(tmp_path / "ct.nii.gz", ct, aff)
+    params = {"preview": False, "fast": False, "ml": True, "nr_thr_resamp": 1, "nr_thr_saving": 1, "quiet": True,
+              "verbose": False, "device": "gpu", "license_number": None}
+    labels = {}
+    for kind, root in roots.items():
+        monkeypatch.setenv("nnUNet_results", str(root))
+        compute_all_models(tmp_path / "ct.nii.gz", tmp_path / kind, ["total"], params)
+        labels[kind] = nifti.load(tmp_path / kind / "total.nii.gz")[0]
+    assert len(np.unique(labels["plain"])) > 5
+    np.testing.assert_array_equal(labels["upstream"], labels["plain"])
+    # a checkpoint with a key the architecture does not have is refused, not silently truncated
+    import torch
+    pth = next((roots["upstream"]).glob("Dataset291_*/*/fold_0/checkpoint_final.pth"))
+    ck = torch.load(pth, map_location="cpu", weights_only=False)
+    ck["network_weights"]["_orig_mod.encoder.stages.0.0.convs.0.norm.running_mean"] = torch.zeros(32)
+    torch.save(ck, pth)
+    with pytest.raises(ValueError, match="unexpected checkpoint key"):
+        compute_all_models(tmp_path / "ct.nii.gz", tmp_path / "bad", ["total"], params)

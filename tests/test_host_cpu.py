@@ -401,3 +401,57 @@ def test_nifti_indexed_gzip_members_parallel_read(tmp_path):
     open(tmp_path / "bad.gz", "wb").write(bytes(bad))
     with pytest.raises(Exception):
         nifti.read_bytes(tmp_path / "bad.gz", threads=4)
+
+
+def _upstream_checkpoint_keys(sd, n_stages):
+    """The key set a real dynamic_network_architectures PlainConvUNet checkpoint carries on top of the canonical names: the
+    nn.Sequential aliases of every conv block, the decoder's reference to the encoder, the deep-supervision heads."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if ".convs." in k and (".conv." in k or ".norm." in k):
+            out[k.replace(".conv.", ".all_modules.0.").replace(".norm.", ".all_modules.1.")] = v
+    for k, v in list(out.items()):
+        if k.startswith("encoder."):
+            out["decoder." + k] = v
+    last = n_stages - 2
+    w, b = sd[f"decoder.seg_layers.{last}.weight"], sd[f"decoder.seg_layers.{last}.bias"]
+    for lvl in range(last):                                   # coarser deep-supervision heads (other input widths upstream; unused)
+        out[f"decoder.seg_layers.{lvl}.weight"] = np.zeros((w.shape[0], 7, 1, 1, 1), np.float32)
+        out[f"decoder.seg_layers.{lvl}.bias"] = np.zeros_like(b)
+    return {("_orig_mod." + k): v for k, v in out.items()}    # torch.compile prefix (predict_from_raw_data.py:95-98 strips it)
+
+
+def test_loader_accepts_upstream_alias_keys_and_rejects_unknown_ones():
+    from boa_hip import plans
+    pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64, 128), num_classes=5)
+    geom = plans.model_config_from_plans(pj, dj).geometry
+    sd = plans.synthetic_state_dict(geom, 3)
+    want = plans.weight_blob_from_state_dict(geom, sd)
+    full = _upstream_checkpoint_keys(sd, geom.n_stages)
+    assert len(full) > 2 * len(sd)
+    np.testing.assert_array_equal(plans.weight_blob_from_state_dict(geom, full), want)
+    bad = dict(full)
+    bad["_orig_mod.encoder.stages.0.0.convs.0.all_modules.0.weight"] = bad["_orig_mod.encoder.stages.0.0.convs.0.all_modules.0.weight"] + 1
+    with pytest.raises(ValueError, match="alias"):
+        plans.weight_blob_from_state_dict(geom, bad)
+    for extra in ("encoder.stages.0.0.convs.0.norm.running_mean", "decoder.stages.0.convs.5.conv.weight", "some.other.module.weight"):
+        bad = dict(sd)
+        bad[extra] = np.zeros(3, np.float32)
+        with pytest.raises(ValueError, match="unexpected checkpoint key"):
+            plans.weight_blob_from_state_dict(geom, bad)
+    missing = {k: v for k, v in sd.items() if k != "decoder.transpconvs.0.bias"}
+    with pytest.raises(KeyError):
+        plans.weight_blob_from_state_dict(geom, missing)
+
+
+def test_legacy_plans_format_gives_the_same_geometry():
+    """plans.json of the older nnU-Net format (UNet_class_name / conv_kernel_sizes / pool_op_kernel_sizes / modality /
+    foreground_intensity_properties_by_modality: plans_handler.py:36-97 reconstructs the architecture from them) -> the same
+    ModelConfig as the new `architecture.arch_kwargs` form."""
+    from boa_hip import plans
+    pj, dj = plans.synthetic_plans(patch=(32, 48, 40), features=(32, 64, 128, 256), num_classes=7, spacing=(3.0, 1.5, 1.5))
+    new = plans.model_config_from_plans(pj, dj)
+    lj, ldj = plans.legacy_plans_from(pj, dj)
+    assert "architecture" not in lj["configurations"]["3d_fullres"] and "channel_names" not in ldj
+    old = plans.model_config_from_plans(lj, ldj)
+    assert old.geometry == new.geometry and old.spacing == new.spacing and old.intensity_properties == new.intensity_properties
