@@ -328,7 +328,11 @@ def main():
     comm = None
     if dist is not None and args.shard != "volumes":
         from boa_hip import tile_shard as ts
-        comm = ts.ShardComm(dist, rank, world, f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+        if args.backend == "nccl":     # RCCL through the C ABI: collectives on the engine's communication stream (boa_hip/rccl.py)
+            from boa_hip.rccl import RcclComm
+            comm = RcclComm(ctx, rank, world)
+        else:                          # gloo: host-staged slabs (validation of the protocol with several ranks on one GPU)
+            comm = ts.ShardComm(dist, rank, world, "cpu")
         for t in tasks:
             if args.shard == "tiles":
                 t.shard = ts.TileShard(comm, args.shard_mode)

@@ -104,6 +104,17 @@ _PROTOS = {
     "boa_resample_nearest_u8": (i32, [vp, vp, ip, vp, ip]),
     "boa_resize_skimage_f32": (i32, [vp, vp, ip, vp, ip, i32, i32]),
     "boa_resize_logits_argmax": (i32, [vp, vp, i32, ip, ip, ip, ip, i32, vp, i32, vp]),
+    "boa_comm_available": (i32, []),
+    "boa_comm_library": (C.c_char_p, []),
+    "boa_comm_unique_id": (i32, [vp]),
+    "boa_comm_create": (i32, [vp, i32, i32, vp, C.POINTER(vp)]),
+    "boa_comm_destroy": (None, [vp]),
+    "boa_comm_wait": (i32, [vp]),
+    "boa_comm_exchange": (i32, [vp, i32, C.POINTER(vp), C.POINTER(u64), i32, i32, C.POINTER(vp), C.POINTER(u64), i32]),
+    "boa_comm_shift_slab": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, ip, vp]),
+    "boa_comm_all_reduce": (i32, [vp, vp, u64, i32]),
+    "boa_comm_stats": (i32, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "boa_add_f16_planes": (i32, [vp, vp, vp, vp, i32, ip, i32, i32]),
 }
 
 EXPORTS = sorted(_PROTOS)

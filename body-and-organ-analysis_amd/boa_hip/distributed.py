@@ -5,9 +5,11 @@ independent in the reference (one CT per process, TS/python_api.py:54-72), so ra
 collective exists; the only communication is the timing barrier / max-reduce of bench.py and the gather of small result
 tables.  The two granularities that share ONE volume between the ranks live in `tile_shard.py`: the part models dealt out
 to the ranks (label volumes all-reduced), and the tile rows of the sliding window split across the ranks with the overlap
-slabs of the fp16 accumulators exchanged over RCCL (`TileShard`, exact hand-over or pairwise all-reduce); the z-slab
-sharding of the aggregation stages is in `agg_shard.py`.  torch.distributed is used for the collectives only; the C ABI
-stays free of torch types (device pointers cross as integers).
+slabs of the fp16 accumulators exchanged over RCCL (`TileShard`, exact hand-over or pairwise sum); the z-slab sharding of the
+aggregation stages is in `agg_shard.py`.  The data-path collectives of the shared-volume modes are issued by the C library itself
+(`rccl.RcclComm` -> csrc/comm.hip: RCCL on the engine's communication stream); torch.distributed carries the control plane only
+-- the bench's barrier and max-over-ranks, the 128-byte RCCL id, pickled host tables -- and the gloo transport
+(`tile_shard.ShardComm`) that lets several ranks share one GPU for validation.
 """
 from __future__ import annotations
 
@@ -34,8 +36,10 @@ def init(backend: str, rank: int, world: int, local_rank: int = 0):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if backend == "nccl":
+        # device tensors over RCCL, host tensors / pickled objects (the small tables of agg_shard.AggComm, the RCCL id of
+        # rccl.RcclComm) over gloo: one process group that dispatches on the tensor's device
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     return dist

@@ -297,77 +297,18 @@ class HipPredictor:
         return True
 
     def _predict_segmentation_sharded(self, dvol, V, labels_out, lut, merge, work, shard, resample_to=None):
-        from . import tile_shard as ts
-        PV, below = sw.pad_amounts(V, self.geom.patch_size)
-        origins = sw.get_sliding_window_origins(PV, self.geom.patch_size, self.tile_step_size)
-        plan = ts.plan_rows(origins, self.geom.patch_size[0], PV[0], shard.comm.world)
-        C_, nvox, nv = self.geom.num_classes, int(np.prod(PV)), int(np.prod(V))
-        nf = len(self.list_of_parameters)
-        own = work is None
-        work = work if work is not None else {}
+        job = self.begin_segmentation_sharded(dvol, V, labels_out, lut, merge, work, shard, resample_to)
+        job.finish()
 
-        def buf(name, nbytes):
-            b = work.get(name)
-            if b is None or b.nbytes < nbytes:
-                if b is not None:
-                    b.free()
-                b = self.ctx.alloc(nbytes)
-                work[name] = b
-            return b
-
-        acc, nacc = buf("acc", C_ * nvox * 2), buf("n", nvox * 2)
-        fold = buf("fold", C_ * nvox * 2) if nf > 1 else None
-        part = buf("part", nv)
-        flag = buf("flag", 4)
-        flag.zero()
-        check(self.lib.boa_memset(self.ctx.h, part.vp, 0, nv), "boa_memset")
-        lut_arr = None
-        if lut is not None:
-            lut_arr = np.zeros(256, dtype=np.uint8)
-            lut_arr[:len(lut)] = lut
-        crop = any(b != 0 for b in below) or list(PV) != list(V)
-        direct = resample_to is None
-        lo = hi = 0
-        for f in range(nf):
-            self._ensure_net(f)
-            eng = ts.HipShardEngine(self, shard.comm, dvol, V, PV, below, origins, acc, nacc)
-            try:
-                lo, hi = ts.run_fold_sharded(eng, plan, shard.comm, shard.mode)
-            finally:
-                eng.close()
-            last = f == nf - 1
-            # (resampled path: keep the normalised fold-mean logits of the owned planes -- in `acc` for one fold, in `fold` otherwise)
-            check(self.lib.boa_finalize_labels_planes(
-                self.ctx.h, acc.vp, nacc.vp, C_, int3(PV), fold.vp if fold else None, 0 if f == 0 else 1,
-                nf if (last and fold) else 0, 0 if (direct or fold) else 1, lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None,
-                0, part.vp if (last and direct) else None, int3(below) if crop else None, int3(V) if crop else None, flag.vp, lo, hi),
-                "boa_finalize_labels_planes")
-        bad = int(flag.download((1,), np.int32)[0])
-        import torch
-        if direct:
-            ts.all_reduce_labels(self.ctx, shard.comm, part, nv)
-        else:
-            # nnU-Net resamples the logits (order 1) before the argmax: every rank needs all planes -> sum the plane-disjoint logits
-            # over the ranks, then the same fused resize + argmax as on one GPU (identical labels on every rank)
-            out_dims, slice_axis = resample_to
-            logits = fold if fold else acc
-            ts.all_reduce_logit_planes(self.ctx, shard.comm, logits, C_, PV, lo, hi)
-        t = torch.tensor([bad], dtype=torch.int32, device=shard.comm.device)
-        shard.comm.all_reduce_sum(t)
-        if int(t.item()):
-            raise RuntimeError("Encountered inf in predicted array. Aborting...")
-        if not direct:
-            check(self.lib.boa_resize_logits_argmax(self.ctx.h, logits.vp, C_, int3(PV), int3(below), int3(V), int3(out_dims), int(slice_axis),
-                                                    lut_arr.ctypes.data_as(C.c_void_p) if lut_arr is not None else None, 1 if merge else 0,
-                                                    labels_out.vp), "boa_resize_logits_argmax")
-        elif merge:
-            check(self.lib.boa_label_overlay(self.ctx.h, part.vp, nv, labels_out.vp), "boa_label_overlay")
-        else:
-            one, st = (C.c_int * 3)(1, 1, nv), (C.c_longlong * 3)(0, 0, 1)
-            check(self.lib.boa_copy3(self.ctx.h, part.vp, 0, 0, st, one, labels_out.vp, 0, 0, st), "boa_copy3")
-        if own:
-            for b in work.values():
-                b.free()
+    def begin_segmentation_sharded(self, dvol, V, labels_out, lut, merge, work, shard, resample_to=None, after_first_start=None):
+        """Shared-volume prediction in two halves (tile_shard.start_fold_sharded / finish_fold_sharded): this call runs the tiles
+        of every fold and queues the slab exchanges; the returned job's `finish()` applies what arrived, reduces the owned planes
+        to labels and merges the ranks' label planes.  A multi-model task calls `begin` of model k + 1 before `finish` of model k
+        (`after_first_start`: called once this model's first fold is queued -- the previous model's finish), so that with the RCCL
+        transport the exchange of model k runs under the tiles of model k + 1.  The accumulators alternate between two slots."""
+        job = _ShardedJob(self, dvol, V, labels_out, lut, merge, work, shard, resample_to)
+        job.begin(after_first_start)
+        return job
 
     def predict_segmentation(self, input_image: np.ndarray, lut: Optional[np.ndarray] = None) -> np.ndarray:
         V = list(input_image.shape[1:])
@@ -379,3 +320,109 @@ class HipPredictor:
         finally:
             dvol.free()
             lab.free()
+
+
+class _ShardedJob:
+    """One model (all folds) of a volume that several ranks share; see HipPredictor.begin_segmentation_sharded."""
+
+    def __init__(self, pred: HipPredictor, dvol, V, labels_out, lut, merge, work, shard, resample_to):
+        from . import tile_shard as ts
+        self.ts, self.p, self.ctx, self.lib = ts, pred, pred.ctx, pred.lib
+        self.dvol, self.V, self.labels_out, self.merge, self.shard, self.resample_to = dvol, list(V), labels_out, merge, shard, resample_to
+        self.own = work is None
+        self.work = work if work is not None else {}
+        self.PV, self.below = sw.pad_amounts(self.V, pred.geom.patch_size)
+        self.origins = sw.get_sliding_window_origins(self.PV, pred.geom.patch_size, pred.tile_step_size)
+        self.plan = ts.plan_rows(self.origins, pred.geom.patch_size[0], self.PV[0], shard.comm.world,
+                                 assignment=getattr(shard, "assignment", None))
+        self.C_, self.nvox, self.nv = pred.geom.num_classes, int(np.prod(self.PV)), int(np.prod(self.V))
+        self.nf = len(pred.list_of_parameters)
+        self.lut_arr = None
+        if lut is not None:
+            self.lut_arr = np.zeros(256, dtype=np.uint8)
+            self.lut_arr[:len(lut)] = lut
+        self.crop = any(b != 0 for b in self.below) or list(self.PV) != list(self.V)
+        self.direct = resample_to is None
+        self.pending = None
+        self.lo = self.hi = 0
+        self.done = False
+
+    def _buf(self, name, nbytes):
+        b = self.work.get(name)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            b = self.ctx.alloc(nbytes)
+            self.work[name] = b
+        return b
+
+    def _lut_p(self):
+        return self.lut_arr.ctypes.data_as(C.c_void_p) if self.lut_arr is not None else None
+
+    def begin(self, after_first_start=None):
+        job_slot = self.work.get("_job", 0) & 1
+        self.work["_job"] = self.work.get("_job", 0) + 1
+        self.flag = self._buf(f"flag{job_slot}", 4)
+        self.flag.zero()
+        self.fold = self._buf("fold", self.C_ * self.nvox * 2) if self.nf > 1 else None
+        self.part = self._buf("part", self.nv)
+        for f in range(self.nf):
+            self.p._ensure_net(f)
+            slot = self.work.get("_seq", 0) & 1            # two accumulator sets: the one whose exchange is in flight and the one being filled
+            self.work["_seq"] = self.work.get("_seq", 0) + 1
+            acc, nacc = self._buf(f"acc{slot}", self.C_ * self.nvox * 2), self._buf(f"n{slot}", self.nvox * 2)
+            eng = self.ts.HipShardEngine(self.p, self.shard.comm, self.dvol, self.V, self.PV, self.below, self.origins, acc, nacc)
+            state = self.ts.start_fold_sharded(eng, self.plan, self.shard.comm, self.shard.mode)
+            if f == 0 and after_first_start is not None:
+                after_first_start()
+            if self.pending is not None:
+                self._finish_fold(*self.pending)
+            self.pending = (f, eng, state)
+
+    def _finish_fold(self, f, eng, state):
+        try:
+            self.lo, self.hi = self.ts.finish_fold_sharded(state)
+        finally:
+            eng.close()
+        last = f == self.nf - 1
+        fold, direct = self.fold, self.direct
+        # (resampled path: keep the normalised fold-mean logits of the owned planes -- in the accumulators for one fold, in `fold` otherwise)
+        check(self.lib.boa_finalize_labels_planes(
+            self.ctx.h, eng.acc.vp, eng.nacc.vp, self.C_, int3(self.PV), fold.vp if fold else None, 0 if f == 0 else 1,
+            self.nf if (last and fold) else 0, 0 if (direct or fold) else 1, self._lut_p(), 0, self.part.vp if (last and direct) else None,
+            int3(self.below) if self.crop else None, int3(self.V) if self.crop else None, self.flag.vp, self.lo, self.hi),
+            "boa_finalize_labels_planes")
+        self.logits = fold if fold else eng.acc
+
+    def finish(self):
+        if self.done:
+            return
+        self.done = True
+        ts, comm, nv = self.ts, self.shard.comm, self.nv
+        check(self.lib.boa_memset(self.ctx.h, self.part.vp, 0, nv), "boa_memset")
+        if self.pending is not None:
+            self._finish_fold(*self.pending)
+            self.pending = None
+        if self.direct:
+            ts.all_reduce_labels(self.ctx, comm, self.part, nv)
+        else:
+            # nnU-Net resamples the logits (order 1) before the argmax: every rank needs all planes -> sum the plane-disjoint logits
+            # over the ranks, then the same fused resize + argmax as on one GPU (identical labels on every rank)
+            out_dims, slice_axis = self.resample_to
+            ts.all_reduce_logit_planes(self.ctx, comm, self.logits, self.C_, self.PV, self.lo, self.hi)
+        if ts.all_reduce_flag(self.ctx, comm, self.flag):
+            raise RuntimeError("Encountered inf in predicted array. Aborting...")
+        if not self.direct:
+            check(self.lib.boa_resize_logits_argmax(self.ctx.h, self.logits.vp, self.C_, int3(self.PV), int3(self.below), int3(self.V), int3(out_dims),
+                                                    int(slice_axis), self._lut_p(), 1 if self.merge else 0, self.labels_out.vp),
+                  "boa_resize_logits_argmax")
+        elif self.merge:
+            check(self.lib.boa_label_overlay(self.ctx.h, self.part.vp, nv, self.labels_out.vp), "boa_label_overlay")
+        else:
+            one, st = (C.c_int * 3)(1, 1, nv), (C.c_longlong * 3)(0, 0, 1)
+            check(self.lib.boa_copy3(self.ctx.h, self.part.vp, 0, 0, st, one, self.labels_out.vp, 0, 0, st), "boa_copy3")
+        if self.own:
+            for b in self.work.values():
+                if hasattr(b, "free"):
+                    b.free()
+

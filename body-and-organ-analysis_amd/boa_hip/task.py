@@ -113,7 +113,7 @@ class SegmentationTask:
     def close(self):
         for _, _, p, _ in self.parts:
             p.close()
-        for b in self._work.values():
+        for b in [v for v in self._work.values() if hasattr(v, "free")]:
             b.free()
         self._work = {}
 
@@ -133,8 +133,55 @@ class SegmentationTask:
         d_labels.zero()
         if self.model_shard is not None and self.model_shard.world > 1 and self.multimodel:
             return self._predict_zyx_model_sharded(d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx)
+        if self.shard is not None and self.shard.comm.world > 1 and self.multimodel and len(self.parts) > 1 and self._units_applicable(shape, spacing_zyx):
+            return self._predict_zyx_unit_sharded(d_ct, shape, d_labels, in_dtype, n)
         for k in range(len(self.parts)):
             self._run_model(k, d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx, merge=self.multimodel, shard=self.shard)
+
+    # ---- (row x model) units: all ranks busy on one multi-model volume ---------------------------------------------------------
+    def _units_applicable(self, shape, spacing_zyx) -> bool:
+        """Every model runs on the array as it is (no plan-spacing resampling: that path all-reduces whole logit volumes)."""
+        if spacing_zyx is None:
+            return True
+        return all(nr.compute_new_shape(shape, spacing_zyx, cfg.spacing) == list(shape) for _, cfg, _, _ in self.parts)
+
+    def _predict_zyx_unit_sharded(self, d_ct, shape, d_labels, in_dtype, n):
+        """The part models of a multi-model task are independent until the label merge (TS/nnunet.py:542-556), so the work units of a
+        shared volume are (model, tile row) pairs: tile_shard.plan_units cuts the model-major unit list into one contiguous run
+        per rank (512^3 `total`: 5 x 5 units -> 3-4 per rank on 8 GPUs, where tile rows alone keep 5 busy).  A model's rows then
+        live on a subset of the ranks, which exchange that model's overlap slabs; every rank takes part in the label all-reduce.
+        The models are software-pipelined: model k + 1's tiles are queued before model k's exchange is waited for, every model
+        with its own normalised copy of the CT (the models have different intensity properties).  Labels are bit-identical to
+        the one-GPU run in `exact` mode: per model the accumulation order is the reference's, the merge order is the part order."""
+        import dataclasses
+        from . import sliding_window as sw
+        ctx, world = self.ctx, self.shard.comm.world
+        rows, weights = [], []
+        for _, cfg, p, _ in self.parts:
+            PV, _b = sw.pad_amounts(list(shape), p.geom.patch_size)
+            o = sw.get_sliding_window_origins(PV, p.geom.patch_size, p.tile_step_size)
+            r = len(set(int(v) for v in o[:, 0]))
+            rows.append(r)
+            weights.append(len(o) / r)
+        from .tile_shard import plan_units
+        units = plan_units(rows, world, weights)
+        prev = None
+        for k in range(len(self.parts)):
+            task_id, cfg, p, lut = self.parts[k]
+            vol = self._work.get(f"vol{k & 1}")
+            if vol is None or vol.nbytes < n * 4:
+                if vol is not None:
+                    vol.free()
+                vol = self._work[f"vol{k & 1}"] = ctx.alloc(n * 4)
+            ip = cfg.intensity_properties["0"]
+            check(ctx.lib.boa_ct_normalize(ctx.h, d_ct.vp, in_dtype, vol.vp, n, ip["mean"], ip["std"], ip["percentile_00_5"],
+                                           ip["percentile_99_5"]), "boa_ct_normalize")
+            shard_k = dataclasses.replace(self.shard, assignment=units[k])
+            job = p.begin_segmentation_sharded(vol, list(shape), d_labels, lut, True, self._work, shard_k,
+                                               after_first_start=(prev.finish if prev is not None else None))
+            prev = job
+        if prev is not None:
+            prev.finish()
 
     def _run_model(self, k, d_ct, shape, d_out, in_dtype, vol, n, spacing_zyx, merge, shard):
         """One model of the task on the resident array: CTNormalization with the model's own intensity properties

@@ -41,24 +41,36 @@ from ._lib import check, int3
 @dataclass
 class RowPlan:
     rows: List[int]                    # sorted axis-0 tile starts
-    blocks: List[Tuple[int, int]]      # per active rank: row indices [b0, b1)
+    blocks: List[Tuple[int, int]]      # per active block: row indices [b0, b1)
     patch0: int
     pv0: int
     row_of_tile: np.ndarray            # [n_tiles] row index of every tile (canonical order)
+    ranks: Optional[List[int]] = None  # global rank that owns block i (default: rank i) -- (row x model) units put the blocks of
+                                       # one model on a subset of the ranks (plan_units)
+
+    def __post_init__(self):
+        if self.ranks is None:
+            self.ranks = list(range(len(self.blocks)))
+        assert len(self.ranks) == len(self.blocks) and len(set(self.ranks)) == len(self.ranks)
 
     @property
     def active(self) -> int:
         return len(self.blocks)
 
+    def index(self, rank: int) -> Optional[int]:
+        """Block index of global rank `rank`, None when the rank has no tiles of this model."""
+        return self.ranks.index(rank) if rank in self.ranks else None
+
     def tiles(self, rank: int) -> np.ndarray:
         """Indices (canonical order kept) of the tiles of `rank`."""
-        if rank >= self.active:
+        i = self.index(rank)
+        if i is None:
             return np.zeros(0, dtype=np.int64)
-        b0, b1 = self.blocks[rank]
+        b0, b1 = self.blocks[i]
         return np.nonzero((self.row_of_tile >= b0) & (self.row_of_tile < b1))[0]
 
     def boundary(self, k: int) -> Optional[Tuple[int, int]]:
-        """Planes [lo, hi) shared by rank k (its last row) and rank k+1 (its first row); None if they do not overlap."""
+        """Planes [lo, hi) shared by block k (its last row) and block k+1 (its first row); None if they do not overlap."""
         if k < 0 or k + 1 >= self.active:
             return None
         first_upper = self.blocks[k + 1][0]
@@ -67,10 +79,11 @@ class RowPlan:
 
     def owned_planes(self, rank: int) -> Tuple[int, int]:
         """Planes whose sums are complete on `rank` after the exchange (a partition of [0, pv0))."""
-        if rank >= self.active:
+        i = self.index(rank)
+        if i is None:
             return (0, 0)
-        lo = 0 if rank == 0 else self.rows[self.blocks[rank][0]]
-        hi = self.pv0 if rank == self.active - 1 else self.rows[self.blocks[rank + 1][0]]
+        lo = 0 if i == 0 else self.rows[self.blocks[i][0]]
+        hi = self.pv0 if i == self.active - 1 else self.rows[self.blocks[i + 1][0]]
         return (lo, hi)
 
     def defer_planes(self, rank: int) -> np.ndarray:
@@ -78,21 +91,42 @@ class RowPlan:
         the tile below the end of the lower rank's last row (normally only the first row of the block reaches it)."""
         t = self.tiles(rank)
         out = np.zeros(len(t), dtype=np.int32)
-        b = self.boundary(rank - 1)
+        i = self.index(rank)
+        b = self.boundary(i - 1) if i is not None else None
         if b is not None:
             starts = np.asarray(self.rows)[self.row_of_tile[t]]
             out[:] = np.clip(b[1] - starts, 0, self.patch0)
         return out
 
 
-def plan_rows(origins: np.ndarray, patch0: int, pv0: int, world: int) -> RowPlan:
+def _two_apart_ok(rows, blocks, patch0) -> bool:
+    # blocks two apart must not overlap: then the slab a rank sends up never contains planes it deferred itself
+    return all(rows[blocks[i][1] - 1] + patch0 <= rows[blocks[i + 2][0]] for i in range(len(blocks) - 2))
+
+
+def plan_rows(origins: np.ndarray, patch0: int, pv0: int, world: int, assignment: Optional[Sequence[Tuple[int, int]]] = None) -> RowPlan:
     """Contiguous, balanced blocks of tile rows for at most `world` ranks.  The number of active ranks is reduced until
-    blocks two apart do not overlap (small volumes, where the actual step can fall to 0.4 * patch)."""
+    blocks two apart do not overlap (small volumes, where the actual step can fall to 0.4 * patch).
+    `assignment` = [(global rank, number of rows), ...] in row order (plan_units): those blocks on those ranks; when they violate
+    the two-apart rule the rows are re-balanced over the same ranks (fewer of them if need be)."""
     origins = np.asarray(origins).reshape(-1, 3)
     rows = sorted(set(int(v) for v in origins[:, 0]))
     row_of_tile = np.searchsorted(np.asarray(rows), origins[:, 0]).astype(np.int64)
     if np.any(np.diff(row_of_tile) < 0):
         raise ValueError("tile origins must be in canonical (axis 0 outermost) order")
+    rank_ids = None
+    if assignment is not None:
+        assignment = [(int(r), int(c)) for r, c in assignment if int(c) > 0]
+        if sum(c for _, c in assignment) != len(rows):
+            raise ValueError(f"row assignment {assignment} does not cover the {len(rows)} tile rows")
+        blocks, lo = [], 0
+        for _, c in assignment:
+            blocks.append((lo, lo + c))
+            lo += c
+        rank_ids = [r for r, _ in assignment]
+        if _two_apart_ok(rows, blocks, patch0):
+            return RowPlan(rows, blocks, int(patch0), int(pv0), row_of_tile, rank_ids)
+        world = len(rank_ids)
     for a in range(max(1, min(world, len(rows))), 0, -1):
         q, r = divmod(len(rows), a)
         blocks, lo = [], 0
@@ -100,10 +134,34 @@ def plan_rows(origins: np.ndarray, patch0: int, pv0: int, world: int) -> RowPlan
             hi = lo + q + (1 if i < r else 0)
             blocks.append((lo, hi))
             lo = hi
-        # blocks two apart must not overlap: then the slab a rank sends up never contains planes it deferred itself
-        if all(rows[blocks[i][1] - 1] + patch0 <= rows[blocks[i + 2][0]] for i in range(a - 2)):
-            return RowPlan(rows, blocks, int(patch0), int(pv0), row_of_tile)
+        if _two_apart_ok(rows, blocks, patch0):
+            return RowPlan(rows, blocks, int(patch0), int(pv0), row_of_tile, None if rank_ids is None else rank_ids[:a])
     raise AssertionError("unreachable: one block is always valid")
+
+
+def plan_units(rows_per_model: Sequence[int], world: int, weights: Optional[Sequence[float]] = None) -> List[List[Tuple[int, int]]]:
+    """(row x model) work units of a multi-model task (the five part models of `total` are independent until the label merge,
+    TS/nnunet.py:542-556): the units -- tile row j of model m, model-major order -- are cut into `world` contiguous runs of
+    near-equal weight (weight of a unit = `weights[m]`, e.g. its tiles per row; default 1).  -> per model the
+    [(rank, number of its rows), ...] blocks in row order: plan_rows(..., assignment=that).  A 512^3 `total` volume has
+    5 x 5 units: tile rows alone keep 5 of 8 ranks busy, units all 8 (3-4 units each)."""
+    rows_per_model = [int(v) for v in rows_per_model]
+    w = [1.0] * len(rows_per_model) if weights is None else [float(v) for v in weights]
+    total = sum(r * wm for r, wm in zip(rows_per_model, w))
+    out: List[List[Tuple[int, int]]] = []
+    cum = 0.0
+    for m, n_rows in enumerate(rows_per_model):
+        blocks: List[Tuple[int, int]] = []
+        for _ in range(n_rows):
+            # the rank whose share [r, r + 1) * total / world holds the unit's centre: monotone in the unit index -> contiguous runs
+            r = min(world - 1, int((cum + 0.5 * w[m]) * world / total)) if total > 0 else 0
+            cum += w[m]
+            if blocks and blocks[-1][0] == r:
+                blocks[-1] = (r, blocks[-1][1] + 1)
+            else:
+                blocks.append((r, 1))
+        out.append(blocks)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------- transport
@@ -127,27 +185,20 @@ class ShardComm:
             import torch
             torch.cuda.synchronize()
 
-    def shift_up(self, send, recv):
-        """send -> rank+1, recv <- rank-1 (either may be None); every boundary moves at the same time."""
+    def shift(self, send, dst, recv, src):
+        """send -> rank `dst`, recv <- rank `src` (either side may be None); every boundary moves at the same time."""
         ops = []
         if send is not None:
-            ops.append(self.dist.P2POp(self.dist.isend, send, self.rank + 1))
+            ops.append(self.dist.P2POp(self.dist.isend, send, int(dst)))
         if recv is not None:
-            ops.append(self.dist.P2POp(self.dist.irecv, recv, self.rank - 1))
+            ops.append(self.dist.P2POp(self.dist.irecv, recv, int(src)))
         if ops:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
             self._done()
 
-    def pair_group(self, k: int):
-        """Group of ranks {k, k+1}; created collectively (every rank creates every pair, in the same order)."""
-        if self._pairs is None:
-            self._pairs = [self.dist.new_group([i, i + 1]) for i in range(self.world - 1)]
-        return self._pairs[k]
-
-    def pair_all_reduce(self, k: int, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.pair_group(k))
-        self._done()
+    def shift_up(self, send, recv):
+        self.shift(send, self.rank + 1, recv, self.rank - 1)
 
     def all_reduce_sum(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
@@ -161,44 +212,70 @@ class ShardComm:
 
 
 # ---------------------------------------------------------------------------------------------------- protocol
-def run_fold_sharded(engine, plan: RowPlan, comm: ShardComm, mode: str = "exact") -> Tuple[int, int]:
-    """One fold of one model on this rank.  Engine interface:
+def _exchange_via_tensors(engine, comm, dst, upper, src, lower, add: bool):
+    """Default slab exchange of an engine without its own `exchange`: pack -> shift -> unpack (exact hand-over) or add."""
+    send = engine.pack(*upper) if upper else None
+    recv = engine.empty(*lower) if lower else None
+    if hasattr(comm, "shift"):
+        comm.shift(send, dst, recv, src)
+    else:                                    # (rank +- 1 neighbours only)
+        comm.shift_up(send, recv)
+    if lower:
+        if add:      # P + Q with one RTNE rounding per element: what a two-rank fp16 sum all-reduce leaves on the slab's owner
+            cur = engine.pack(*lower)
+            recv = (cur.float() + recv.float()).to(cur.dtype)
+        engine.unpack(lower[0], lower[1], recv)
+    return None
+
+
+def start_fold_sharded(engine, plan: RowPlan, comm, mode: str = "exact"):
+    """First half of one fold of one model on this rank: zero the accumulators, run this rank's tiles, QUEUE the slab exchange
+    with the neighbouring blocks' ranks.  With the RCCL transport (RcclComm + HipShardEngine) nothing here waits: the exchange runs
+    on the communication stream while the caller queues the next model's tiles; `finish_fold_sharded` orders the rest behind it.
+    Engine interface:
          begin()                         zero the accumulators
          run(tile_idx, defer) -> stash   forward + accumulate this rank's tiles; `defer[i]` leading planes kept back
          pack(lo, hi) -> tensor          planes [lo, hi) of (acc channels..., n) as one fp16 tensor on comm.device
          empty(lo, hi) -> tensor         receive buffer of the same shape
          unpack(lo, hi, tensor)          overwrite those planes
          apply(stash)                    add the kept planes in tile order
-       Returns the planes this rank owns afterwards."""
+         exchange(comm, dst, upper, src, lower, add) -> token     (optional) the engine's own transport of the slabs
+         complete(token)                 (with exchange) make later engine work wait for the exchange; add the received sums"""
     if mode not in ("exact", "allreduce"):
         raise ValueError(f"unknown tile-shard mode {mode!r}")
-    r = comm.rank
-    if mode == "allreduce" and comm.world > 1:
-        comm.pair_group(0)  # collective creation, also on idle ranks
     engine.begin()
-    if r >= plan.active:
-        return (0, 0)
-    tiles = plan.tiles(r)
-    lower, upper = plan.boundary(r - 1), plan.boundary(r)
-    if mode == "exact":
-        stash = engine.run(tiles, plan.defer_planes(r))
-        send = engine.pack(*upper) if upper else None
-        recv = engine.empty(*lower) if lower else None
-        comm.shift_up(send, recv)
-        if lower:
-            engine.unpack(lower[0], lower[1], recv)
-        engine.apply(stash)
+    i = plan.index(comm.rank)
+    if i is None:
+        return None
+    exact = mode == "exact"
+    tiles = plan.tiles(comm.rank)
+    lower, upper = plan.boundary(i - 1), plan.boundary(i)
+    dst = plan.ranks[i + 1] if upper else None
+    src = plan.ranks[i - 1] if lower else None
+    stash = engine.run(tiles, plan.defer_planes(comm.rank) if exact else np.zeros(len(tiles), dtype=np.int32))
+    if hasattr(engine, "exchange"):
+        token = engine.exchange(comm, dst, upper, src, lower, not exact)
     else:
-        engine.run(tiles, np.zeros(len(tiles), dtype=np.int32))
-        for parity in (0, 1):                     # a rank sits in at most one boundary of each parity
-            for k, slab in ((r - 1, lower), (r, upper)):
-                if slab is None or k % 2 != parity:
-                    continue
-                t = engine.pack(*slab)
-                comm.pair_all_reduce(k, t)
-                if k == r - 1:                     # the upper rank owns the slab
-                    engine.unpack(slab[0], slab[1], t)
-    return plan.owned_planes(r)
+        token = _exchange_via_tensors(engine, comm, dst, upper, src, lower, not exact)
+    return (engine, plan, comm, exact, stash, token)
+
+
+def finish_fold_sharded(state) -> Tuple[int, int]:
+    """Second half: the received partial sums are in place (exact) / added (allreduce), the kept planes are applied in tile
+    order.  Returns the planes this rank owns afterwards."""
+    if state is None:
+        return (0, 0)
+    engine, plan, comm, exact, stash, token = state
+    if hasattr(engine, "complete"):
+        engine.complete(token)
+    if exact:
+        engine.apply(stash)
+    return plan.owned_planes(comm.rank)
+
+
+def run_fold_sharded(engine, plan: RowPlan, comm, mode: str = "exact") -> Tuple[int, int]:
+    """One fold of one model on this rank, both halves back to back."""
+    return finish_fold_sharded(start_fold_sharded(engine, plan, comm, mode))
 
 
 # ---------------------------------------------------------------------------------------------------- product engine
@@ -305,17 +382,43 @@ class HipShardEngine:
             st.upload(t.view(torch.int16).numpy())
             self._move(lo, hi, st, False)
 
+    # ---- RCCL transport (boa_hip/rccl.py): the slabs go straight out of / into the accumulator planes, on the C library's
+    #      communication stream; nothing here waits, `complete` orders the later kernels behind the exchange ---------------------
+    def exchange(self, comm, dst, upper, src, lower, add: bool):
+        if not hasattr(comm, "shift_slab"):
+            return _exchange_via_tensors(self, comm, dst, upper, src, lower, add)
+        if upper is None and lower is None:
+            return ("rccl", comm, None, None)
+        stage = None
+        if add and lower is not None:     # pairwise fp16 sum: the lower block's sums land in a staging buffer and are added in `complete`
+            stage = self.ctx.alloc((self.C + 1) * (lower[1] - lower[0]) * self.PV[1] * self.PV[2] * 2)
+        comm.shift_slab(dst if upper else None, upper, src if lower else None, lower, self.acc, self.nacc, self.C, self.PV, stage)
+        return ("rccl", comm, stage, lower)
+
+    def complete(self, token):
+        if not token or token[0] != "rccl":
+            return
+        _, comm, stage, lower = token
+        comm.wait()
+        if stage is not None:
+            check(self.lib.boa_add_f16_planes(self.ctx.h, self.acc.vp, self.nacc.vp, stage.vp, self.C, int3(self.PV), int(lower[0]), int(lower[1])),
+                  "boa_add_f16_planes")
+            stage.free()
+
     def close(self):
         if self._stage is not None:
             self._stage.free()
             self._stage = None
 
 
-def all_reduce_labels(ctx, comm: ShardComm, buf, n: int):
+def all_reduce_labels(ctx, comm, buf, n: int):
     """Sum of uint8 label volumes with disjoint supports, in place in the device buffer `buf` (n voxels)."""
-    import torch
     if comm.world == 1:
         return
+    if hasattr(comm, "shift_slab"):       # RcclComm: in place, on the communication stream
+        comm.all_reduce(buf, n, 0)
+        return
+    import torch
     if comm.on_device:
         comm.make_room(ctx)
         t = comm.empty((n,), torch.uint8)
@@ -338,7 +441,6 @@ def all_reduce_logit_planes(ctx, comm: ShardComm, buf, C_: int, PV, lo: int, hi:
     sliding window after the normalisation).  The other planes are cleared and the buffers summed over the ranks (disjoint
     supports: x + 0 is exact in fp16), so every rank ends with the complete logits -- needed when nnU-Net resamples the logits
     before the argmax (export_prediction.py:25-33), which reads across plane ownership."""
-    import torch
     if comm.world == 1:
         return
     plane = int(PV[1]) * int(PV[2])
@@ -350,6 +452,10 @@ def all_reduce_logit_planes(ctx, comm: ShardComm, buf, C_: int, PV, lo: int, hi:
         if hi < PV[0]:
             check(ctx.lib.boa_memset(ctx.h, C.c_void_p(base + 2 * hi * plane), 0, 2 * (int(PV[0]) - hi) * plane), "boa_memset")
     n = C_ * vox
+    if hasattr(comm, "shift_slab"):       # RcclComm: fp16 sum in place (x + 0 is exact)
+        comm.all_reduce(buf, n, 1)
+        return
+    import torch
     if comm.on_device:
         # one class plane set at a time: boa_copy3 takes 32-bit extents (25 classes x a 333 x 333 x 1000 volume would wrap), and the
         # staging tensor is one class, not the whole logit volume
@@ -374,6 +480,23 @@ def all_reduce_logit_planes(ctx, comm: ShardComm, buf, C_: int, PV, lo: int, hi:
 
 @dataclass
 class TileShard:
-    """What `HipPredictor.predict_segmentation_device(..., shard=...)` needs: the transport and the exchange mode."""
-    comm: ShardComm
+    """What `HipPredictor.predict_segmentation_device(..., shard=...)` needs: the transport (ShardComm over torch.distributed, or
+    rccl.RcclComm over the C ABI), the exchange mode and -- per model of a multi-model task -- the row assignment of plan_units."""
+    comm: object
     mode: str = "exact"
+    assignment: Optional[list] = None
+
+
+def all_reduce_flag(ctx, comm, flag_buf) -> int:
+    """Sum of the per-rank inf flags (a device int32) over the ranks -> host int."""
+    if comm.world > 1 and hasattr(comm, "shift_slab"):
+        comm.all_reduce(flag_buf, 1, 2)
+        return int(flag_buf.download((1,), np.int32)[0])
+    bad = int(flag_buf.download((1,), np.int32)[0])
+    if comm.world == 1:
+        return bad
+    import torch
+    t = torch.tensor([bad], dtype=torch.int32, device=comm.device)
+    comm.all_reduce_sum(t)
+    return int(t.item())
+

@@ -962,6 +962,11 @@ extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume
 struct boa_stash {
     boa_ctx* ctx = nullptr;
     unsigned char* arena = nullptr;
+    // head weights of the weight set that produced the stashed activations: the stash may be applied after the network has
+    // switched to the next fold's weights (the exchange of fold f overlaps the tiles of fold f + 1); the sets are cached device
+    // arenas (boa_net::wsets), so the pointers outlive the switch
+    const float* head_w = nullptr;
+    const float* head_b = nullptr;
     struct Item {
         size_t act_off, ss_off;
         int planes;
@@ -999,6 +1004,8 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
     const size_t esz = (f32 || x3) ? 4 : 2;
     boa_stash* st = new boa_stash;
     st->ctx = net->ctx;
+    st->head_w = net->head_w;
+    st->head_b = net->head_b;
     size_t bytes = 0;
     for (int i = 0; i < n_tiles; ++i) {
         int dp = host_defer_planes[i];
@@ -1077,19 +1084,19 @@ extern "C" int boa_net_apply_deferred(boa_net* net, const boa_stash* st, const u
         int P[3] = {it.planes, d.patch[1], d.patch[2]};
         if (net->precision == 1)
             BOA_TRY(launch_head_f32(net->ctx, (const float*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
-                                    d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
+                                    d.features[0], P, d.num_classes, st->head_w, st->head_b, d.lrelu_slope, nullptr, dev_gauss,
                                     dev_acc, dev_n, PV, it.start));
         else if (net->precision == 2 && d.features[0] == 32 && d.num_classes <= 32)
             BOA_TRY(launch_head_x3(net->ctx, (const float*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
-                                   d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
+                                   d.features[0], P, d.num_classes, st->head_w, st->head_b, d.lrelu_slope, nullptr, dev_gauss,
                                    dev_acc, dev_n, PV, it.start, (size_t)it.planes * d.patch[1] * d.patch[2]));
         else if (net->precision == 2)
             BOA_TRY(launch_head_f32(net->ctx, (const float*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
-                                    d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
+                                    d.features[0], P, d.num_classes, st->head_w, st->head_b, d.lrelu_slope, nullptr, dev_gauss,
                                     dev_acc, dev_n, PV, it.start, (size_t)it.planes * d.patch[1] * d.patch[2]));
         else
             BOA_TRY(launch_head(net->ctx, (const __half*)(st->arena + it.act_off), (const float*)(st->arena + it.ss_off),
-                                d.features[0], P, d.num_classes, net->head_w, net->head_b, d.lrelu_slope, nullptr, dev_gauss,
+                                d.features[0], P, d.num_classes, st->head_w, st->head_b, d.lrelu_slope, nullptr, dev_gauss,
                                 dev_acc, dev_n, PV, it.start, (size_t)it.planes * d.patch[1] * d.patch[2]));
     }
     return BOA_OK;

@@ -426,6 +426,40 @@ int boa_resize_logits_argmax(boa_ctx* ctx, const uint16_t* dev_logits, int C, co
                              const int* crop_dims, const int out_dims[3], int slice_axis, const uint8_t* host_lut, int merge,
                              uint8_t* dev_labels_out);
 
+/* ------------------------------------------------------------------ several GPUs on one volume (RCCL) -- */
+/* The tile-sharded sliding window (boa_hip/tile_shard.py): ranks own blocks of tile rows of the sliding window
+ * (NN/inference/predict_from_raw_data.py:523-558 orders the tiles axis 0 outermost; :611-614 adds them one after the other into
+ * fp16 buffers) and exchange the partial sums of the planes where two blocks overlap.  The reference has no counterpart (one
+ * device per process); these entry points carry its accumulate loop across devices.  RCCL is resolved at run time (dlopen;
+ * $BOA_RCCL_LIB overrides the search), collectives run on a communication stream of the boa_comm that is ordered against the
+ * context's compute stream by events: boa_comm_* calls queue work and return, boa_comm_wait makes LATER compute work wait for
+ * what has been queued (no host synchronisation anywhere).
+ *   boa_comm_unique_id : ncclGetUniqueId on one rank; the 128 bytes reach the other ranks out of band (launcher / store)
+ *   boa_comm_create    : ncclCommInitRank (collective over all ranks)
+ *   boa_comm_shift_slab: planes [send_lo, send_hi) of the C class planes of `acc` + of `nacc` (fp16 [.][PV0][PV1][PV2]: one
+ *                        contiguous run per class, sent in place) -> rank dst; planes [recv_lo, recv_hi) <- rank src, written in
+ *                        place (recv_stage NULL: the exact hand-over, the receiver has not added anything there yet) or into
+ *                        recv_stage [(C + 1)][planes][PV1 PV2] for boa_add_f16_planes (the pairwise fp16 sum).  dst / src < 0: none
+ *   boa_comm_exchange  : generic grouped send / recv of byte ranges (pieces matched in order)
+ *   boa_comm_all_reduce: in-place sum over all ranks; dtype 0 uint8, 1 fp16, 2 int32, 3 fp32 (label volumes with disjoint
+ *                        supports: TS/nnunet.py:553-556 merges the parts afterwards; inf flags; plane-disjoint logits) */
+typedef struct boa_comm boa_comm;
+int boa_comm_available(void);
+const char* boa_comm_library(void);
+int boa_comm_unique_id(unsigned char id_out[128]);
+int boa_comm_create(boa_ctx* ctx, int world, int rank, const unsigned char id[128], boa_comm** out);
+void boa_comm_destroy(boa_comm* comm);
+int boa_comm_wait(boa_comm* comm);
+int boa_comm_exchange(boa_comm* comm, int dst, const void* const* send_ptrs, const size_t* send_bytes, int n_send, int src,
+                      void* const* recv_ptrs, const size_t* recv_bytes, int n_recv);
+int boa_comm_shift_slab(boa_comm* comm, int dst, int send_lo, int send_hi, int src, int recv_lo, int recv_hi, uint16_t* dev_acc,
+                        uint16_t* dev_n, int C, const int PV[3], uint16_t* recv_stage);
+int boa_comm_all_reduce(boa_comm* comm, void* dev, size_t count, int dtype);
+int boa_comm_stats(boa_comm* comm, long long* calls, long long* bytes);
+/* acc[k][lo:hi] = half(float(acc[k][lo:hi]) + float(stage[k])), k = 0 .. C (C = the n plane): the owner's side of the pairwise
+ * fp16 sum of a slab ("allreduce" exchange mode) */
+int boa_add_f16_planes(boa_ctx* ctx, uint16_t* dev_acc, uint16_t* dev_n, const uint16_t* dev_stage, int C, const int PV[3], int lo, int hi);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,10 +95,11 @@ def _worker(rank, world, port, mode, q, backend="gloo"):
     from boa_hip import distributed as D
     from boa_hip import tile_shard as ts
     from boa_hip.device import Context
-    if backend == "nccl":           # RCCL: one GPU per rank, device tensors alias the engine's buffers
+    if backend == "nccl":           # RCCL: one GPU per rank; the slabs travel through the C ABI's communicator (boa_hip/rccl.py)
+        from boa_hip.rccl import RcclComm
         dist = D.init("nccl", rank, world, rank)
         ctx = Context(rank)
-        comm = ts.ShardComm(dist, rank, world, f"cuda:{rank}")
+        comm = RcclComm(ctx, rank, world)
     else:                           # gloo: the ranks share cuda:0, slabs are staged through the host
         dist = D.init("gloo", rank, world)
         ctx = Context(0)
@@ -273,6 +274,62 @@ def test_rccl_plumbing_single_rank(single):
         c.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_c_abi_single_rank_self_loop():
+    """The C ABI's RCCL transport (csrc/comm.hip) on hardware with one rank: communicator creation from a unique id, the slab
+    exchange as a self-loop (planes [6, 9) sent, received into planes [1, 4): in place, and through the staging buffer + the
+    fp16 add of the "allreduce" mode), the in-place all-reduce, and the event ordering between the compute stream and the
+    communication stream (work queued before / after an exchange sees consistent data without any host synchronisation in
+    between).  Two RCCL ranks cannot share one GPU; the multi-rank protocol is covered over gloo and -- when two devices are
+    visible -- by test_rccl_two_gpus_bit_identical."""
+    import ctypes as C
+    from boa_hip._lib import check, int3
+    from boa_hip.device import Context
+    from boa_hip.rccl import RcclComm
+    c = Context(0)
+    try:
+        comm = RcclComm(c, 0, 1, bcast=lambda b: b)
+        assert c.lib.boa_comm_library()
+        C_, PV = 3, (10, 6, 8)
+        plane = PV[1] * PV[2]
+        rng = np.random.default_rng(0)
+        acc_h = rng.normal(0, 3, size=(C_, *PV)).astype(np.float16)
+        n_h = rng.uniform(0.1, 4, size=PV).astype(np.float16)
+        acc, nacc = c.from_numpy(acc_h.view(np.uint16)), c.from_numpy(n_h.view(np.uint16))
+        # exact hand-over, in place
+        comm.shift_slab(0, (6, 9), 0, (1, 4), acc, nacc, C_, PV)
+        comm.wait()
+        want_a, want_n = acc_h.copy(), n_h.copy()
+        want_a[:, 1:4], want_n[1:4] = acc_h[:, 6:9], n_h[6:9]
+        np.testing.assert_array_equal(acc.download((C_, *PV), np.uint16), want_a.view(np.uint16))
+        np.testing.assert_array_equal(nacc.download(PV, np.uint16), want_n.view(np.uint16))
+        # pairwise sum: stage + add, with compute-stream work queued on both sides of the exchange and no host sync in between
+        stage = c.alloc((C_ + 1) * 3 * plane * 2)
+        check(c.lib.boa_memset(c.h, C.c_void_p(acc.ptr + 2 * (0 * PV[0] + 7) * plane), 0, 2 * plane))   # class 0, plane 7 := 0 BEFORE the send
+        comm.shift_slab(0, (6, 9), 0, (2, 5), acc, nacc, C_, PV, stage)
+        comm.wait()
+        check(c.lib.boa_add_f16_planes(c.h, acc.vp, nacc.vp, stage.vp, C_, int3(PV), 2, 5))
+        src_a, src_n = want_a.copy(), want_n.copy()
+        src_a[0, 7] = 0
+        exp_a, exp_n = src_a.copy(), src_n.copy()
+        exp_a[:, 2:5] = (src_a[:, 2:5].astype(np.float32) + src_a[:, 6:9].astype(np.float32)).astype(np.float16)
+        exp_n[2:5] = (src_n[2:5].astype(np.float32) + src_n[6:9].astype(np.float32)).astype(np.float16)
+        np.testing.assert_array_equal(acc.download((C_, *PV), np.uint16), exp_a.view(np.uint16))
+        np.testing.assert_array_equal(nacc.download(PV, np.uint16), exp_n.view(np.uint16))
+        # in-place all-reduce (one rank: identity) on the dtypes the protocol uses
+        lab = rng.integers(0, 255, size=5000, dtype=np.uint8)
+        d = c.from_numpy(lab)
+        comm.all_reduce(d, lab.size, 0)
+        np.testing.assert_array_equal(d.download(lab.shape, np.uint8), lab)
+        flag = c.from_numpy(np.array([7], np.int32))
+        comm.all_reduce(flag, 1, 2)
+        assert int(flag.download((1,), np.int32)[0]) == 7
+        st = comm.stats()
+        assert st["calls"] == 4 and st["bytes_sent_or_reduced"] >= 2 * (C_ + 1) * 3 * plane * 2
+        comm.close()
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("shard", ["tiles", "models"])

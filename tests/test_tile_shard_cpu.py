@@ -182,14 +182,11 @@ class _MailboxComm:
     def __init__(self, world):
         self.world, self.rank, self.box = world, 0, {}
 
-    def shift_up(self, send, recv):
+    def shift(self, send, dst, recv, src):
         if send is not None:
-            self.box[self.rank + 1] = send.clone()
+            self.box[(self.rank, dst)] = send.clone()
         if recv is not None:
-            recv.copy_(self.box.pop(self.rank))
-
-    def pair_group(self, k):
-        raise AssertionError("exact mode only")
+            recv.copy_(self.box.pop((src, self.rank)))
 
 
 def test_exact_protocol_random_geometries():
@@ -227,3 +224,131 @@ def test_exact_protocol_random_geometries():
                 np.testing.assert_array_equal(eng.n[lo:hi].view(np.uint16), single.n[lo:hi].view(np.uint16))
         assert covered == shape[0] and not comm.box
     assert seen_reduced > 0          # the plan had to give up ranks at least once
+
+
+# ------------------------------------------------------------------------------------------------ (row x model) units
+def test_plan_units_keeps_eight_ranks_busy_at_512():
+    """configs[1] / configs[3] geometry: 512^3, patch 128^3, step 0.8 -> 5 tile rows per part model, 5 part models.  Tile rows alone
+    give 5 active ranks of 8 (missing #2); (row x model) units give every rank 3-4 units, every unit exactly once,
+    contiguous blocks per model in ascending rank order."""
+    from boa_hip import sliding_window as sw
+    from boa_hip import tile_shard as ts
+    PV, _ = sw.pad_amounts([512, 512, 512], [128, 128, 128])
+    o = sw.get_sliding_window_origins(PV, [128, 128, 128], 0.8)
+    assert ts.plan_rows(o, 128, PV[0], 8).active == 5
+    for world in (1, 2, 3, 4, 5, 8, 16):
+        units = ts.plan_units([5] * 5, world)
+        load = np.zeros(world, int)
+        for blocks in units:
+            assert sum(c for _, c in blocks) == 5
+            rk = [r for r, _ in blocks]
+            assert rk == sorted(set(rk))                              # ascending, each rank one block per model
+            plan = ts.plan_rows(o, 128, PV[0], world, assignment=blocks)
+            assert plan.ranks == rk and plan.active == len(blocks)
+            tiles = np.concatenate([plan.tiles(r) for r in range(world)])
+            assert sorted(tiles.tolist()) == list(range(len(o)))
+            for r, c in blocks:
+                load[r] += c
+        assert load.sum() == 25
+        if world == 8:
+            assert (load > 0).all() and load.max() == 4 and load.min() == 3, load
+        if world <= 25:
+            assert load.max() - load.min() <= 1, (world, load)
+    # weights: models with more tiles per row count more
+    units = ts.plan_units([2, 8], 4, weights=[49.0, 25.0])
+    assert sum(c for _, c in units[0]) == 2 and sum(c for _, c in units[1]) == 8
+
+
+def test_unit_sharded_protocol_bit_identical_mailbox():
+    """Five models on the 5 x 5 x 5 tile grid of a 512^3 volume (scaled 1/8: 64^3, patch 16^3, step 0.8 -> the same tile starts / 8),
+    8 ranks, units from plan_units: per model the ranks of its blocks run the exact protocol; accumulators of every model are
+    bit-identical to the single-process loop on the planes each rank owns, and all 8 ranks do work."""
+    from boa_hip import tile_shard as ts
+    from oracle import sliding_window as osw
+    shape, patch, step, world, n_models = (64, 64, 64), (16, 16, 16), 0.8, 8, 5
+    origins = np.array([[s[0], s[1], s[2]] for s in osw.get_sliding_window_slicers(shape, patch, step)])
+    assert len(origins) == 125 and sorted(set(origins[:, 0])) == [0, 12, 24, 36, 48]
+    units = ts.plan_units([5] * n_models, world)
+    busy = set()
+    for m in range(n_models):
+        data = np.random.default_rng(100 + m).normal(0, 1.5, size=(1, *shape)).astype(np.float32)
+        single = NumpyEngine(data, origins, patch, HEADS)
+        single.begin()
+        single.run(range(len(origins)), [0] * len(origins))
+        plan = ts.plan_rows(origins, patch[0], shape[0], world, assignment=units[m])
+        comm = _MailboxComm(world)
+        covered = 0
+        for r in range(world):
+            comm.rank = r
+            eng = NumpyEngine(data, origins, patch, HEADS)
+            lo, hi = ts.run_fold_sharded(eng, plan, comm, "exact")
+            if hi:
+                busy.add(r)
+                assert lo == covered
+                covered = hi
+                np.testing.assert_array_equal(eng.acc[:, lo:hi].view(np.uint16), single.acc[:, lo:hi].view(np.uint16))
+                np.testing.assert_array_equal(eng.n[lo:hi].view(np.uint16), single.n[lo:hi].view(np.uint16))
+            else:
+                assert plan.index(r) is None
+        assert covered == shape[0] and not comm.box
+    assert busy == set(range(world))
+
+
+def _unit_worker(rank, world, port, q):
+    sys.path[:0] = [HERE, os.path.join(HERE, "body-and-organ-analysis_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from boa_hip import distributed as D
+    from boa_hip import tile_shard as ts
+    from oracle import sliding_window as osw
+    dist = D.init("gloo", rank, world)
+    shape, patch, step, n_models = (64, 32, 32), (16, 16, 16), 0.8, 5
+    origins = np.array([[s[0], s[1], s[2]] for s in osw.get_sliding_window_slicers(shape, patch, step)])
+    units = ts.plan_units([5] * n_models, world)
+    comm = ts.ShardComm(dist, rank, world, "cpu")
+    out = []
+    for m in range(n_models):
+        data = np.random.default_rng(100 + m).normal(0, 1.5, size=(1, *shape)).astype(np.float32)
+        plan = ts.plan_rows(origins, patch[0], shape[0], world, assignment=units[m])
+        eng = NumpyEngine(data, origins, patch, HEADS)
+        lo, hi = ts.run_fold_sharded(eng, plan, comm, "exact")
+        out.append((m, lo, hi, eng.acc[:, lo:hi].copy(), eng.n[lo:hi].copy()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unit_sharded_eight_ranks_over_gloo():
+    """The same over real processes: 8 gloo ranks, 5 models x 5 tile rows, neighbour-addressed send / recv between the ranks that
+    share a model."""
+    from oracle import sliding_window as osw
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    shape, patch, step = (64, 32, 32), (16, 16, 16), 0.8
+    origins = np.array([[s[0], s[1], s[2]] for s in osw.get_sliding_window_slicers(shape, patch, step)])
+    active = set()
+    for m in range(5):
+        data = np.random.default_rng(100 + m).normal(0, 1.5, size=(1, *shape)).astype(np.float32)
+        single = NumpyEngine(data, origins, patch, HEADS)
+        single.begin()
+        single.run(range(len(origins)), [0] * len(origins))
+        covered = 0
+        for r in range(world):
+            _, lo, hi, a, nn = got[r][m]
+            if hi:
+                active.add(r)
+                assert lo == covered
+                covered = hi
+                np.testing.assert_array_equal(a.view(np.uint16), single.acc[:, lo:hi].view(np.uint16))
+                np.testing.assert_array_equal(nn.view(np.uint16), single.n[lo:hi].view(np.uint16))
+        assert covered == shape[0]
+    assert active == set(range(world))
