@@ -733,11 +733,17 @@ struct FirstMfmaArgs {
     const float* vol;
     const int* origins;  // [N][3]
     int V0, V1, V2, o0, o1, o2, flip;
+    float* out32;        // X3: fp32 octet planes [N][4][voxel][8]
+    float wscale, winv;  // X3: power-of-two scale of the split weights
 };
 
+// X3 (split-precision mode): the fp32 input is staged as hi / lo fp16 halo tiles, a K step covers 8 taps ([Wh | Wh] x [Xh ; Xl] +
+// [Wl | Wl] x [Xh ; Xl], 4 steps = 8 MFMAs per 32 voxels), the epilogue stores fp32 octet planes (128 B per voxel: the kernel
+// stays store-bound).
+template <bool X3>
 __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
     constexpr int H0 = MF0 + 2, H1 = MF1 + 2, H2 = MF2 + 2, HV = H0 * H1 * H2;
-    __shared__ _Float16 halo[2][HV + 8];
+    __shared__ _Float16 halo[X3 ? 4 : 2][HV + 8];   // [buffer][X3: hi, lo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
     // A fragments: lane (cout = l31, kh) holds k = 8 kh + i (step 0) and 16 + 8 kh + i (step 1); taps >= 27 are zero
     f16x8 a0, a1;
@@ -747,11 +753,24 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
         a0[i] = (_Float16)p.w[k0 * 32 + l31];
         a1[i] = k1 < 27 ? (_Float16)p.w[k1 * 32 + l31] : (_Float16)0.f;
     }
+    f16x8 xah[X3 ? 4 : 1], xal[X3 ? 4 : 1];
+    if constexpr (X3) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 8 * st + i;
+                const float wv = k < 27 ? p.w[k * 32 + l31] * p.wscale : 0.f;
+                const _Float16 h = (_Float16)wv;
+                xah[st][i] = h;
+                xal[st][i] = (_Float16)(wv - (float)h);
+            }
+    }
     // MFMA column (lane l31) <-> voxel lv of the 32-voxel row: even lanes take voxels 0-15, odd lanes 16-31, so that after the
     // register transpose the lane pair (2m, 2m + 1) can exchange one 16-byte piece and ONE store instruction writes the complete
     // 32-byte records of voxels 0-15 (the next one 16-31): whole 64-byte lines per instruction in this write-bound kernel
     // (column = voxel made every instruction write bytes [0, 16) or [16, 32) of all 32 records)
-    const int lv = (l31 >> 1) + ((l31 & 1) << 4);
+    const int lv = X3 ? l31 : (l31 >> 1) + ((l31 & 1) << 4);   // (X3: column = voxel, 16-byte stores of a half-wave are 1 KiB contiguous)
     const bool odd = (l31 & 1) != 0;
     // LDS offsets (in halves) of this lane's 16 taps relative to the M-tile's first halo voxel
     int toff[16];
@@ -760,6 +779,14 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
         int t = (i < 8 ? 8 * kh + i : 16 + 8 * kh + (i - 8));
         t = t < 27 ? t : 26;  // padded taps: any finite value (their weights are zero)
         toff[i] = ((t / 9) * H1 + (t / 3) % 3) * H2 + t % 3 + lv;
+    }
+    int xoff[X3 ? 32 : 1];   // X3: taps 8 st + i for both k-halves (the k-half selects the hi / lo tile)
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int t = i < 27 ? i : 26;
+            xoff[i] = ((t / 9) * H1 + (t / 3) % 3) * H2 + t % 3 + lv;
+        }
     }
     float4 bq[4];
 #pragma unroll
@@ -892,7 +919,15 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
 #pragma unroll
         for (int j = 0; j < NPRE; ++j) {
             const int i = tid + 256 * j;
-            if (i < HV) halo[buf][i] = (_Float16)pre[j];
+            if constexpr (X3) {
+                if (i < HV) {
+                    const _Float16 h = (_Float16)pre[j];
+                    halo[2 * buf][i] = h;
+                    halo[2 * buf + 1][i] = (_Float16)(pre[j] - (float)h);
+                }
+            } else {
+                if (i < HV) halo[buf][i] = (_Float16)pre[j];
+            }
         }
     };
     Seq cur = seq_first();
@@ -918,28 +953,41 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
             st_n = n;
             slot = cur.j * 4 + wave;
         }
-        const _Float16* hb = halo[buf];
+        const _Float16* hb = X3 ? halo[2 * buf + kh] : halo[buf];
 #pragma unroll 2
         for (int r = 0; r < (MF0 * MF1) / 4; ++r) {
             const int row = wave * ((MF0 * MF1) / 4) + r;  // (x, y) row of the block tile
             const int x = row / MF1, y = row % MF1;
             const _Float16* hr = hb + (x * H1 + y) * H2;
-            f16x8 b0, b1;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                b0[i] = hr[toff[i]];
-                b1[i] = hr[toff[8 + i]];
-            }
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+            f32x16 acc;
+            if constexpr (X3) {
+                acc = zero;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    f16x8 b;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) b[i] = hr[xoff[8 * st + i]];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xah[st], b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xal[st], b, acc, 0, 0, 0);
+                }
+            } else {
+                f16x8 b0, b1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    b0[i] = hr[toff[i]];
+                    b1[i] = hr[toff[8 + i]];
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, zero, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+            }
             float v[16];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                v[gq * 4 + 0] = acc[gq * 4 + 0] + bq[gq].x;
-                v[gq * 4 + 1] = acc[gq * 4 + 1] + bq[gq].y;
-                v[gq * 4 + 2] = acc[gq * 4 + 2] + bq[gq].z;
-                v[gq * 4 + 3] = acc[gq * 4 + 3] + bq[gq].w;
+                v[gq * 4 + 0] = (X3 ? acc[gq * 4 + 0] * p.winv : acc[gq * 4 + 0]) + bq[gq].x;
+                v[gq * 4 + 1] = (X3 ? acc[gq * 4 + 1] * p.winv : acc[gq * 4 + 1]) + bq[gq].y;
+                v[gq * 4 + 2] = (X3 ? acc[gq * 4 + 2] * p.winv : acc[gq * 4 + 2]) + bq[gq].z;
+                v[gq * 4 + 3] = (X3 ? acc[gq * 4 + 3] * p.winv : acc[gq * 4 + 3]) + bq[gq].w;
             }
             // packed fp32 statistics (v_pk_add_f32 / v_pk_fma_f32: the same operations per entry, two entries per instruction)
 #pragma unroll
@@ -951,6 +999,13 @@ __global__ __launch_bounds__(256) void k_conv_first_mfma(FirstMfmaArgs p) {
                 q2 = __builtin_elementwise_fma(vv, vv, q2);
                 st_s[2 * i] = s2.x; st_s[2 * i + 1] = s2.y;
                 st_q[2 * i] = q2.x; st_q[2 * i + 1] = q2.y;
+            }
+            if constexpr (X3) {
+                // fp32 octet planes [N][4][voxel][8]: entries 4 gq .. + 3 = couts 8 gq + 4 kh .. + 3 of voxel l31
+                float* dst32 = p.out32 + ((size_t)n * 32 * ovox + (((size_t)(tx * MF0 + x) * p.P1 + ty * MF1 + y) * p.P2 + tz * MF2 + l31) * 8) + 4 * kh;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) *(float4*)(dst32 + (size_t)gq * 8 * ovox) = make_float4(v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]);
+                continue;
             }
             unsigned w8[8];
 #pragma unroll
@@ -1027,7 +1082,7 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
     const double vox = (double)N * P[0] * P[1] * P[2];
     KernelTimer tm(ctx, BOA_K_CONV_FIRST, 2.0 * vox * k[0] * k[1] * k[2] * Cin * Cout, vox * (4.0 * Cin + 2.0 * Cout));
     static const bool fuse_gather = !(getenv("BOA_FIRST_GATHER") && atoi(getenv("BOA_FIRST_GATHER")) == 1);  // 1: separate gather kernel
-    const bool fused = !out32 && fuse_gather && first_mfma_ok(Cin, P, k, Cout);
+    const bool fused = fuse_gather && first_mfma_ok(Cin, P, k, Cout);
     if (!fused)
     hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)((pvol + 255) / 256), Cin, N), dim3(256), 0, ctx->stream, volume,
                        dev_origins, V[0], V[1], V[2], vol_off ? vol_off[0] : 0, vol_off ? vol_off[1] : 0,
@@ -1035,8 +1090,11 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
                        PD[1], PD[2], flip_mask, padded_scratch);
     const int nblk_tab = conv_first_nblk(P, ctx->cu_count);
     if (nblk_out) *nblk_out = nblk_tab;
-    if (!out32 && first_mfma_ok(Cin, P, k, Cout)) {
+    if (first_mfma_ok(Cin, P, k, Cout)) {
         FirstMfmaArgs m;
+        m.out32 = out32;
+        m.wscale = X3_HEAD_WSCALE;   // (first-conv weights are O(0.1 .. 1) like the head's: one fixed power of two)
+        m.winv = 1.0f / X3_HEAD_WSCALE;
         m.padded = padded_scratch; m.PX = PD[0]; m.PY = PD[1]; m.PZ = PD[2];
         m.vol = fused ? volume : nullptr; m.origins = dev_origins; m.flip = flip_mask;
         m.V0 = V[0]; m.V1 = V[1]; m.V2 = V[2];
@@ -1048,9 +1106,14 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
         // (physical workgroup b runs the virtual workgroups b, b + G, ...: any G gives the same results; more than one workgroup
         //  per CU hides the halo gather's and the stores' latency -- the kernel is a 3.4 GB write per 25 tiles)
         static const int grid_mult = getenv("BOA_FIRST_GRID") ? std::max(1, atoi(getenv("BOA_FIRST_GRID"))) : 4;
-        hipLaunchKernelGGL(k_conv_first_mfma, dim3((unsigned)std::min<long long>((long long)m.vw * N, (long long)ctx->cu_count * grid_mult)),
-                           dim3(256), 0, ctx->stream, m);
-        ctx->counters[BOA_CNT_FIRST_MFMA]++;
+        const dim3 fgrid((unsigned)std::min<long long>((long long)m.vw * N, (long long)ctx->cu_count * grid_mult));
+        if (out32) {
+            hipLaunchKernelGGL(k_conv_first_mfma<true>, fgrid, dim3(256), 0, ctx->stream, m);
+            ctx->counters[BOA_CNT_X3]++;
+        } else {
+            hipLaunchKernelGGL(k_conv_first_mfma<false>, fgrid, dim3(256), 0, ctx->stream, m);
+            ctx->counters[BOA_CNT_FIRST_MFMA]++;
+        }
         tm.stop();
         BOA_HIP_TRY(hipGetLastError());
         return BOA_OK;

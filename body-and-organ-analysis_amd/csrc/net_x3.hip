@@ -8,6 +8,8 @@
 // into the consumer as in the fp16 mode (y = lrelu(fma(x, scale, shift)) in fp32), its statistics come from the conv epilogue's
 // fp32 partial sums reduced in fp64 (k_norm_finalize).  The 3x3x3 convs are k_conv_ws<..., X3> (conv_ws.hip); this file holds the
 // rest of the stack: transposed conv, 1x1x1 head (scatter form), layout helpers.
+#include <algorithm>
+
 #include "conv.h"
 
 namespace {
@@ -90,7 +92,9 @@ __global__ __launch_bounds__(256) void k_convt_x3(X3ConvTArgs p) {
     const int taps = p.s0 * p.s1 * p.s2, nco = p.Cout / 32;
     const int Ho = p.Hi * p.s1, Wo = p.Wi * p.s2;
     const size_t vout = (size_t)vin * taps;
-    for (int pair = wave; pair < taps * nco; pair += 4) {
+    // (small inputs: the (tap, cout chunk) pairs are spread over gridDim.z blocks that stage the same voxels -- the 4^3 / 8^3 layers
+    //  have 2-16 voxel groups per tile and ~100 pairs of 3 MB of weights to stream: one block per group left 240 CUs idle)
+    for (int pair = wave + 4 * (int)blockIdx.z; pair < taps * nco; pair += 4 * (int)gridDim.z) {
         const int tap = pair / nco, co0 = (pair - tap * nco) * 32;
         const int tz = tap % p.s2, ty = (tap / p.s2) % p.s1, tx = tap / (p.s2 * p.s1);
         f32x16 acc[MT];
@@ -251,7 +255,10 @@ int launch_convt_x3(boa_ctx* ctx, const float* src, const float* ss, int Cin, in
     static bool once = (hipFuncSetAttribute((const void*)k_convt_x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                         hipFuncSetAttribute((const void*)k_convt_x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
-    const dim3 grid((unsigned)((vin + 32 * MT - 1) / (32 * MT)), N);
+    const unsigned gx = (unsigned)((vin + 32 * MT - 1) / (32 * MT));
+    const int pairs = taps * (Cout / 32);
+    const int gz = std::max(1, std::min((pairs + 3) / 4, (int)(1024 / std::max(1u, gx * (unsigned)N))));
+    const dim3 grid(gx, N, gz);
     if (MT == 2)
         hipLaunchKernelGGL(k_convt_x3<2>, grid, dim3(256), lds, ctx->stream, a);
     else
