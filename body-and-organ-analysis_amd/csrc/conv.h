@@ -141,7 +141,7 @@ int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, con
 bool conv_ns_applicable(const ConvGeom& g);
 void conv_ns_tile(const ConvGeom& g, ConvTile* t);
 int conv_ns_ncy(int Cout);
-int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double flops, double bytes);
+int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, double flops, double bytes, bool x3 = false);
 
 // ---- fp32 "exact" mode (net_f32.hip): channels-last fp32 activations, weights [tap][Cin][Cout] fp32 -------------------
 int launch_conv_f32(boa_ctx* ctx, const float* src0, const float* ss0, int C0, const float* src1, const float* ss1, int C1, int N,

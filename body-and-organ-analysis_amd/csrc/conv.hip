@@ -130,8 +130,9 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out, bool x3) {
     const int ncc = x3 ? g.Cin / 8 : g.Cin / 16;   // split-precision mode: 8 real channels per staged chunk, two MFMAs per tap
     double best_cost = 1e30;
     bool found = false;
-    const int force = x3 ? 1 : conv_variant_override();
-    if (!x3 && force < 0 && conv_ns_applicable(g)) {  // N-split kernel (conv_ns.hip): stride-2 and deep layers, fixed tile shape
+    const int force = x3 ? -1 : conv_variant_override();
+    // (split-precision mode: the stride-2 layers take the N-split kernel too -- its stride-1 instantiation is not built for X3)
+    if (force < 0 && conv_ns_applicable(g) && !(x3 && g.s[0] != 2) && !(x3 && getenv("BOA_X3_NO_NS"))) {  // N-split kernel (conv_ns.hip): stride-2 and deep layers, fixed tile shape
         conv_ns_tile(g, out);
         return true;
     }
@@ -146,7 +147,7 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out, bool x3) {
             if (!relax && (w1 > next_pow2(dims[1]) || w0 > next_pow2(dims[0]))) continue;
             const int w[3] = {w0, w1, w2};
             for (int variant : {1, 0}) {
-                if (force >= 0 && variant != force) continue;
+                if ((force >= 0 && variant != force) || (x3 && variant != 1)) continue;
                 for (int R : {4, 2, 1}) {
                     const int M = 4 * R;
                     for (int b0 = 1; b0 <= M; b0 *= 2)
@@ -487,7 +488,7 @@ int launch_conv_x3(boa_ctx* ctx, const float* src0, const float* ss0, int C0, co
                    float* partials) {
     BOA_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && C0 > 0, "conv_x3: input channels (%d,%d) must be multiples of 8", C0, C1);
     BOA_REQUIRE(g.Cout % 32 == 0, "conv_x3: Cout=%d must be a multiple of 32", g.Cout);
-    BOA_REQUIRE(t.variant == 1, "conv_x3: tile variant %d", t.variant);
+    BOA_REQUIRE(t.variant == 1 || t.variant == 2, "conv_x3: tile variant %d", t.variant);
     ConvArgs a;
     a.src0 = (const __half*)src0; a.src1 = (const __half*)src1; a.ss0 = ss0; a.ss1 = ss1; a.C0 = 2 * C0; a.C1 = 2 * C1;
     a.ss16_0 = (const unsigned*)ss0; a.ss16_1 = (const unsigned*)ss1;   // read as 16 fp32 words per 8-channel chunk
@@ -504,6 +505,7 @@ int launch_conv_x3(boa_ctx* ctx, const float* src0, const float* ss0, int C0, co
     const double vox = (double)g.N * g.Do * g.Ho * g.Wo;
     const double flops = 2.0 * vox * taps * (C0 + C1) * g.Cout;
     const double bytes = 4.0 * ((double)g.N * g.Di * g.Hi * g.Wi * (C0 + C1) + vox * g.Cout);
+    if (t.variant == 2) return launch_conv_ns(ctx, a, t, flops, bytes, true);
     return launch_conv_ws(ctx, a, t, flops, bytes, true);
 }
 

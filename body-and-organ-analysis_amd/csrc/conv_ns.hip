@@ -27,11 +27,14 @@
 // packed weights (wave-uniform base); vcur / vnext: this lane's byte offset of (chunk, tap 0) of this and of the following
 // chunk for the wave's cout chunk (always valid: the last chunk of the last tile prefetches a dummy); gs: bytes per tap.
 // The accumulators enter a tile's first chunk holding the bias.
-template <int S, int RM>
-__device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16 (&acc)[RM], f16x8 (&a)[3][3],
-                                                const WS_GLOBAL unsigned char* wb, unsigned vcur, unsigned vnext, unsigned gs) {
+// X3 (split-precision mode, see k_conv_ws): the chunk is 8 fp32 channels as hi / lo fp16 planes, the weight fragments come in
+// hi / lo pairs (lo = `lo_off` bytes behind hi in the packed array: the part stride Cout * 16) and every (plane, dx) pair is two MFMAs.
+template <int S, int RM, bool X3>
+__device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16 (&acc)[RM], f16x8 (&a)[3][3], f16x8 (&al)[X3 ? 3 : 1][3],
+                                                const WS_GLOBAL unsigned char* wb, unsigned vcur, unsigned vnext, unsigned gs, unsigned lo_off) {
     constexpr int NB = S * (RM - 1) + 3;
     constexpr int H1 = 3 * S + 3, H2 = 7 * S + 3;
+    constexpr int MM = X3 ? 2 : 1;
     f16x8 b[NB];
     auto fetch_a = [&](unsigned vchunk, int g, int slot) {  // group g = dy * 3 + dz: taps g + 9 dx
 #pragma unroll
@@ -39,6 +42,11 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
             unsigned vo = __umul24((unsigned)(g + 9 * dx), gs) + vchunk;
             asm volatile("" : "+v"(vo));  // keep the 32 -> 64 bit extension in this block: scalar-base load form
             a[slot][dx] = *(const WS_GLOBAL f16x8*)(wb + vo);
+            if constexpr (X3) {
+                unsigned vl = vo + lo_off;
+                asm volatile("" : "+v"(vl));
+                al[slot][dx] = *(const WS_GLOBAL f16x8*)(wb + vl);
+            }
         }
     };
 #pragma unroll
@@ -51,7 +59,7 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
             fetch_a(vcur, g + 2, (g + 2) % 3);
         else
             fetch_a(vnext, g + 2 - 9, (g + 2) % 3);
-        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 3 * MM, 0);
 #pragma unroll
         for (int jj = 0; jj < NB; ++jj) {
             int cnt = 0;
@@ -61,14 +69,15 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
                 if (rr < 0 || rr % S != 0 || rr / S >= RM) continue;
                 const int r = rr / S;
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[slot][dx], b[jj], acc[r], 0, 0, 0);
+                if constexpr (X3) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[slot][dx], b[jj], acc[r], 0, 0, 0);
                 ++cnt;
             }
             if (cnt == 1)
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1 * MM, 0);
             else if (cnt == 2)
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * MM, 0);
             else if (cnt == 3)
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MM, 0);
             if (g + 1 < 9) {
                 const int gn = g + 1, dy = gn / 3, dz = gn % 3;
                 b[jj] = *(const f16x8*)(b0p + ((jj * H1 + dy) * H2 + dz) * 16);
@@ -80,7 +89,7 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
 
 // S: conv stride (all axes); WN: consumer waves along the cout axis (cout group = WN chunks), 4 / WN wave rows along x;
 // RM: M-tiles (x-planes of 4 x 8 output voxels) per wave.  Block tile = (4 / WN) * RM planes.
-template <int S, int WN, int RM>
+template <int S, int WN, int RM, bool X3>
 __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -153,7 +162,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     NS_PSTAMP(7);
                 }
-                prod_commit(p, rg, nxt, q, HV, plane, dbg);
+                if constexpr (X3)
+                    prod_commit_x3(p, rg, nxt, q, HV, plane, dbg);
+                else
+                    prod_commit(p, rg, nxt, q, HV, plane, dbg);
                 NS_PSTAMP(2);
                 if (do_issue) {
                     prod_issue(p, ptc, items, pc.in_halo, pcc, false, q, dbg, rg);
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
             const float dm = ok ? 1.f : 0.f;
             float v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = acc[r][i];
+            for (int i = 0; i < 16; ++i) v[i] = X3 ? acc[r][i] * p.winv : acc[r][i];
             // packed fp32 (v_pk_add_f32 / v_pk_fma_f32: two entries per instruction; same operations and order per entry)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -252,6 +264,20 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
                 q2 = __builtin_elementwise_fma(vm, vm, q2);
                 st_s[2 * i] = s2.x; st_s[2 * i + 1] = s2.y;
                 st_q[2 * i] = q2.x; st_q[2 * i + 1] = q2.y;
+            }
+            if constexpr (X3) {   // fp32 octet planes (k_conv_ws<X3>'s store)
+                if (ok && !(dbg & 4)) {
+                    const size_t doff = ((size_t)tc.n * p.Cout + cout0) * out_vox * 4 + ((((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) + (size_t)mrel) * 32;
+                    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)doff), dhi = __builtin_amdgcn_readfirstlane((unsigned)(doff >> 32));
+                    WS_GLOBAL unsigned char* dst = sgpr_ptr((const unsigned char*)p.out + (((size_t)dhi << 32) | dlo));
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        unsigned ol = ((unsigned)srel0 * 32u + (unsigned)kh * 16u) + (unsigned)gq * ((unsigned)out_vox * 32u);
+                        asm volatile("" : "+v"(ol));
+                        *(WS_GLOBAL f32x4_t*)(dst + ol) = f32x4_t{v[gq * 4 + 0], v[gq * 4 + 1], v[gq * 4 + 2], v[gq * 4 + 3]};
+                    }
+                }
+                continue;
             }
             __builtin_amdgcn_sched_barrier(0);
             unsigned w[8];
@@ -282,15 +308,20 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
     // weights: wpk [(cc * 27 + tap) * 2 + kh][Cout][8 halves]; a wave's fragment of (cc, tap, cout chunk ch): lane (kh, l31)
     // reads 16 bytes at ((cc * 27 + tap) * 2 * Cout + kh * Cout + ch * 32 + l31) * 16
     const unsigned gs = 32u * (unsigned)p.Cout;  // bytes per tap
-    const unsigned voff = ((unsigned)kh * (unsigned)p.Cout + (unsigned)l31) * 16u;
+    const unsigned voff = X3 ? (unsigned)l31 * 16u : ((unsigned)kh * (unsigned)p.Cout + (unsigned)l31) * 16u;   // (X3: both k-halves read the same hi / lo fragments)
+    const unsigned lo_off = (unsigned)p.Cout * 16u;
     auto woff = [&](int cc, int ch) -> unsigned { return voff + (unsigned)cc * 27u * gs + (unsigned)ch * 512u; };
     f16x8 a[3][3];
+    f16x8 al[X3 ? 3 : 1][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[i][j][e] = (_Float16)0.f;
+            for (int e = 0; e < 8; ++e) {
+                a[i][j][e] = (_Float16)0.f;
+                if (X3 || i == 0) al[X3 ? i : 0][j][e] = (_Float16)0.f;
+            }
     auto prime = [&](unsigned vchunk) {  // groups 0 and 1 of a chunk into ring slots 0 and 1
         const WS_GLOBAL unsigned char* wb = sgpr_ptr(p.wpk);
 #pragma unroll
@@ -300,6 +331,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
                 unsigned vo = __umul24((unsigned)(g + 9 * dx), gs) + vchunk;
                 asm volatile("" : "+v"(vo));
                 a[g][dx] = *(const WS_GLOBAL f16x8*)(wb + vo);
+                if constexpr (X3) {
+                    unsigned vl = vo + lo_off;
+                    asm volatile("" : "+v"(vl));
+                    al[g][dx] = *(const WS_GLOBAL f16x8*)(wb + vl);
+                }
             }
     };
 
@@ -354,7 +390,8 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
                 const f32x4_t bv = *(const f32x4_t*)(lb + 8 * gq);
 #pragma unroll
                 for (int r = 0; r < RM; ++r) {
-                    acc[r][gq * 4 + 0] = bv[0]; acc[r][gq * 4 + 1] = bv[1]; acc[r][gq * 4 + 2] = bv[2]; acc[r][gq * 4 + 3] = bv[3];
+                    acc[r][gq * 4 + 0] = X3 ? bv[0] * p.wscale : bv[0]; acc[r][gq * 4 + 1] = X3 ? bv[1] * p.wscale : bv[1];
+                    acc[r][gq * 4 + 2] = X3 ? bv[2] * p.wscale : bv[2]; acc[r][gq * 4 + 3] = X3 ? bv[3] * p.wscale : bv[3];
                 }
             }
             if (!ring_valid) prime(woff(0, ch));
@@ -369,7 +406,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
                 const WS_GLOBAL unsigned char* wb = sgpr_ptr(p.wpk);
                 const unsigned vcur = woff(cc, ch);
                 const unsigned vnext = cc + 1 < ncc ? woff(cc + 1, ch) : woff(0, ch_next);
-                consume_chunk_x<S, RM>(cur + ho, acc, a, wb, vcur, vnext, gs);
+                consume_chunk_x<S, RM, X3>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
             }
             NS_STAMP(3);
             __syncthreads();
@@ -430,15 +467,15 @@ void conv_ns_tile(const ConvGeom& g, ConvTile* t) {
 
 int conv_ns_ncy(int Cout) { return (Cout / 32 + ns_wn(Cout) - 1) / ns_wn(Cout); }
 
-template <int S, int WN, int RM>
+template <int S, int WN, int RM, bool X3 = false>
 static void launch_ns(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int grid) {
-    static bool once = (hipFuncSetAttribute((const void*)k_conv_ns<S, WN, RM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    static bool once = (hipFuncSetAttribute((const void*)k_conv_ns<S, WN, RM, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL((k_conv_ns<S, WN, RM>), dim3(grid), dim3(WS_THREADS), t.lds_bytes, ctx->stream, a,
+    hipLaunchKernelGGL((k_conv_ns<S, WN, RM, X3>), dim3(grid), dim3(WS_THREADS), t.lds_bytes, ctx->stream, a,
                        getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0);
 }
 
-int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes) {
+int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes, bool x3) {
     ConvArgs a = a_in;
     a.ncy = conv_ns_ncy(a.Cout);
     const int total = t.tiles[0] * t.tiles[1] * t.tiles[2] * a.ncy;  // tiles of one sample
@@ -462,8 +499,14 @@ int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     a.runs = ws_run_table(ctx, a, total, vw);
     BOA_REQUIRE(a.runs != nullptr, "conv_ns: could not allocate the run table");
     KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);
-    ctx->counters[BOA_CNT_CONV_WS]++;
-    if (ns_wn(a.Cout) == 2) {
+    ctx->counters[x3 ? BOA_CNT_CONV_X3 : BOA_CNT_CONV_WS]++;
+    if (x3) {
+        BOA_REQUIRE(a.s0 == 2, "conv_ns: the split-precision instantiations are stride 2 only");
+        if (ns_wn(a.Cout) == 2)
+            launch_ns<2, 2, 2, true>(ctx, a, t, grid);
+        else
+            launch_ns<2, 4, 4, true>(ctx, a, t, grid);
+    } else if (ns_wn(a.Cout) == 2) {
         BOA_REQUIRE(a.s0 == 2, "conv_ns: the two-chunk cout group is instantiated for stride 2 only");
         launch_ns<2, 2, 2>(ctx, a, t, grid);
     } else if (a.s0 == 1)
