@@ -58,7 +58,8 @@ def parse_args():
     ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host (PCIe-inclusive) extra")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp16-vs-exact-mode label flip sample")
     ap.add_argument("--no-exact", action="store_true", help="skip the measured whole-volume run of the fp32 (split-precision) mode")
-    ap.add_argument("--exact-batch", type=int, default=8, help="tile batch of the fp32-mode volume (2 GB of fp32 activations per tile and net)")
+    ap.add_argument("--exact-batch", type=int, default=25,
+                    help="tile batch of the fp32-mode volume (2 GB of fp32 activations per tile: one 50 GB arena shared by the context's networks)")
     ap.add_argument("--cpu-tiles", type=int, default=8)
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="cpu_baseline: also time one tile forward on every host core (oversubscribed hosts: ~30 s; off by default)")
@@ -660,7 +661,8 @@ def main():
         if not args.no_exact and args.gpus == 1:
             # The label-contract mode, MEASURED: one whole volume of the same workload with every network in the fp32 mode
             # (split precision on the matrix cores, csrc/net_x3.hip; labels of the CPU path: tests/test_gpu_production_geometry.py).
-            # The production predictors are closed first (fp32 activations are 2 GB per tile and net).
+            # The production predictors are closed first (their weight sets and statistics tables are not needed any more; the
+            # activation arena of the context is shared by all networks and simply grows to the fp32 mode's 2 GB per tile).
             try:
                 for t in tasks:
                     t.close()

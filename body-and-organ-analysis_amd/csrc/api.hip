@@ -58,6 +58,7 @@ extern "C" void boa_destroy(boa_ctx* c) {
     for (auto& b : c->pool_free) hipFree(b.second);
     for (auto& b : c->pool_live) hipFree(b.first);  // buffers the caller never freed
     if (c->stash) hipFree(c->stash);
+    if (c->act_arena) hipFree(c->act_arena);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }

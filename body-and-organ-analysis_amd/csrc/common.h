@@ -78,6 +78,10 @@ struct boa_ctx {
     void* stash = nullptr;
     size_t stash_bytes = 0;
     bool stash_busy = false;        // a tile loop is filling it (boa_trim leaves it alone)
+    // activation arena shared by the context's networks (net.hip: net_bind_arena); act_gen counts re-allocations
+    void* act_arena = nullptr;
+    size_t act_bytes = 0;
+    unsigned long long act_gen = 0;
 };
 int boa_malloc_raw(boa_ctx* c, size_t bytes, void** dev_out);
 

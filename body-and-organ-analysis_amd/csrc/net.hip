@@ -74,6 +74,19 @@ struct boa_net {
     int* dev_origins = nullptr;
     float* first_padded = nullptr;  // zero-padded fp32 gather buffer of the first conv
     std::vector<void*> allocs;
+    // Activation buffers (one per layer, ~1 GB per tile at 128^3: 25 GB at tile batch 25) live in ONE arena per context that all
+    // of its networks share: the networks of a context run one after the other on its stream and every forward overwrites a
+    // layer's buffer before reading it, so seven resident networks need the largest network's activations once, not seven times
+    // (175 GB -> 25 GB at the bench's batch; what persists across forwards -- statistics partials, (scale, shift) tables, weight
+    // arenas, the gather head's stash -- stays outside).  A layer records its offset; pointers are (re)bound whenever the arena
+    // has been re-allocated for a larger network (boa_ctx::act_gen).
+    struct ActSlot {
+        void** where;
+        size_t offset;
+    };
+    std::vector<ActSlot> act_slots;
+    size_t act_need = 0;
+    unsigned long long act_gen_seen = 0;
     int dims[BOA_MAX_STAGES][3];
     // packed weight sets (one device arena each), cached per host blob: switching folds is a pointer swap, not a re-pack
     struct WeightSet {
@@ -89,6 +102,36 @@ struct boa_net {
 static int net_alloc(boa_net* net, size_t bytes, void** out) {
     BOA_TRY(boa_malloc_raw(net->ctx, bytes, out));   // (long-lived: not through the caching allocator; freed with hipFree)
     net->allocs.push_back(*out);
+    return BOA_OK;
+}
+
+// an activation buffer: a slice of the context's shared arena (bound by net_bind_arena)
+static int net_alloc_act(boa_net* net, size_t bytes, void** out) {
+    static const bool own = getenv("BOA_NO_ACT_ARENA") != nullptr;   // experiment hook: private buffers as in rounds 1-3
+    if (own) return net_alloc(net, bytes, out);
+    *out = nullptr;
+    net->act_slots.push_back({out, net->act_need});
+    net->act_need += (bytes + 255) & ~(size_t)255;
+    return BOA_OK;
+}
+
+// make the arena large enough for this network (re-allocating it if another, smaller network sized it) and point the layers at it
+static int net_bind_arena(boa_net* net) {
+    boa_ctx* c = net->ctx;
+    if (net->act_slots.empty()) return BOA_OK;
+    if (c->act_bytes < net->act_need) {
+        BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->act_arena) hipFree(c->act_arena);
+        c->act_arena = nullptr;
+        c->act_bytes = 0;
+        BOA_TRY(boa_malloc_raw(c, net->act_need, &c->act_arena));
+        c->act_bytes = net->act_need;
+        c->act_gen++;
+    }
+    if (net->act_gen_seen != c->act_gen) {
+        for (auto& sl : net->act_slots) *sl.where = (unsigned char*)c->act_arena + sl.offset;
+        net->act_gen_seen = c->act_gen;
+    }
     return BOA_OK;
 }
 
@@ -153,7 +196,7 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
     if (net->precision == 1) {
         BOA_REQUIRE(cout % 32 == 0, "conv %d+%d -> %d: Cout must be a multiple of 32", cin0, cin1, cout);
         size_t vox32 = (size_t)dout[0] * dout[1] * dout[2];
-        BOA_TRY(net_alloc(net, (size_t)N * vox32 * cout * sizeof(float), (void**)&L.out32));
+        BOA_TRY(net_alloc_act(net, (size_t)N * vox32 * cout * sizeof(float), (void**)&L.out32));
         BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * sizeof(float), (void**)&L.ss));
         return BOA_OK;
     }
@@ -172,7 +215,7 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
                         din[0], din[1], din[2], k[0], k[1], k[2]);
             L.nblk = conv_nblk(L.t, net->ctx->cu_count, cout);
         }
-        BOA_TRY(net_alloc(net, (size_t)N * vox2 * cout * sizeof(float), (void**)&L.out32));
+        BOA_TRY(net_alloc_act(net, (size_t)N * vox2 * cout * sizeof(float), (void**)&L.out32));
         BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * L.nblk * sizeof(float), (void**)&L.partials));
         BOA_HIP_TRY(hipMemsetAsync(L.partials, 0, (size_t)N * cout * 2 * L.nblk * sizeof(float), net->ctx->stream));
         BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * sizeof(float), (void**)&L.ss));
@@ -194,7 +237,7 @@ static int setup_conv(boa_net* net, ConvLayer& L, int N, const int din[3], int c
         L.nblk = conv_nblk(L.t, net->ctx->cu_count, cout);
     }
     size_t vox = (size_t)dout[0] * dout[1] * dout[2];
-    BOA_TRY(net_alloc(net, (size_t)N * vox * cout * sizeof(__half), (void**)&L.out));
+    BOA_TRY(net_alloc_act(net, (size_t)N * vox * cout * sizeof(__half), (void**)&L.out));
     BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * L.nblk * sizeof(float), (void**)&L.partials));
     BOA_HIP_TRY(hipMemsetAsync(L.partials, 0, (size_t)N * cout * 2 * L.nblk * sizeof(float), net->ctx->stream));
     BOA_TRY(net_alloc(net, (size_t)N * cout * 2 * sizeof(float), (void**)&L.ss));
@@ -438,8 +481,8 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
         }
         size_t vox = (size_t)dup[0] * dup[1] * dup[2];
         if (precision >= 1) {
-            if ((rc = net_alloc(net, (size_t)max_batch * vox * U.Cout * sizeof(float), (void**)&U.out32))) return fail(rc);
-        } else if ((rc = net_alloc(net, (size_t)max_batch * vox * U.Cout * sizeof(__half), (void**)&U.out)))
+            if ((rc = net_alloc_act(net, (size_t)max_batch * vox * U.Cout * sizeof(float), (void**)&U.out32))) return fail(rc);
+        } else if ((rc = net_alloc_act(net, (size_t)max_batch * vox * U.Cout * sizeof(__half), (void**)&U.out)))
             return fail(rc);
         net->dec[k].resize(d.n_conv_dec[k]);
         int one[3] = {1, 1, 1};
@@ -451,16 +494,17 @@ extern "C" int boa_net_create(boa_ctx* ctx, const boa_net_desc* desc, const floa
     }
     if ((rc = net_alloc(net, (size_t)max_batch * 3 * sizeof(int), (void**)&net->dev_origins))) return fail(rc);
     if (precision == 1) {
-        if ((rc = net_alloc(net, (size_t)max_batch * d.in_channels * d.patch[0] * d.patch[1] * d.patch[2] * sizeof(float),
-                            (void**)&net->tiles32)))
+        if ((rc = net_alloc_act(net, (size_t)max_batch * d.in_channels * d.patch[0] * d.patch[1] * d.patch[2] * sizeof(float),
+                                (void**)&net->tiles32)))
             return fail(rc);
     } else {
         int PD[3];
         conv_first_padded_dims(d.patch, d.kernel[0], PD);
-        if ((rc = net_alloc(net, (size_t)max_batch * d.in_channels * PD[0] * PD[1] * PD[2] * sizeof(float),
-                            (void**)&net->first_padded)))
+        if ((rc = net_alloc_act(net, (size_t)max_batch * d.in_channels * PD[0] * PD[1] * PD[2] * sizeof(float),
+                                (void**)&net->first_padded)))
             return fail(rc);
     }
+    if ((rc = net_bind_arena(net))) return fail(rc);
     if (host_weights) {
         rc = boa_net_load_weights(net, host_weights, n_floats);
         if (rc) return fail(rc);
@@ -753,6 +797,7 @@ extern "C" int boa_net_set_mirroring(boa_net* net, int axes_mask) {
 extern "C" int boa_net_forward(boa_net* net, const float* dev_volume, const int V[3], const int* host_origins,
                                int n_tiles, float* dev_logits_out) {
     BOA_REQUIRE(net && dev_volume && V && host_origins && dev_logits_out, "boa_net_forward: NULL argument");
+    BOA_TRY(net_bind_arena(net));
     const boa_net_desc& d = net->d;
     const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2];
     const int zero[3] = {0, 0, 0};
@@ -778,6 +823,7 @@ extern "C" int boa_net_predict_sliding_window(boa_net* net, const float* dev_vol
                                               const uint16_t* dev_gauss, uint16_t* dev_acc, uint16_t* dev_n) {
     BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_acc && dev_n,
                 "boa_net_predict_sliding_window: NULL argument");
+    BOA_TRY(net_bind_arena(net));
     const boa_net_desc& d = net->d;
     const int zero[3] = {0, 0, 0};
     const int* off = vol_off ? vol_off : zero;
@@ -851,6 +897,7 @@ extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume
                                            const int* crop_off, const int* crop_dims, int* dev_inf_flag) {
     BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_inf_flag, "boa_net_predict_labels_fold: NULL argument");
     BOA_REQUIRE(boa_net_labels_supported(net, host_origins, n_tiles), "boa_net_predict_labels_fold: unsupported network / tile layout");
+    BOA_TRY(net_bind_arena(net));
     BOA_REQUIRE(n_folds >= 1 && fold_index >= 0 && fold_index < n_folds && (n_folds == 1 || dev_fold), "boa_net_predict_labels_fold: folds");
     BOA_REQUIRE(fold_index + 1 < n_folds || dev_labels_out, "boa_net_predict_labels_fold: the last fold needs the label buffer");
     boa_ctx* c = net->ctx;
@@ -988,6 +1035,7 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
                                                        boa_stash** stash_out) {
     BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_acc && dev_n && host_defer_planes && stash_out,
                 "boa_net_predict_sliding_window_deferred: NULL argument");
+    BOA_TRY(net_bind_arena(net));
     const boa_net_desc& d = net->d;
     BOA_REQUIRE(net->mirror_mask == 0, "deferred sliding window (tile sharding) is not available with test-time mirroring");
     const int zero[3] = {0, 0, 0};
@@ -1162,6 +1210,7 @@ extern "C" int boa_net_debug_activation(boa_net* net, int kind, int stage, int c
                                         int dims_out[3]) {
     BOA_REQUIRE(net && channels_out && dims_out, "boa_net_debug_activation: NULL argument");
     BOA_REQUIRE(tile >= 0 && tile < net->maxN, "boa_net_debug_activation: tile %d outside the batch", tile);
+    BOA_TRY(net_bind_arena(net));
     const float* ss = nullptr;
     const __half* a16 = nullptr;
     const float* a32 = nullptr;
