@@ -76,7 +76,11 @@ __global__ void k_pack_head_ss(const float* __restrict__ ss, unsigned* __restric
 // four octets c, normalises in fp32, splits into hi / lo fp16 parts, and two v_permlane32_swap per octet hand the k-half-0 lane
 // the hi parts of all 8 channels and the k-half-1 lane the lo parts: the B operand of [Wh | Wh] x [Xh ; Xl] + [Wl | Wl] x [Xh ; Xl]
 // (8 MFMAs per covering tile instead of 2).  Everything after the logits is the same code.
-template <bool GAUSS, bool SSLDS, bool MULTI, bool X3>
+// PF (fp16 mode): the stash records and the Gaussian of covering tile p + 1 are fetched by LDS-DMA (global_load_lds: no VGPRs, no
+// ds_write) into a per-wave LDS slot while tile p is consumed, so every wave keeps loads in flight all the time -- the kernel was
+// bound by HBM round trips of 1 KiB pieces at the occupancy its registers allow; holding the next pair in registers cost the
+// occupancy it was meant to replace.
+template <bool GAUSS, bool SSLDS, bool MULTI, bool X3, bool PF = false>
 __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
     const int fold_mode = MULTI ? p.fold_mode : 0;
     const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
@@ -168,6 +172,94 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
         //  alone took 5 of the kernel's 9.6 ms per 512^3 part model)
         const int wx = cvx[x], wy = cvy[y], wz = cvz[zb >> 5];
         const int fx = wx & 255, cx = wx >> 8, fy = wy & 255, cy = wy >> 8, fz = wz & 255, cz = wz >> 8;
+        if constexpr (PF && !X3) {
+            __shared__ __attribute__((aligned(16))) unsigned char s_pf[4][2][2560];   // [wave][buffer][plane 0 | plane 1 | gauss words]
+            unsigned char* pfb = &s_pf[threadIdx.x >> 6][0][0];
+            const unsigned pf_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)pfb);
+            const int np = cx * cy * cz;
+            int jx = fx, jy = fy, jz = fz;   // the pair being issued
+            auto dma16 = [](gptr_t base, unsigned voff, unsigned lds_off) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_off) : "memory");
+            };
+            auto dma4 = [](gptr_t base, unsigned voff, unsigned lds_off) {
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_off) : "memory");
+            };
+            auto issue = [&](int buf, unsigned& tile_o, int& in_o, unsigned& gsel_o) {
+                const int dx = x - sx[jx], dy = y - sy[jy], tz0 = sz[jz];
+                const bool in = zvalid && z >= tz0 && z < tz0 + p.P2;
+                const unsigned tile = (unsigned)((jx * p.n1 + jy) * p.n2 + jz);
+                const unsigned tvl = (unsigned)(dx * p.P1 + dy) * (unsigned)p.P2 + (unsigned)(in ? z - tz0 : 0);
+                gptr_t ab = (gptr_t)p.act + (size_t)tile * 2 * pv * 32;
+                asm volatile("" : "+s"(ab));
+                const unsigned lo = pf_lds + (unsigned)buf * 2560u;
+                const unsigned o0 = tvl * 32u + (unsigned)kh * 16u;
+                dma16(ab, o0, lo);
+                gptr_t ab1 = ab + pv * 32;
+                asm volatile("" : "+s"(ab1));
+                dma16(ab1, o0, lo + 1024u);
+                if (GAUSS) {
+                    gptr_t gb = (gptr_t)p.gauss;
+                    asm volatile("" : "+s"(gb));
+                    dma4(gb, (tvl * 2u) & ~3u, lo + 2048u);       // the aligned word that holds this voxel's fp16 weight
+                }
+                tile_o = tile;
+                in_o = in ? 1 : 0;
+                gsel_o = tvl & 1u;
+                if (++jz == fz + cz) {
+                    jz = fz;
+                    if (++jy == fy + cy) {
+                        jy = fy;
+                        ++jx;
+                    }
+                }
+            };
+            unsigned tile_n = 0, gsel_n = 0;
+            int in_n = 0;
+            if (np > 0) issue(0, tile_n, in_n, gsel_n);
+            for (int pi = 0; pi < np; ++pi) {
+                const unsigned tile = tile_n, gsel = gsel_n;
+                const bool in = in_n != 0;
+                const bool more = pi + 1 < np;
+                if (more) issue((pi + 1) & 1, tile_n, in_n, gsel_n);
+                // the DMAs of pair pi are older than the (2 + GAUSS) of pair pi + 1: in-order completion
+                if (more)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + (GAUSS ? 1 : 0)) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned char* cb = pfb + (pi & 1) * 2560;
+                const uint4 r0 = *(const uint4*)(cb + lane * 16), r1 = *(const uint4*)(cb + 1024 + lane * 16);
+                float g = 1.0f;
+                if (GAUSS) {
+                    const unsigned gw2 = *(const unsigned*)(cb + 2048 + lane * 4);
+                    g = us2f((unsigned short)(gsel ? (gw2 >> 16) : (gw2 & 0xFFFFu)));
+                }
+                uint4 sc0, sh0, sc1, sh1;
+                if (SSLDS) {
+                    const uint4* sw = (const uint4*)(s_ssp + (tile * 2 + kh) * 16);
+                    sc0 = sw[0]; sh0 = sw[1]; sc1 = sw[2]; sh1 = sw[3];
+                } else {
+                    const uint4* sw = (const uint4*)(p.ssp + ((size_t)tile * 2 + kh) * 16);
+                    sc0 = sw[0]; sh0 = sw[1]; sc1 = sw[2]; sh1 = sw[3];
+                }
+                f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xform(r0, sc0, sh0), zero, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xform(r1, sc1, sh1), d, 0, 0, 0);
+                if (in) {
+                    typedef float gf2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const gf2_t sum = gf2_t{d[2 * i], d[2 * i + 1]} + gf2_t{s_bz[kh][2 * i], s_bz[kh][2 * i + 1]};
+                        const gf2_t pr = GAUSS ? sum * gf2_t{g, g} : sum;
+                        const float a0_ = us2f((unsigned short)(acch[i] & 0xFFFFu)), a1_ = us2f((unsigned short)(acch[i] >> 16));
+                        acch[i] = (unsigned)f2us(a0_ + pr.x) | ((unsigned)f2us(a1_ + pr.y) << 16);
+                    }
+                    nacc = us2f(f2us(nacc + g));
+                }
+            }
+        } else
         for (int ix = fx; ix < fx + cx; ++ix) {
             const int dx = x - sx[ix];
             for (int iy = fy; iy < fy + cy; ++iy) {
@@ -443,6 +535,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
     gather_head_body<GAUSS, SSLDS, MULTI, false>(p);
 }
 
+// prefetching variant of the fp16 head: 20 KB of LDS slots per block + the (scale, shift) table: four blocks per CU
+template <bool GAUSS, bool SSLDS, bool MULTI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_gather_head_pf(GatherArgs p) {
+    gather_head_body<GAUSS, SSLDS, MULTI, false, true>(p);
+}
+
 // (32 + 16 more registers for the split weights and the four fp32 octets: four waves per SIMD)
 template <bool GAUSS, bool SSLDS, bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_gather_head_x3(GatherArgs p) {
@@ -490,6 +588,10 @@ int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, con
                         hipFuncSetAttribute((const void*)k_gather_head<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
                         hipFuncSetAttribute((const void*)k_gather_head<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
                         hipFuncSetAttribute((const void*)k_gather_head<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head_pf<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head_pf<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head_pf<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
+                        hipFuncSetAttribute((const void*)k_gather_head_pf<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
                         hipFuncSetAttribute((const void*)k_gather_head_x3<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
                         hipFuncSetAttribute((const void*)k_gather_head_x3<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
                         hipFuncSetAttribute((const void*)k_gather_head_x3<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
@@ -501,10 +603,13 @@ int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, con
     do {                                                                                                 \
         if (x3)                                                                                          \
             hipLaunchKernelGGL((k_gather_head_x3<G, S, M>), dim3(grid), dim3(256), lds, ctx->stream, a); \
+        else if (pf)                                                                                     \
+            hipLaunchKernelGGL((k_gather_head_pf<G, S, M>), dim3(grid), dim3(256), lds, ctx->stream, a); \
         else                                                                                             \
             hipLaunchKernelGGL((k_gather_head<G, S, M>), dim3(grid), dim3(256), lds, ctx->stream, a);    \
     } while (0)
     const bool multi = fold_mode != 0;
+    static const bool pf = !(getenv("BOA_GH_PF") && atoi(getenv("BOA_GH_PF")) == 0);   // 0: the round-3 kernel without the LDS-DMA prefetch
     if (gauss && a.ss_in_lds) {
         if (multi) GH_LAUNCH(true, true, true); else GH_LAUNCH(true, true, false);
     } else if (gauss) {
