@@ -1563,6 +1563,153 @@ __global__ __launch_bounds__(256) void k_convt_mfma_rw(ConvTArgs p) {
     }
 }
 
+// Deep transposed convs (Cin = 16 NCC >= 256: 4^3 ... 16^3 inputs, round 4).  These layers are not HBM-bound at all -- a pass's
+// weights (2 NCC KiB per (x tap, y tap, cout chunk)) outweigh the activations, and k_convt_mfma streams them from L2 once per WAVE:
+// 230 / 138 / 41 us per 25 tiles for 84 / 19 / 3 MB of tensor traffic.  Here the block shares them: a wave keeps the B fragments of
+// its MT x 32 input voxels (deferred norm applied) in REGISTERS for the whole kernel (one wave per SIMD: 512 VGPRs), the pass's
+// weight fragments are moved L2 -> LDS once per BLOCK by LDS-DMA (double-buffered: the next pass's weights arrive under this
+// pass's MFMAs) and every wave reads its A fragments from LDS: 0.5 KiB of LDS reads per MFMA, no weight traffic per wave.
+// Same arithmetic as k_convt_mfma (chunk order, fp32 accumulation, bias add, RTNE to fp16), same slab interleave for the stores.
+template <int NCC>
+__global__ __launch_bounds__(256) void k_convt_deep(ConvTArgs p) {
+    constexpr int TZ = 2, MT = 2;
+    constexpr int WB = TZ * NCC * 1024;          // bytes of one pass's weights in LDS
+    constexpr int SLAB = 2 * 32 * TZ * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [weights 0][weights 1][4 slabs]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned in_vox = (unsigned)(p.Di * p.Hi * p.Wi);
+    const unsigned total = (unsigned)p.N * in_vox;
+    unsigned char* slab = smem + 2 * WB + wave * SLAB;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+    const int Ho = p.Hi * p.s1, Wo = p.Wi * p.s2;
+    const size_t ovox = (size_t)(p.Di * p.s0) * Ho * Wo;
+    const int nco = p.Cout / 32;
+    const int npairs = p.s0 * p.s1 * nco;
+    // weights of pass `pr` -> LDS buffer `buf`: fragment f = tz * NCC + cc is one wave-wide LDS-DMA (64 lanes x 16 B: k-half
+    // lane / 32, cout lane % 32); the four waves take f = wave, wave + 4, ...
+    const unsigned wvoff = ((unsigned)kh * (unsigned)p.Cout + (unsigned)l31) * 16u;
+    auto dma_pass = [&](int pr, int buf) {
+        const int txy = pr / nco, co = pr - txy * nco;
+        const int ty = txy % p.s1, tx = txy / p.s1;
+        const int tap0 = (tx * p.s1 + ty) * p.s2;
+        for (int f = wave; f < TZ * NCC; f += 4) {
+            const int t = f / NCC, cc = f - t * NCC;
+            const size_t woff = ((size_t)((tap0 + t) * NCC + cc) * 2 * p.Cout + (size_t)co * 32) * 16;
+            // (wave-uniform by construction; readfirstlane makes it so for the compiler: the SGPR operands of the DMA)
+            const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)woff), whi = __builtin_amdgcn_readfirstlane((unsigned)(woff >> 32));
+            const unsigned char* src = (const unsigned char*)p.wpk + (((size_t)whi << 32) | wlo);
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_w + (unsigned)(buf * WB + f * 1024));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(wvoff), "s"(src), "s"(m0v) : "memory");
+        }
+    };
+    int pr = blockIdx.y;
+    if (pr < npairs) dma_pass(pr, 0);
+    // this wave's B fragments (registers) and store pointers
+    union {
+        unsigned u;
+        ct_h2 v;
+    } sl2;
+    sl2.v = ct_h2{(_Float16)p.slope, (_Float16)p.slope};
+    const unsigned g0 = ((unsigned)blockIdx.x * 4 + wave) * (32 * MT);
+    f16x8 b[MT][NCC];
+    unsigned char* optr[MT][TZ];
+    unsigned ovalid = 0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const unsigned gv = g0 + 32 * m + l31;
+        const bool valid = gv < total;
+        const unsigned n = valid ? gv / in_vox : 0;
+        const unsigned vi = valid ? gv - n * in_vox : 0;
+        const __half* src_l = p.src + ((size_t)n * NCC * in_vox + vi) * 16 + kh * 8;
+        const unsigned* ss16_l = p.ss16 + ((size_t)n * p.Cin + kh * 8);
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+            uint4 o = *(const uint4*)(src_l + (size_t)cc * in_vox * 16);
+            const uint4 w0 = *(const uint4*)(ss16_l + cc * 16), w1 = *(const uint4*)(ss16_l + cc * 16 + 4);
+            o = convt_norm_act8_pk(o, w0, w1, sl2.u);
+            if (!valid) o = make_uint4(0, 0, 0, 0);
+            union {
+                uint4 u;
+                f16x8 f;
+            } cv;
+            cv.u = o;
+            b[m][cc] = cv.f;
+        }
+#pragma unroll
+        for (int k = 0; k < TZ; ++k) {
+            const int ov = (lane + 64 * k) >> 1;
+            const int j = ov / TZ, tz = ov % TZ;
+            const unsigned gg = g0 + 32 * m + j;
+            const bool ok = gg < total;
+            ovalid |= ok ? (1u << (m * TZ + k)) : 0u;
+            const unsigned nn = ok ? gg / in_vox : 0;
+            const unsigned v2 = ok ? gg - nn * in_vox : 0;
+            const unsigned r2 = v2 / (unsigned)p.Wi;
+            const int iz = (int)(v2 - r2 * (unsigned)p.Wi);
+            const int ix = (int)(r2 / (unsigned)p.Hi), iy = (int)(r2 - (unsigned)ix * (unsigned)p.Hi);
+            const size_t ospat = ((size_t)(ix * p.s0) * Ho + (size_t)(iy * p.s1)) * Wo + (size_t)(iz * p.s2 + tz);
+            optr[m][k] = (unsigned char*)p.out + ((size_t)nn * (p.Cout / 16) * ovox + ospat) * 32 + 16 * (lane & 1);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int it = 0; pr < npairs; pr += gridDim.y, ++it) {
+        const int buf = it & 1;
+        if (pr + (int)gridDim.y < npairs) dma_pass(pr + (int)gridDim.y, buf ^ 1);
+        const int txy = pr / nco, co = pr - txy * nco;
+        const int ty = txy % p.s1, tx = txy / p.s1;
+        float4 bq[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) bq[gq] = *(const float4*)(p.bias + co * 32 + 8 * gq + 4 * kh);
+        const unsigned char* wl = smem + buf * WB + (kh * 32 + l31) * 16;
+        f32x16 acc[TZ][MT];
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc)
+#pragma unroll
+            for (int t = 0; t < TZ; ++t) {
+                const f16x8 a = *(const f16x8*)(wl + (t * NCC + cc) * 1024);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[t][m] = cc == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[m][cc], zero, 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[m][cc], acc[t][m], 0, 0, 0);
+            }
+        const size_t poff = ((size_t)(co * 2) * ovox + ((size_t)tx * Ho + ty) * Wo) * 32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int t = 0; t < TZ; ++t) {
+                    union {
+                        uint2 u;
+                        __half h[4];
+                    } pk;
+                    pk.h[0] = __float2half_rn(acc[t][m][gq * 4 + 0] + bq[gq].x);
+                    pk.h[1] = __float2half_rn(acc[t][m][gq * 4 + 1] + bq[gq].y);
+                    pk.h[2] = __float2half_rn(acc[t][m][gq * 4 + 2] + bq[gq].z);
+                    pk.h[3] = __float2half_rn(acc[t][m][gq * 4 + 3] + bq[gq].w);
+                    *(uint2*)(slab + ((gq >> 1) * 32 * TZ + l31 * TZ + t) * 32 + (8 * (gq & 1) + 4 * kh) * 2) = pk.u;
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int k = 0; k < TZ; ++k) {
+                    const int piece = lane + 64 * k;
+                    const uint4 d = *(const uint4*)(slab + pl * 32 * TZ * 32 + piece * 16);
+                    if ((ovalid >> (m * TZ + k)) & 1u) *(uint4*)(optr[m][k] + poff + (size_t)pl * ovox * 32) = d;
+                }
+            __builtin_amdgcn_wave_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next pass's weights have landed (and this pass's stores are out)
+        __syncthreads();
+    }
+}
+
 int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], const int s[3], int Cout,
                       const __half* wpk, const float* bias, float slope, __half* out) {
     BOA_REQUIRE(src.C % 16 == 0 && Cout % 32 == 0, "convT: channels %d -> %d unsupported", src.C, Cout);
@@ -1588,7 +1735,29 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
     KernelTimer tm(ctx, BOA_K_CONVT, 2.0 * total * taps * src.C * Cout, 2.0 * total * (src.C + taps * Cout));
     static const bool no_rw = getenv("BOA_CONVT_NO_RW") != nullptr;
     const bool rw = !no_rw && s[2] == 2 && src.ss16 != nullptr && (src.C == 64 || src.C == 128);
-    if (rw) {
+    static const bool no_deep = getenv("BOA_CONVT_NO_DEEP") != nullptr;
+    static const bool deep128 = getenv("BOA_CONVT_DEEP128") != nullptr;   // experiment: the 32^3 -> 64^3 layer on k_convt_deep too
+    const bool deep = !no_deep && s[0] == 2 && s[1] == 2 && s[2] == 2 && src.ss16 != nullptr && (src.C == 256 || src.C == 320 || (deep128 && src.C == 128));
+    if (deep) {
+        const int ncc = src.C / 16;
+        const int gxd = (int)((total + 255) / 256);    // 4 waves x 2 M-tiles x 32 voxels per block
+        // the (x tap, y tap, cout chunk) passes are spread over gridDim.y until there is about one block per CU (one fits: 64-80 KiB of
+        // weight buffers), at least two passes per block so that the weight DMA overlaps (measured at 25 tiles: 16^3 124 / 140 / 151 /
+        // 189 us at 1 / 2 / 4 / 8 slices, 8^3 139 / 81 / 48 / 58, 4^3 166 / 94 / 52 / 34 and 22 at 20)
+        static const int gy_force = getenv("BOA_CONVT_DEEP_GY") ? atoi(getenv("BOA_CONVT_DEEP_GY")) : 0;
+        const int gyd = gy_force > 0 ? std::min(gy_force, npairs) : std::max(1, std::min(npairs / 2, ctx->cu_count / std::max(gxd, 1)));
+        const size_t ldsd = (size_t)2 * 2 * ncc * 1024 + 4 * (2 * 32 * 2 * 32);
+        static bool od = (hipFuncSetAttribute((const void*)k_convt_deep<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                          hipFuncSetAttribute((const void*)k_convt_deep<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                          hipFuncSetAttribute((const void*)k_convt_deep<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)od;
+        if (ncc == 8)
+            hipLaunchKernelGGL(k_convt_deep<8>, dim3(gxd, gyd), dim3(256), ldsd, ctx->stream, a);
+        else if (ncc == 16)
+            hipLaunchKernelGGL(k_convt_deep<16>, dim3(gxd, gyd), dim3(256), ldsd, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(k_convt_deep<20>, dim3(gxd, gyd), dim3(256), ldsd, ctx->stream, a);
+    } else if (rw) {
         // register-weights variant: G groups of 32 voxels per wave (G x 128 voxels per block)
         static const int g128 = getenv("BOA_CONVT_G128") ? atoi(getenv("BOA_CONVT_G128")) : 2;   // (32^3 -> 64^3: 125 -> 105 us per 8 tiles: two workgroups per CU)
         static const int g64 = getenv("BOA_CONVT_G64") ? atoi(getenv("BOA_CONVT_G64")) : 2;
