@@ -170,7 +170,13 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
         // covering tiles in ascending tile index: x outermost, z innermost (predict_from_raw_data.py:506-538)
         // (wave-uniform table look-ups: scalar loads; the first version scanned the origins in LDS and divided per pair -- the walk
         //  alone took 5 of the kernel's 9.6 ms per 512^3 part model)
-        const int wx = cvx[x], wy = cvy[y], wz = cvz[zb >> 5];
+        // (PF: the tables are read through the CONSTANT address space -- the DMA / s_waitcnt asm statements clobber "memory", after which
+        //  hipcc no longer issues scalar loads for ordinary global pointers: it fell back to vector loads + v_readfirstlane whose
+        //  vmcnt(0) waits also waited for the prefetch that had just been issued)
+        typedef const int __attribute__((address_space(4))) * ctab_t;
+        const ctab_t csx = (ctab_t)(unsigned long long)sx, csy = (ctab_t)(unsigned long long)sy, csz = (ctab_t)(unsigned long long)sz;
+        const int wx = PF ? ((ctab_t)(unsigned long long)cvx)[x] : cvx[x], wy = PF ? ((ctab_t)(unsigned long long)cvy)[y] : cvy[y],
+                  wz = PF ? ((ctab_t)(unsigned long long)cvz)[zb >> 5] : cvz[zb >> 5];
         const int fx = wx & 255, cx = wx >> 8, fy = wy & 255, cy = wy >> 8, fz = wz & 255, cz = wz >> 8;
         if constexpr (PF && !X3) {
             __shared__ __attribute__((aligned(16))) unsigned char s_pf[4][2][2560];   // [wave][buffer][plane 0 | plane 1 | gauss words]
@@ -181,15 +187,15 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
             auto dma16 = [](gptr_t base, unsigned voff, unsigned lds_off) {
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_off) : "memory");
+                             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_off));
             };
             auto dma4 = [](gptr_t base, unsigned voff, unsigned lds_off) {
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_off) : "memory");
+                             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_off));
             };
             auto issue = [&](int buf, unsigned& tile_o, int& in_o, unsigned& gsel_o) {
-                const int dx = x - sx[jx], dy = y - sy[jy], tz0 = sz[jz];
+                const int dx = x - csx[jx], dy = y - csy[jy], tz0 = csz[jz];
                 const bool in = zvalid && z >= tz0 && z < tz0 + p.P2;
                 const unsigned tile = (unsigned)((jx * p.n1 + jy) * p.n2 + jz);
                 const unsigned tvl = (unsigned)(dx * p.P1 + dy) * (unsigned)p.P2 + (unsigned)(in ? z - tz0 : 0);
@@ -442,13 +448,23 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
                 // lower classes whose quotient ties with the maximum's
                 const float lo = gmax - fabsf(gmax) * 0.00390625f;
                 int ci = gi;
+                // (one ballot for "any candidate at all" -- the common case has none -- instead of sixteen)
+                unsigned cmask = 0u;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
                     const bool cand = zvalid && c < p.C && c < gi && acc[i] >= lo;
-                    if (__builtin_amdgcn_ballot_w64(cand) != 0) {
-                        const float q = us2f(f2us(__fdiv_rn(acc[i], nacc)));
-                        if (cand && q == gq) ci = min(ci, c);
+                    cmask |= cand ? (1u << i) : 0u;
+                }
+                if (__builtin_amdgcn_ballot_w64(cmask != 0u) != 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
+                        const bool cand = (cmask >> i) & 1u;
+                        if (__builtin_amdgcn_ballot_w64(cand) != 0) {
+                            const float q = us2f(f2us(__fdiv_rn(acc[i], nacc)));
+                            if (cand && q == gq) ci = min(ci, c);
+                        }
                     }
                 }
                 bidx = min(ci, __shfl_xor(ci, 32));
