@@ -1581,6 +1581,8 @@ __global__ __launch_bounds__(256) void k_convt_deep(ConvTArgs p) {
     const unsigned in_vox = (unsigned)(p.Di * p.Hi * p.Wi);
     const unsigned total = (unsigned)p.N * in_vox;
     unsigned char* slab = smem + 2 * WB + wave * SLAB;
+    float* lbias = (float*)(smem + 2 * WB + 4 * SLAB);   // the bias vector in LDS: a global load inside the pass loop would make hipcc wait
+    for (int i = tid; i < p.Cout; i += 256) lbias[i] = p.bias[i];   // with vmcnt(0) -- i.e. also for the next pass's weight DMA
     const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
     const int Ho = p.Hi * p.s1, Wo = p.Wi * p.s2;
     const size_t ovox = (size_t)(p.Di * p.s0) * Ho * Wo;
@@ -1664,7 +1666,7 @@ __global__ __launch_bounds__(256) void k_convt_deep(ConvTArgs p) {
         const int ty = txy % p.s1, tx = txy / p.s1;
         float4 bq[4];
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) bq[gq] = *(const float4*)(p.bias + co * 32 + 8 * gq + 4 * kh);
+        for (int gq = 0; gq < 4; ++gq) bq[gq] = *(const float4*)(lbias + co * 32 + 8 * gq + 4 * kh);
         const unsigned char* wl = smem + buf * WB + (kh * 32 + l31) * 16;
         f32x16 acc[TZ][MT];
 #pragma unroll
@@ -1746,7 +1748,7 @@ int launch_convt_mfma(boa_ctx* ctx, const ActSrc& src, int N, const int din[3], 
         // 189 us at 1 / 2 / 4 / 8 slices, 8^3 139 / 81 / 48 / 58, 4^3 166 / 94 / 52 / 34 and 22 at 20)
         static const int gy_force = getenv("BOA_CONVT_DEEP_GY") ? atoi(getenv("BOA_CONVT_DEEP_GY")) : 0;
         const int gyd = gy_force > 0 ? std::min(gy_force, npairs) : std::max(1, std::min(npairs / 2, ctx->cu_count / std::max(gxd, 1)));
-        const size_t ldsd = (size_t)2 * 2 * ncc * 1024 + 4 * (2 * 32 * 2 * 32);
+        const size_t ldsd = (size_t)2 * 2 * ncc * 1024 + 4 * (2 * 32 * 2 * 32) + (size_t)Cout * sizeof(float);
         static bool od = (hipFuncSetAttribute((const void*)k_convt_deep<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                           hipFuncSetAttribute((const void*)k_convt_deep<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                           hipFuncSetAttribute((const void*)k_convt_deep<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
