@@ -263,7 +263,19 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     WS_STAMP(7);
                 }
-                if (want_w) dma_weights(p, w_cc, w_cy, nxt + 2 * plane, q, taps);
+                {
+                    // The halo registers of the chunk to commit are made "used" HERE: hipcc does not see the LDS-DMA loads of the
+                    // inline asm below, so the s_waitcnt it places in front of the first use of rg.d is vmcnt(0) -- placed after the
+                    // DMA issue it also waited for the seven DMA round trips (L2 latency on the producers' critical path in every
+                    // chunk of every streamed-weight layer; found in the ISA in round 4).  The halo loads were issued an interval ago.
+#pragma unroll
+                    for (int j = 0; j < WS_MAXV; ++j) touch128(rg.d[j]);                        // as ONE 128-bit tuple (per component
+                                                                                               // hipcc splits the load destinations)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(rg.ssw[j]));
+                    // (unconditionally: at the join behind a conditional use hipcc would wait again)
+                    if (want_w) dma_weights(p, w_cc, w_cy, nxt + 2 * plane, q, taps);
+                }
                 if constexpr (X3)
                     prod_commit_x3(p, rg, nxt, q, HV, plane, dbg);
                 else

@@ -239,6 +239,15 @@ __device__ __forceinline__ WS_GLOBAL unsigned char* sgpr_ptr(const void* p) {
 
 #define OPAQUE4(a) "+v"((a).x), "+v"((a).y), "+v"((a).z), "+v"((a).w)
 
+// a "use" of a uint4 as ONE 128-bit register tuple (OPAQUE4 names the four components separately, and hipcc then splits a
+// global_load_dwordx4 destination into copies -- with a vmcnt(0) right behind the load)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void touch128(uint4& a) {
+    u32x4_t t = {a.x, a.y, a.z, a.w};
+    asm volatile("" : "+v"(t));
+    a = make_uint4(t.x, t.y, t.z, t.w);
+}
+
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
