@@ -128,7 +128,10 @@ def cpu_baseline(part_model, n_tiles_sample, work, log, device_tiles=None):
                  for o in origins]
     else:
         tiles = [torch.randn(1, 1, *patch) for _ in range(n_tiles_sample)]
-    vs = {"fp16": {"max_err_over_range": 0.0, "flips": 0}, "fp32": {"max_err_over_range": 0.0, "flips": 0}, "voxels": 0}
+    MARGIN_THRESHOLDS = (0.001, 0.003, 0.01)
+    vs = {p_: {"max_err_over_range": 0.0, "flips": 0, "max_flip_margin": 0.0, "flips_margin_above": {t: 0 for t in MARGIN_THRESHOLDS}}
+          for p_ in ("fp16", "fp32")}
+    vs.update({"voxels": 0, "margin_above": {t: 0 for t in MARGIN_THRESHOLDS}})
     t_cpu = 0.0
     with torch.inference_mode():
         net(tiles[0])  # warm-up (allocator, mkldnn primitives)
@@ -140,10 +143,19 @@ def cpu_baseline(part_model, n_tiles_sample, work, log, device_tiles=None):
             if device_tiles is not None:      # (untimed) the same tile on the device, both precisions
                 rng_ = float(y.max() - y.min())
                 lab = y.argmax(0)
+                top2 = np.partition(y, -2, axis=0)[-2:]
+                margin = (top2[1] - top2[0]) / rng_          # the oracle's winner over its runner-up, in units of the logit range
+                for thr in MARGIN_THRESHOLDS:
+                    vs["margin_above"][thr] += int((margin > thr).sum())
                 for prec in ("fp16", "fp32"):
                     d = dev_fn(prec, origins[i])
                     vs[prec]["max_err_over_range"] = max(vs[prec]["max_err_over_range"], float(np.abs(d - y).max()) / rng_)
-                    vs[prec]["flips"] += int((d.argmax(0) != lab).sum())
+                    flipped = d.argmax(0) != lab
+                    vs[prec]["flips"] += int(flipped.sum())
+                    if flipped.any():
+                        vs[prec]["max_flip_margin"] = max(vs[prec]["max_flip_margin"], float(margin[flipped].max()))
+                        for thr in MARGIN_THRESHOLDS:
+                            vs[prec]["flips_margin_above"][thr] += int((margin[flipped] > thr).sum())
                 vs["voxels"] += int(lab.size)
         t_tile = t_cpu / len(tiles)
         # the same forward with every host core (SURVEY 8d asks for both settings): 2 tiles
@@ -160,6 +172,13 @@ def cpu_baseline(part_model, n_tiles_sample, work, log, device_tiles=None):
         vs_oracle = {"tiles": len(tiles), "voxels": vs["voxels"],
                      "fp16_max_logit_err_over_range": vs["fp16"]["max_err_over_range"], "fp16_label_flip_fraction": vs["fp16"]["flips"] / vs["voxels"],
                      "exact_max_logit_err_over_range": vs["fp32"]["max_err_over_range"], "exact_label_flip_fraction": vs["fp32"]["flips"] / vs["voxels"],
+                     # where the flips are: only voxels whose two best oracle logits are closer than `max_flip_margin` (in units of the
+                     # logit range) change label -- the synthetic net's random head leaves most voxels that close; a trained net's
+                     # confident voxels (margin above a few 1e-3 of the range) cannot flip at these error levels
+                     "fp16_flip_margin": {"max_margin_over_range_of_a_flipped_voxel": vs["fp16"]["max_flip_margin"],
+                                          "flips_with_margin_above": {str(t): vs["fp16"]["flips_margin_above"][t] for t in MARGIN_THRESHOLDS},
+                                          "voxels_with_margin_above": {str(t): vs["margin_above"][t] for t in MARGIN_THRESHOLDS}},
+                     "exact_flip_margin": {"max_margin_over_range_of_a_flipped_voxel": vs["fp32"]["max_flip_margin"]},
                      "sample": f"the {len(tiles)} 128^3 tiles (step 0.8) of a 160x160x192 phantom crop, part model 291: per-tile logits of the device "
                                "(fp16 production mode and fp32 exact mode) against the torch-CPU fp32 oracle outputs of the cpu_baseline leg"}
         log(f"parity vs oracle on {len(tiles)} tiles: fp16 max|err| {vs_oracle['fp16_max_logit_err_over_range']:.3g} of the range, flips "

@@ -13,7 +13,7 @@ BOA_OK, BOA_EINVAL, BOA_EHIP, BOA_ENOMEM, BOA_EINF = 0, -1, -2, -3, -4
 K_CONV_MFMA, K_CONV_FIRST, K_CONVT, K_NORM_FINALIZE, K_HEAD_ACCUM, K_ARGMAX, K_OTHER, K_AGG, K_MORPH, K_RESAMPLE, K_COPY, K_COUNT = range(12)
 K_NAMES = ["conv_mfma", "conv_first", "convT_mfma", "norm_finalize", "head_accum", "finalize_argmax", "other", "aggregation",
            "morphology", "resample", "copy_remap"]
-CNT_NAMES = ["head_mfma", "head_valu", "conv_ws", "conv_simple", "first_mfma", "first_valu", "f32", "conv_x3", "x3"]
+CNT_NAMES = ["head_mfma", "head_valu", "conv_ws", "conv_simple", "first_mfma", "first_valu", "f32", "conv_x3", "x3", "head_gather"]
 MAX_STAGES = 8
 
 

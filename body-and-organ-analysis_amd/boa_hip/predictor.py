@@ -147,11 +147,24 @@ class HipPredictor:
         return out
 
     # ---- sliding window on a resident volume --------------------------------------------------------
-    def _run_fold(self, dvol: DeviceBuffer, V, PV, below, origins, acc: DeviceBuffer, nacc: DeviceBuffer, fold: int):
+    def _run_fold(self, dvol: DeviceBuffer, V, PV, below, origins, acc: DeviceBuffer, nacc: DeviceBuffer, fold: int, gather: bool = False):
         self._ensure_net(fold)
         acc.zero()
         nacc.zero()
         g = self._gaussian()
+        org = np.ascontiguousarray(origins, dtype=np.int32).reshape(-1, 3)
+        if gather and self.use_gather_head and self.lib.boa_net_labels_supported(self._net, org.ctypes.data_as(C.POINTER(C.c_int)), len(org)):
+            # the accumulator planes from ONE gather-head launch (raw partial sums: the tile-sharded path's kernel with nothing
+            # deferred) instead of one read-modify-write per tile; the library falls back to the tile loop when the network / tile
+            # grid do not qualify.  Same head arithmetic as the label-only path and the sharded path for every tile origin.
+            defer = np.zeros(len(org), dtype=np.int32)
+            st = C.c_void_p()
+            check(self.lib.boa_net_predict_sliding_window_deferred(
+                self._net, dvol.vp, int3(V), int3(PV), int3(below), org.ctypes.data_as(C.POINTER(C.c_int)), len(org),
+                g.vp if g else None, acc.vp, nacc.vp, defer.ctypes.data_as(C.POINTER(C.c_int)), C.byref(st)),
+                "boa_net_predict_sliding_window_deferred")
+            self.lib.boa_stash_destroy(st)
+            return
         check(self.lib.boa_net_predict_sliding_window(
             self._net, dvol.vp, int3(V), int3(PV), int3(below), origins.ctypes.data_as(C.POINTER(C.c_int)),
             origins.shape[0], g.vp if g else None, acc.vp, nacc.vp), "boa_net_predict_sliding_window")
@@ -251,7 +264,7 @@ class HipPredictor:
         nacc = buf("n", nvox * 2)
         fold = buf("fold", C_ * nvox * 2) if nf > 1 else None
         for f in range(nf):
-            self._run_fold(dvol, V, PV, below, origins, acc, nacc, f)
+            self._run_fold(dvol, V, PV, below, origins, acc, nacc, f, gather=True)
             last = f == nf - 1
             # resampled path: keep the normalised (fold-mean) logits -- in `acc` for one fold, in `fold` otherwise -- and
             # take the argmax after the resampling

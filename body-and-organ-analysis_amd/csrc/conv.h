@@ -136,7 +136,8 @@ int launch_pack_head_ss(boa_ctx* ctx, const float* ss, unsigned* out, int n_tile
 int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, const float* w, const float* bias, const uint16_t* gauss,
                        int C, const int P[3], const int PV[3], const int ntile[3], const int* dev_tab, uint16_t* fold, int fold_mode,
                        int n_folds, const uint8_t* host_lut, int merge, uint8_t* labels, const int* crop_off, const int* crop_dims,
-                       int* inf_flag, float slope, int tiles_total, bool x3 = false);
+                       int* inf_flag, float slope, int tiles_total, bool x3 = false, const int* x_range = nullptr, uint16_t* raw_n = nullptr,
+                       int raw_init = 0);
 // k_conv_ns (conv_ns.hip): consumer waves split the cout axis, weights straight from L2 (stride-2 / deep 3x3x3 layers)
 bool conv_ns_applicable(const ConvGeom& g);
 void conv_ns_tile(const ConvGeom& g, ConvTile* t);

@@ -33,8 +33,13 @@ struct GatherArgs {
     const int* tab;               // device: [tile origins per axis: n0 + n1 + n2][cover of x: V0][cover of y: V1][cover of the z runs]
                                   // cover word = first covering tile | count << 8 (host-built: the walk is scalar table look-ups)
     unsigned short* fold;         // [C][V0 V1 V2] fp16 (several folds) or nullptr
-    int fold_mode;                // 0 single fold; 1 first of several (store); 2 middle (add); 3 last (add, / n_folds, argmax)
+    int fold_mode;                // 0 single fold; 1 first of several (store); 2 middle (add); 3 last (add, / n_folds, argmax);
+                                  // 4 raw partial sums (tile sharding): `fold` = the fp16 accumulator planes [C][V], `raw_n` = the weight plane [V];
+                                  //   the running sums of planes [x_lo, x_hi) are WRITTEN there (started from the planes' contents when raw_init)
     int n_folds;
+    int x_lo, x_hi;               // axis-0 planes this launch covers (the whole volume except in mode 4)
+    unsigned short* raw_n;
+    int raw_init;
     unsigned char* labels;
     int merge, crop, o0, o1, o2, c0, c1, c2;
     int* inf_flag;
@@ -138,8 +143,8 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
     const size_t vv = (size_t)p.V0 * p.V1 * p.V2;
     const int mpr = (p.V2 + 31) / 32;
     // (32-bit run indices: 64-bit divisions cost ~100 instructions each; the host checks that the run count fits)
-    const unsigned n_mt = (unsigned)p.V0 * (unsigned)p.V1 * (unsigned)mpr;
-    const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6), nw = gridDim.x * 4u;   // (wave-uniform: scalar tile walk)
+    const unsigned n_mt = (unsigned)p.x_hi * (unsigned)p.V1 * (unsigned)mpr, mt_lo = (unsigned)p.x_lo * (unsigned)p.V1 * (unsigned)mpr;
+    const unsigned gw = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6) + mt_lo, nw = gridDim.x * 4u;   // (wave-uniform: scalar tile walk)
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // every tile's packed (scale, shift) table in LDS (128 B per tile) when it fits (SSLDS): four ds_read_b128 per (run, tile)
     // pair instead of four L2 round trips
@@ -167,6 +172,18 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acch[i] = 0u;
         float nacc = 0.f;
+        if (MULTI && fold_mode == 4 && p.raw_init) {   // tile sharding: continue the lower rank's partial sums (same fp16 += sequence)
+            // (a wave-uniform branch with clamped per-lane addresses: behind a per-lane branch hipcc's backend rejected the scalar-base
+            //  pins of the tile loop, "illegal VGPR to SGPR copy")
+            const size_t vi0 = ((size_t)x * p.V1 + y) * p.V2 + (zvalid ? z : 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
+                const unsigned v = p.fold[(size_t)(c < p.C ? c : 0) * vv + vi0];
+                acch[i >> 1] |= (c < p.C && zvalid ? v : 0u) << (16 * (i & 1));
+            }
+            nacc = zvalid ? us2f(p.raw_n[vi0]) : 0.f;
+        }
         // covering tiles in ascending tile index: x outermost, z innermost (predict_from_raw_data.py:506-538)
         // (wave-uniform table look-ups: scalar loads; the first version scanned the origins in LDS and divided per pair -- the walk
         //  alone took 5 of the kernel's 9.6 ms per 512^3 part model)
@@ -390,6 +407,18 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
                 }
             }
         }
+        if (MULTI && fold_mode == 4) {   // the running sums as they are: the accumulator planes of the scatter form
+            if (zvalid) {
+                const size_t vi0 = ((size_t)x * p.V1 + y) * p.V2 + z;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int c = 8 * (i >> 2) + 4 * kh + (i & 3);
+                    if (c < p.C) p.fold[(size_t)c * vv + vi0] = (unsigned short)(acch[i >> 1] >> (16 * (i & 1)));
+                }
+                if (kh == 0) p.raw_n[vi0] = f2us(nacc);
+            }
+            continue;
+        }
         // normalise, fold sum / mean, argmax (k_finalize_labels)
         float acc[16];
 #pragma unroll
@@ -572,7 +601,7 @@ int launch_pack_head_ss(boa_ctx* ctx, const float* ss, unsigned* out, int n_tile
 int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, const float* w, const float* bias, const uint16_t* gauss,
                        int C, const int P[3], const int PV[3], const int ntile[3], const int* dev_tab, uint16_t* fold, int fold_mode,
                        int n_folds, const uint8_t* host_lut, int merge, uint8_t* labels, const int* crop_off, const int* crop_dims,
-                       int* inf_flag, float slope, int tiles_total, bool x3) {
+                       int* inf_flag, float slope, int tiles_total, bool x3, const int* x_range, uint16_t* raw_n, int raw_init) {
     BOA_REQUIRE(C >= 1 && C <= 32 && ntile[0] < 256 && ntile[1] < 256 && ntile[2] < 256, "gather head: C=%d / %d+%d+%d tiles per axis unsupported", C,
                 ntile[0], ntile[1], ntile[2]);
     GatherArgs a;
@@ -588,16 +617,22 @@ int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, con
         a.c0 = crop_dims[0]; a.c1 = crop_dims[1]; a.c2 = crop_dims[2];
     }
     a.inf_flag = inf_flag; a.slope = slope;
+    a.x_lo = x_range ? x_range[0] : 0;
+    a.x_hi = x_range ? x_range[1] : PV[0];
+    a.raw_n = raw_n; a.raw_init = raw_init;
+    BOA_REQUIRE(a.x_lo >= 0 && a.x_lo <= a.x_hi && a.x_hi <= PV[0] && (fold_mode != 4 || (fold && raw_n)), "gather head: plane range / raw buffers");
     a.wscale = X3_HEAD_WSCALE;
     a.winv = 1.0f / a.wscale;
     for (int i = 0; i < 256; ++i) a.lut[i] = host_lut ? host_lut[i] : (unsigned char)i;
     const long long n_mt = (long long)PV[0] * PV[1] * ((PV[2] + 31) / 32);
     BOA_REQUIRE(n_mt < (1ll << 31), "gather head: volume too large for 32-bit run indices");
-    const unsigned grid = (unsigned)std::min<long long>(std::max<long long>((n_mt + 3) / 4, 1), (long long)ctx->cu_count * 16);
+    const long long n_mt_run = (long long)(a.x_hi - a.x_lo) * PV[1] * ((PV[2] + 31) / 32);
+    const unsigned grid = (unsigned)std::min<long long>(std::max<long long>((n_mt_run + 3) / 4, 1), (long long)ctx->cu_count * 16);
     // algorithmic bytes: every tile's stash is read once (64 B activation + 2 B Gaussian per voxel), one label byte per voxel
     // (+ the fold buffer's read-modify-write)
     const double pvd = (double)P[0] * P[1] * P[2], vvd = (double)PV[0] * PV[1] * PV[2];
-    const double bytes = (double)tiles_total * pvd * (x3 ? 130.0 : 66.0) + vvd * (fold_mode == 0 ? 1.0 : (fold_mode == 1 ? 2.0 * C : 4.0 * C));
+    const double bytes = fold_mode == 4 ? (double)n_mt_run * 32.0 * ((x3 ? 130.0 : 66.0) * 2.0 + 2.0 * (C + 1) * (raw_init ? 2 : 1))   // (~2 covering tiles per voxel)
+                                        : (double)tiles_total * pvd * (x3 ? 130.0 : 66.0) + vvd * (fold_mode == 0 ? 1.0 : (fold_mode == 1 ? 2.0 * C : 4.0 * C));
     const size_t ss_bytes = (size_t)tiles_total * (x3 ? 256 : 128);
     a.ss_in_lds = ss_bytes <= 96 * 1024 ? 1 : 0;
     static bool once = (hipFuncSetAttribute((const void*)k_gather_head<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024),
@@ -637,6 +672,7 @@ int launch_gather_head(boa_ctx* ctx, const __half* act, const unsigned* ssp, con
     }
 #undef GH_LAUNCH
     if (x3) ctx->counters[BOA_CNT_X3]++;
+    ctx->counters[BOA_CNT_HEAD_GATHER]++;
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;

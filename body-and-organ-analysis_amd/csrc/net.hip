@@ -705,6 +705,11 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
                                       L.wfirst, L.bias, net->first_padded, L.out, L.partials, &nblk, flip_mask));
         } else {
             BOA_TRY(launch_conv_mfma(c, a, b, g, L.t, L.wpk, L.bias, d.lrelu_slope, L.out, L.partials));
+            static const int prof_repeat = getenv("BOA_LAYER_PROF_REPEAT") ? atoi(getenv("BOA_LAYER_PROF_REPEAT")) : 0;
+            for (int rep = 0; layer_prof && rep < prof_repeat; ++rep) {   // (same launch again, timed alone: warm caches / clocks)
+                prof_begin();
+                BOA_TRY(launch_conv_mfma(c, a, b, g, L.t, L.wpk, L.bias, d.lrelu_slope, L.out, L.partials));
+            }
         }
         {
             const int din[3] = {g.Di, g.Hi, g.Wi};
@@ -881,33 +886,25 @@ static bool grid_origins(const int* o, int n, std::vector<int> (&steps)[3]) {
     return n0 < 256 && n1 < 256 && n2 < 256;
 }
 
-extern "C" int boa_net_labels_supported(boa_net* net, const int* host_origins, int n_tiles) {
-    if (!net || !host_origins) return 0;
-    static const bool off = getenv("BOA_NO_GATHER_HEAD") != nullptr;
-    // (patch z extent a multiple of 32 and <= 31 classes: the shapes for which the scatter loop's head runs on the matrix cores too,
-    //  so that the label path and the logits API share one head arithmetic)
-    if (off || net->precision == 1 || net->mirror_mask != 0 || net->d.features[0] != 32 || net->d.num_classes > 31 || net->d.patch[2] % 32 != 0) return 0;
-    std::vector<int> steps[3];
-    return grid_origins(host_origins, n_tiles, steps) ? 1 : 0;
-}
+// The last decoder activation of EVERY tile of a fold, kept in the context's stash for the gather head (k_gather_head): layout
+// [activations][fp32 ss][packed ss16 of the conv stack][head ss table][walk table]
+struct TileStash {
+    const __half* act = nullptr;   // fp16 chunk planes (fp32 octet planes in the split-precision mode)
+    float* ss = nullptr;           // [tile][F0][2] fp32 (scale, shift) of the last InstanceNorm
+    unsigned* ssp = nullptr;       // [tile][2][16] packed fp16 (scale, shift): the fp16 head's table
+    int* tab = nullptr;            // walk table (device)
+    bool x3 = false;
+    std::vector<int> steps[3];     // tile origins per axis
+};
 
-extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume, const int V[3], const int PV[3], const int* vol_off,
-                                           const int* host_origins, int n_tiles, const uint16_t* dev_gauss, uint16_t* dev_fold,
-                                           int fold_index, int n_folds, const uint8_t* host_lut, int merge, uint8_t* dev_labels_out,
-                                           const int* crop_off, const int* crop_dims, int* dev_inf_flag) {
-    BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_inf_flag, "boa_net_predict_labels_fold: NULL argument");
-    BOA_REQUIRE(boa_net_labels_supported(net, host_origins, n_tiles), "boa_net_predict_labels_fold: unsupported network / tile layout");
-    BOA_TRY(net_bind_arena(net));
-    BOA_REQUIRE(n_folds >= 1 && fold_index >= 0 && fold_index < n_folds && (n_folds == 1 || dev_fold), "boa_net_predict_labels_fold: folds");
-    BOA_REQUIRE(fold_index + 1 < n_folds || dev_labels_out, "boa_net_predict_labels_fold: the last fold needs the label buffer");
+
+// runs the conv stack over all tiles (batches of max_batch), the last decoder conv writing straight into the stash slots of its tiles, and
+// builds the gather head's walk table.  BOA_ENOMEM when the stash does not fit (the caller falls back to the scatter form).
+static int net_forward_into_stash(boa_net* net, const float* dev_volume, const int V[3], const int PV[3], const int* off, const int* host_origins,
+                                  int n_tiles, TileStash& ts) {
     boa_ctx* c = net->ctx;
     const boa_net_desc& d = net->d;
-    const int zero[3] = {0, 0, 0};
-    const int* off = vol_off ? vol_off : zero;
-    for (int a = 0; a < 3; ++a)
-        BOA_REQUIRE(PV[a] >= d.patch[a] && off[a] >= 0 && off[a] + V[a] <= PV[a],
-                    "fused sliding window: padded dim %d (%d) must cover patch (%d) and volume (%d at %d)", a, PV[a], d.patch[a], V[a], off[a]);
-    std::vector<int> steps[3];
+    std::vector<int> (&steps)[3] = ts.steps;
     grid_origins(host_origins, n_tiles, steps);
     const int F0 = d.features[0];
     const size_t pv = (size_t)d.patch[0] * d.patch[1] * d.patch[2];
@@ -945,6 +942,7 @@ extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume
     }
     unsigned char* base = (unsigned char*)c->stash;
     __half* s_act = (__half*)(base + o_act);
+    ts.x3 = x3;
     float* s_ss = (float*)(base + o_ss);
     unsigned* s_ss16 = (unsigned*)(base + o_ss16);
     unsigned* s_ssp = (unsigned*)(base + o_ssp);
@@ -994,6 +992,47 @@ extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume
     BOA_HIP_TRY(hipMemcpyAsync(s_steps, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     BOA_HIP_TRY(hipStreamSynchronize(c->stream));   // (the table is a stack-lifetime host vector)
     c->prof_break = true;
+    ts.act = s_act;
+    ts.ss = s_ss;
+    ts.ssp = s_ssp;
+    ts.tab = s_steps;
+    return BOA_OK;
+}
+
+extern "C" int boa_net_labels_supported(boa_net* net, const int* host_origins, int n_tiles) {
+    if (!net || !host_origins) return 0;
+    static const bool off = getenv("BOA_NO_GATHER_HEAD") != nullptr;
+    // (patch z extent a multiple of 32 and <= 31 classes: the shapes for which the scatter loop's head runs on the matrix cores too,
+    //  so that the label path and the logits API share one head arithmetic)
+    if (off || net->precision == 1 || net->mirror_mask != 0 || net->d.features[0] != 32 || net->d.num_classes > 31 || net->d.patch[2] % 32 != 0) return 0;
+    std::vector<int> steps[3];
+    return grid_origins(host_origins, n_tiles, steps) ? 1 : 0;
+}
+
+extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume, const int V[3], const int PV[3], const int* vol_off,
+                                           const int* host_origins, int n_tiles, const uint16_t* dev_gauss, uint16_t* dev_fold,
+                                           int fold_index, int n_folds, const uint8_t* host_lut, int merge, uint8_t* dev_labels_out,
+                                           const int* crop_off, const int* crop_dims, int* dev_inf_flag) {
+    BOA_REQUIRE(net && dev_volume && V && PV && host_origins && dev_inf_flag, "boa_net_predict_labels_fold: NULL argument");
+    BOA_REQUIRE(boa_net_labels_supported(net, host_origins, n_tiles), "boa_net_predict_labels_fold: unsupported network / tile layout");
+    BOA_TRY(net_bind_arena(net));
+    BOA_REQUIRE(n_folds >= 1 && fold_index >= 0 && fold_index < n_folds && (n_folds == 1 || dev_fold), "boa_net_predict_labels_fold: folds");
+    BOA_REQUIRE(fold_index + 1 < n_folds || dev_labels_out, "boa_net_predict_labels_fold: the last fold needs the label buffer");
+    boa_ctx* c = net->ctx;
+    const boa_net_desc& d = net->d;
+    const int zero[3] = {0, 0, 0};
+    const int* off = vol_off ? vol_off : zero;
+    for (int a = 0; a < 3; ++a)
+        BOA_REQUIRE(PV[a] >= d.patch[a] && off[a] >= 0 && off[a] + V[a] <= PV[a],
+                    "fused sliding window: padded dim %d (%d) must cover patch (%d) and volume (%d at %d)", a, PV[a], d.patch[a], V[a], off[a]);
+    TileStash ts;
+    BOA_TRY(net_forward_into_stash(net, dev_volume, V, PV, off, host_origins, n_tiles, ts));
+    float* s_ss = ts.ss;
+    unsigned* s_ssp = ts.ssp;
+    int* s_steps = ts.tab;
+    const __half* s_act = ts.act;
+    const bool x3 = ts.x3;
+    std::vector<int> (&steps)[3] = ts.steps;
     const int ntile[3] = {(int)steps[0].size(), (int)steps[1].size(), (int)steps[2].size()};
     const int mode = n_folds == 1 ? 0 : (fold_index == 0 ? 1 : (fold_index + 1 == n_folds ? 3 : 2));
     return launch_gather_head(c, s_act, x3 ? (const unsigned*)s_ss : s_ssp, net->head_w, net->head_b, dev_gauss, d.num_classes, d.patch, PV, ntile,
@@ -1020,6 +1059,12 @@ struct boa_stash {
         int start[3];
     };
     std::vector<Item> items;
+    // gather form (boa_net_predict_sliding_window_deferred ran the gather head): the deferred planes of the block's first tile row in the
+    // gather head's own stash layout -- [tile][F / 16 planes][dp * P1 * P2 voxels][32 B], the (scale, shift) tables, the walk table -- so that
+    // boa_net_apply_deferred is ONE more k_gather_head launch over planes [x0, x0 + dp), started from the lower rank's sums
+    bool gather = false, x3 = false;
+    int dp = 0, x0 = 0, n1 = 0, n2 = 0, n_items = 0;
+    size_t o_ss = 0, o_ssp = 0, o_tab = 0;
 };
 
 extern "C" void boa_stash_destroy(boa_stash* st) {
@@ -1071,7 +1116,127 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
         for (int a = 0; a < 3; ++a) it.start[a] = host_origins[(size_t)i * 3 + a];
         st->items.push_back(it);
     }
-    int rc = bytes ? boa_malloc(net->ctx, bytes, (void**)&st->arena) : BOA_OK;
+    int rc = BOA_OK;
+    // Gather form (the product path when the network / tile grid allow it, as in boa_net_predict_labels_fold): every tile's last
+    // activation goes to the context's stash, the planes to defer are copied out of it, and ONE k_gather_head launch in raw mode
+    // writes the partial sums of all other planes of this rank -- [x_split, end of its last row) -- instead of one accumulator
+    // read-modify-write per covering tile.  The planes below x_split are exactly the deferred ones (checked) and all belong to the
+    // block's first tile row: they stay untouched until boa_net_apply_deferred adds them, with the same kernel, on top of the
+    // lower rank's sums.  Same head arithmetic for every tile (the matrix-core head), whatever the tile origins' alignment.
+    static const bool shard_scatter = getenv("BOA_SHARD_SCATTER") != nullptr;   // experiment hook: the round-3 scatter loop
+    if (!shard_scatter && !f32 && n_tiles > 0 && boa_net_labels_supported(net, host_origins, n_tiles)) {
+        int x_first = host_origins[0], x_split = -1, x_end = 0, dp0 = 0, x0 = 0, n_def = 0;
+        bool consistent = true;
+        for (int i = 0; i < n_tiles; ++i) {
+            const int xo = host_origins[(size_t)i * 3], dpi = host_defer_planes[i];
+            x_first = std::min(x_first, xo);
+            x_end = std::max(x_end, xo + d.patch[0]);
+            if (dpi > 0) {
+                if (n_def == 0) {
+                    dp0 = dpi;
+                    x0 = xo;
+                }
+                consistent = consistent && dpi == dp0 && xo == x0;   // one row, one depth
+                x_split = xo + dpi;
+                ++n_def;
+            }
+        }
+        if (x_split < 0) x_split = x_first;
+        for (int i = 0; i < n_tiles; ++i) {   // every tile that reaches below x_split defers exactly its planes below x_split
+            const int below = std::max(0, std::min(x_split - host_origins[(size_t)i * 3], d.patch[0]));
+            consistent = consistent && host_defer_planes[i] == below;
+        }
+        TileStash ts;
+        int grc = consistent ? net_forward_into_stash(net, dev_volume, V, PV, off, host_origins, n_tiles, ts) : BOA_ENOMEM;
+        if (grc == BOA_OK) {
+            boa_ctx* c = net->ctx;
+            // the deferred planes in the gather head's layout
+            st->gather = true;
+            st->x3 = x3;
+            st->dp = dp0;
+            st->x0 = x0;
+            st->n1 = (int)ts.steps[1].size();
+            st->n2 = (int)ts.steps[2].size();
+            st->n_items = n_def;
+            auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t item_act = (size_t)dp0 * plane * F * esz;
+            st->o_ss = align((size_t)n_def * item_act);
+            st->o_ssp = align(st->o_ss + (size_t)n_def * F * 2 * sizeof(float));
+            st->o_tab = align(st->o_ssp + (size_t)n_def * 32 * sizeof(unsigned));
+            const size_t gbytes = align(st->o_tab + ((size_t)1 + st->n1 + st->n2 + PV[0] + PV[1] + PV[2] / 32 + 8) * sizeof(int));
+            if (n_def > 0) {
+                if ((rc = boa_malloc(c, gbytes, (void**)&st->arena)) != BOA_OK) {
+                    boa_stash_destroy(st);
+                    return rc;
+                }
+                BOA_REQUIRE(n_def == st->n1 * st->n2, "deferred sliding window: %d deferred tiles in a row of %d x %d", n_def, st->n1, st->n2);
+                bool ok_copy = true;
+                int item = 0;
+                const int nplanes = x3 ? F / 8 : F / 16;   // 32-byte records per voxel and plane in both layouts
+                for (int i = 0; i < n_tiles && ok_copy; ++i) {
+                    if (host_defer_planes[i] == 0) continue;
+                    const unsigned char* tile_act = (const unsigned char*)ts.act + (size_t)i * pv * F * esz;
+                    for (int k = 0; k < nplanes && ok_copy; ++k)
+                        ok_copy = hipMemcpyAsync(st->arena + (size_t)item * item_act + (size_t)k * dp0 * plane * 32, tile_act + (size_t)k * pv * 32,
+                                                 (size_t)dp0 * plane * 32, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+                    ok_copy = ok_copy && hipMemcpyAsync(st->arena + st->o_ss + (size_t)item * F * 2 * sizeof(float), ts.ss + (size_t)i * F * 2,
+                                                        (size_t)F * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+                    ++item;
+                }
+                if (!ok_copy) {
+                    boa_stash_destroy(st);
+                    boa_set_error("deferred sliding window: stash copy failed");
+                    return BOA_EHIP;
+                }
+                if (!x3 && (rc = launch_pack_head_ss(c, (const float*)(st->arena + st->o_ss), (unsigned*)(st->arena + st->o_ssp), n_def)) != BOA_OK) {
+                    boa_stash_destroy(st);
+                    return rc;
+                }
+                // walk table of the one-row tile grid with dp planes per tile
+                std::vector<int> tab;
+                tab.push_back(x0);
+                for (int v : ts.steps[1]) tab.push_back(v);
+                for (int v : ts.steps[2]) tab.push_back(v);
+                auto cover = [&](int a, int ext, int lo, int hi) {
+                    const std::vector<int> one = {x0};
+                    const std::vector<int>& stp = a == 0 ? one : ts.steps[a];
+                    int first = 0, cnt = 0;
+                    for (size_t k = 0; k < stp.size(); ++k)
+                        if (stp[k] <= hi && stp[k] + ext > lo) {
+                            if (!cnt) first = (int)k;
+                            ++cnt;
+                        }
+                    return first | (cnt << 8);
+                };
+                for (int x = 0; x < PV[0]; ++x) tab.push_back(cover(0, dp0, x, x));
+                for (int y = 0; y < PV[1]; ++y) tab.push_back(cover(1, d.patch[1], y, y));
+                for (int zb = 0; zb < PV[2]; zb += 32) tab.push_back(cover(2, d.patch[2], zb, std::min(zb + 31, PV[2] - 1)));
+                if (hipMemcpyAsync(st->arena + st->o_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipStreamSynchronize(c->stream) != hipSuccess) {   // (the table is a stack-lifetime host vector)
+                    boa_stash_destroy(st);
+                    boa_set_error("deferred sliding window: walk table copy failed");
+                    return BOA_EHIP;
+                }
+            }
+            c->prof_break = true;
+            const int ntile[3] = {(int)ts.steps[0].size(), (int)ts.steps[1].size(), (int)ts.steps[2].size()};
+            const int xr[2] = {x_split, std::min(x_end, PV[0])};
+            rc = launch_gather_head(c, ts.act, x3 ? (const unsigned*)ts.ss : ts.ssp, net->head_w, net->head_b, dev_gauss, d.num_classes, d.patch, PV, ntile,
+                                    ts.tab, dev_acc, 4, 1, nullptr, 0, nullptr, nullptr, nullptr, nullptr, d.lrelu_slope, n_tiles, x3, xr, dev_n, 0);
+            if (rc != BOA_OK) {
+                boa_stash_destroy(st);
+                return rc;
+            }
+            *stash_out = st;
+            return BOA_OK;
+        }
+        if (grc != BOA_ENOMEM) {
+            boa_stash_destroy(st);
+            return grc;
+        }
+        // (stash does not fit / unusual deferral pattern: the scatter loop below)
+    }
+    rc = bytes ? boa_malloc(net->ctx, bytes, (void**)&st->arena) : BOA_OK;
     if (rc != BOA_OK) {
         delete st;
         return rc;
@@ -1128,6 +1293,15 @@ extern "C" int boa_net_apply_deferred(boa_net* net, const boa_stash* st, const u
                                       uint16_t* dev_n, const int PV[3]) {
     BOA_REQUIRE(net && st && dev_acc && dev_n && PV, "boa_net_apply_deferred: NULL argument");
     const boa_net_desc& d = net->d;
+    if (st->gather) {
+        if (st->n_items == 0) return BOA_OK;
+        const int P[3] = {st->dp, d.patch[1], d.patch[2]};
+        const int ntile[3] = {1, st->n1, st->n2};
+        const int xr[2] = {st->x0, std::min(st->x0 + st->dp, PV[0])};
+        return launch_gather_head(net->ctx, (const __half*)st->arena, (const unsigned*)(st->arena + (st->x3 ? st->o_ss : st->o_ssp)), st->head_w, st->head_b,
+                                  dev_gauss, d.num_classes, P, PV, ntile, (const int*)(st->arena + st->o_tab), dev_acc, 4, 1, nullptr, 0, nullptr, nullptr,
+                                  nullptr, nullptr, d.lrelu_slope, st->n_items, st->x3, xr, dev_n, 1);
+    }
     for (const boa_stash::Item& it : st->items) {  // the stash keeps the canonical tile order
         int P[3] = {it.planes, d.patch[1], d.patch[2]};
         if (net->precision == 1)

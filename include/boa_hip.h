@@ -106,6 +106,7 @@ int boa_prof_get(boa_ctx* ctx, int kclass, double* total_ms, long long* launches
 #define BOA_CNT_F32 6             /* any kernel of the fp32 reference network mode (precision = 1)     */
 #define BOA_CNT_CONV_X3 7         /* k_conv_ws<..., X3>: split-precision conv (precision = 2)          */
 #define BOA_CNT_X3 8              /* the other kernels of the split-precision mode (first conv, transposed conv, head) */
+#define BOA_CNT_HEAD_GATHER 9     /* k_gather_head* (fused head over all covering tiles; raw partial sums in the tile-sharded path) */
 #define BOA_CNT_COUNT 10
 long long boa_debug_counter(boa_ctx* ctx, int which, int reset);
 

@@ -59,7 +59,7 @@ def _ct(big=False):
     return ct
 
 
-def _predict(ctx, shard=None, model_shard=None, max_batch=1, spacing_zyx=None, precision=None, big=False):
+def _predict(ctx, shard=None, model_shard=None, max_batch=1, spacing_zyx=None, precision=None, big=False, scatter=False):
     from boa_hip.task import SegmentationTask
     models, luts = _models(big)
     shape = SHAPE_BIG if big else SHAPE
@@ -70,12 +70,13 @@ def _predict(ctx, shard=None, model_shard=None, max_batch=1, spacing_zyx=None, p
     for _, _, p, _ in task.parts:
         p.tile_step_size = 0.5
     task.shard = shard
-    # the sharded paths run the scatter form of the tile loop (fp16 accumulator planes, overlap slabs exchanged); the unsharded
-    # reference does too, so that "bit-identical" compares like with like also for this geometry's unaligned tile origins (the
-    # gather form computes every tile's head on the matrix cores, the scatter form falls back to the fp32 VALU head for z origins
-    # that are not 8-aligned: tests/test_gpu_gather_head.py)
-    for _, _, p, _ in task.parts:
-        p.use_gather_head = False
+    # every path runs the gather head (the unsharded label path, the unsharded resampled path and the tile-sharded path's raw
+    # partial sums + deferred planes): the same matrix-core head arithmetic for every tile origin, so "bit-identical" compares
+    # like with like also for this geometry's unaligned tile origins (the scatter form falls back to the fp32 VALU head for z
+    # origins that are not 8-aligned: tests/test_gpu_gather_head.py)
+    if scatter:
+        for _, _, p, _ in task.parts:
+            p.use_gather_head = False
     d_ct = ctx.from_numpy(_ct(big))
     d_lab = ctx.alloc(int(np.prod(shape)))
     try:
@@ -113,6 +114,8 @@ def _worker(rank, world, port, mode, q, backend="gloo"):
     else:
         lab = _predict(ctx, ts.TileShard(comm, mode), max_batch=3, spacing_zyx=sp, precision=prec, big=big)
     q.put((rank, lab))
+    if os.environ.get("BOA_TEST_COUNTERS"):     # (second message: which head kernels this rank launched)
+        q.put((rank + 1000, ctx.counters()))
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
@@ -126,7 +129,7 @@ def _run(world, mode, backend="gloo"):
     procs = [mpc.Process(target=_worker, args=(r, world, port, mode, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=300) for _ in range(world))
+    got = dict(q.get(timeout=300) for _ in range(world * (2 if os.environ.get("BOA_TEST_COUNTERS") else 1)))
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -198,7 +201,14 @@ def test_tile_sharding_at_the_production_geometry(mode):
     want = _predict(c, max_batch=4, big=True)
     c.close()
     assert len(np.unique(want)) > 10
-    got = _run(2, mode)
+    os.environ["BOA_TEST_COUNTERS"] = "1"
+    try:
+        got = _run(2, mode)
+    finally:
+        del os.environ["BOA_TEST_COUNTERS"]
+    for r in range(2):      # the sharded ranks ran the gather head (raw partial sums + deferred planes), not the per-tile scatter loop
+        cnt = got[1000 + r]
+        assert cnt["head_gather"] >= (1 + r if mode.startswith("exact") else 1) and cnt["head_mfma"] == 0 and cnt["head_valu"] == 0, cnt
     if mode.startswith("exact"):
         np.testing.assert_array_equal(got[0], want)
         np.testing.assert_array_equal(got[1], want)
