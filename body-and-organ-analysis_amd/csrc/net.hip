@@ -705,8 +705,21 @@ static int net_forward_stack(boa_net* net, const float* volume, const int V[3], 
                                       L.wfirst, L.bias, net->first_padded, L.out, L.partials, &nblk, flip_mask));
         } else {
             BOA_TRY(launch_conv_mfma(c, a, b, g, L.t, L.wpk, L.bias, d.lrelu_slope, L.out, L.partials));
+            // BOA_LAYER_PROF_REPEAT=n [BOA_LAYER_PROF_MATCH=Di,Cin,Cout]: the same launch n more times, timed as one block (sustained
+            // clocks; tools/power_sample.sh samples the socket power meanwhile)
             static const int prof_repeat = getenv("BOA_LAYER_PROF_REPEAT") ? atoi(getenv("BOA_LAYER_PROF_REPEAT")) : 0;
-            for (int rep = 0; layer_prof && rep < prof_repeat; ++rep) {   // (same launch again, timed alone: warm caches / clocks)
+            static int m_di = -1, m_ci = -1, m_co = -1;
+            static const bool has_match = getenv("BOA_LAYER_PROF_MATCH") && sscanf(getenv("BOA_LAYER_PROF_MATCH"), "%d,%d,%d", &m_di, &m_ci, &m_co) == 3;
+            if (layer_prof && prof_repeat > 0 && (!has_match || (g.Di == m_di && L.Cin0 + L.Cin1 == m_ci && g.Cout == m_co))) {
+                prof_begin();
+                for (int rep = 0; rep < prof_repeat; ++rep)
+                    BOA_TRY(launch_conv_mfma(c, a, b, g, L.t, L.wpk, L.bias, d.lrelu_slope, L.out, L.partials));
+                hipEventRecord(c->t1[7], c->stream);
+                hipEventSynchronize(c->t1[7]);
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, c->t0[7], c->t1[7]);
+                fprintf(stderr, "[repeat] in=%d cin=%d cout=%d: %d launches, %.1f us each, %.3f s\n", g.Di, L.Cin0 + L.Cin1, g.Cout, prof_repeat,
+                        ms * 1e3 / prof_repeat, ms * 1e-3);
                 prof_begin();
                 BOA_TRY(launch_conv_mfma(c, a, b, g, L.t, L.wpk, L.bias, d.lrelu_slope, L.out, L.partials));
             }
