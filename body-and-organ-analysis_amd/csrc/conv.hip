@@ -1149,14 +1149,20 @@ int launch_conv_first(boa_ctx* ctx, const float* volume, const int V[3], const i
 
 // ======================================================================================================
 // InstanceNorm finalize: deterministic fp64 reduction of the per-block partials
-__global__ __launch_bounds__(256) void k_norm_finalize(float* __restrict__ partials, int nblk, int C, double count, int clear,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, float* __restrict__ ss,
-                                                      unsigned short* __restrict__ ss16) {
+// T = 256: one block per (n, c).  T = 64 (layers with at most 64 slots per (n, c): the 8^3 / 4^3 layers, whose N x 320 blocks of 256 mostly
+// idle threads took four rounds of dependent HBM round trips to get through the CUs): one wave per (n, c) -- the same additions in the same
+// order (with <= 64 slots only wave 0 of the 256-thread form holds non-zero terms), so the same bits.
+template <int T>
+__global__ __launch_bounds__(T) void k_norm_finalize(float* __restrict__ partials, int nblk, int C, double count, int clear,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float eps, float* __restrict__ ss,
+                                                    unsigned short* __restrict__ ss16) {
     const int c = blockIdx.x, n = blockIdx.y;
     float* ps = partials + (((size_t)n * C + c) * 2 + 0) * nblk;
     float* pq = partials + (((size_t)n * C + c) * 2 + 1) * nblk;
     __shared__ double red[8];
+    // (loaded up front: behind the reduction they were one more dependent round trip per block)
+    const float gam = gamma[c], bet = beta[c];
     double s = 0.0, q = 0.0;
     // (four slots per thread in flight: the loop was a chain of dependent global round trips -- 16 for the 4 096 slots of a 128^3
     //  layer; the additions keep their order)
@@ -1186,20 +1192,24 @@ __global__ __launch_bounds__(256) void k_norm_finalize(float* __restrict__ parti
         s += __shfl_xor(s, m);
         q += __shfl_xor(q, m);
     }
-    if ((threadIdx.x & 63) == 0) {
-        red[(threadIdx.x >> 6) * 2] = s;
-        red[(threadIdx.x >> 6) * 2 + 1] = q;
+    if (T > 64) {
+        if ((threadIdx.x & 63) == 0) {
+            red[(threadIdx.x >> 6) * 2] = s;
+            red[(threadIdx.x >> 6) * 2 + 1] = q;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        s = (red[0] + red[2]) + (red[4] + red[6]);  // fixed order: deterministic
-        q = (red[1] + red[3]) + (red[5] + red[7]);
+        if (T > 64) {
+            s = (red[0] + red[2]) + (red[4] + red[6]);  // fixed order: deterministic
+            q = (red[1] + red[3]) + (red[5] + red[7]);
+        }
         double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
         double inv = 1.0 / sqrt(var + (double)eps);
-        float scale = (float)((double)gamma[c] * inv);
-        float shift = (float)((double)beta[c] - mean * (double)gamma[c] * inv);
+        float scale = (float)((double)gam * inv);
+        float shift = (float)((double)bet - mean * (double)gam * inv);
         ss[((size_t)n * C + c) * 2 + 0] = scale;
         ss[((size_t)n * C + c) * 2 + 1] = shift;
         if (ss16) {  // packed fp16 copy for k_conv_ws: per channel pair {s_c, s_c+1, t_c, t_c+1}
@@ -1213,8 +1223,12 @@ __global__ __launch_bounds__(256) void k_norm_finalize(float* __restrict__ parti
 int launch_norm_finalize(boa_ctx* ctx, float* partials, int nblk, int N, int C, double count,
                          const float* gamma, const float* beta, float eps, float* ss_out, unsigned* ss16_out, int clear) {
     KernelTimer tm(ctx, BOA_K_NORM_FINALIZE, 0, (double)N * C * nblk * 8.0);
-    hipLaunchKernelGGL(k_norm_finalize, dim3(C, N), dim3(256), 0, ctx->stream, partials, nblk, C, count, clear, gamma,
-                       beta, eps, ss_out, (unsigned short*)ss16_out);
+    if (nblk <= 64)
+        hipLaunchKernelGGL(k_norm_finalize<64>, dim3(C, N), dim3(64), 0, ctx->stream, partials, nblk, C, count, clear, gamma,
+                           beta, eps, ss_out, (unsigned short*)ss16_out);
+    else
+        hipLaunchKernelGGL(k_norm_finalize<256>, dim3(C, N), dim3(256), 0, ctx->stream, partials, nblk, C, count, clear, gamma,
+                           beta, eps, ss_out, (unsigned short*)ss16_out);
     tm.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
