@@ -237,7 +237,12 @@ int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume, const int
  * the lower rank's partial sums for those planes into acc / n (they were received over RCCL/xGMI) and then calls
  * boa_net_apply_deferred, which adds the stashed planes in the original tile order -- per voxel the fp16 `+=` sequence
  * is the reference's (predict_from_raw_data.py:611-614), so the result is bit-identical to the single-GPU loop.
- * The head weights must still be those of the same fold when the stash is applied. */
+ * The stash remembers the head weights of the fold that produced it (it may be applied after the network switched folds).
+ * acc / n must be zero on entry in the planes this rank's tiles cover: when the network and tile grid qualify
+ * (boa_net_labels_supported) the non-deferred planes are WRITTEN by one gather-head launch (raw partial sums, all covering
+ * tiles of this rank in ascending order) and boa_net_apply_deferred is one more launch of that kernel over the deferred
+ * planes, started from the planes' contents; otherwise both run the per-tile scatter head.  With host_defer_planes all
+ * zero this is the single-GPU accumulate loop in its gather form (the resampled label path uses it that way). */
 typedef struct boa_stash boa_stash;
 int boa_net_predict_sliding_window_deferred(boa_net* net, const float* dev_volume, const int V[3], const int PV[3],
                                             const int* vol_off, const int* host_origins, int n_tiles,
