@@ -461,7 +461,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     for (int gq = 0; gq < 4; ++gq) {
                         unsigned ol = ((unsigned)srel0 * 32u + (unsigned)kh * 16u) + (unsigned)gq * ((unsigned)out_vox * 32u);
                         asm volatile("" : "+v"(ol));
+#ifndef WS_TEMPORAL_STORES
+                        __builtin_nontemporal_store(f32x4_t{v[gq * 4 + 0], v[gq * 4 + 1], v[gq * 4 + 2], v[gq * 4 + 3]}, (WS_GLOBAL f32x4_t*)(dst + ol));
+#else
                         *(WS_GLOBAL f32x4_t*)(dst + ol) = f32x4_t{v[gq * 4 + 0], v[gq * 4 + 1], v[gq * 4 + 2], v[gq * 4 + 3]};
+#endif
                     }
                 }
                 continue;
@@ -493,8 +497,16 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 WS_GLOBAL unsigned char* dst = sgpr_ptr(p.out + (obase + (size_t)mrel * 16));
                 unsigned ol = olane;
                 asm volatile("" : "+v"(ol));  // keep the 32 -> 64 bit extension in this block (instruction selection is per block)
+#ifndef WS_TEMPORAL_STORES
+                // non-temporal stores: the layer's output is not read again before the launch ends, so it need not displace halo lines from
+                // the XCD's L2 (A/B on one box with tools/build_alt.sh, layers repeated at the power cap: 1 780 -> 1 767, 957 -> 946,
+                // 823 -> 817 us; bench step 1 820 -> 1 806 ms; the HBM-bound first conv measured 0 ... -10 % with them and keeps plain stores)
+                __builtin_nontemporal_store(u32x4_t{w[0], w[1], w[2], w[3]}, (WS_GLOBAL u32x4_t*)(dst + ol));
+                __builtin_nontemporal_store(u32x4_t{w[4], w[5], w[6], w[7]}, (WS_GLOBAL u32x4_t*)(dst + ol + 16));
+#else
                 *(WS_GLOBAL u32x4_t*)(dst + ol) = u32x4_t{w[0], w[1], w[2], w[3]};
                 *(WS_GLOBAL u32x4_t*)(dst + ol + 16) = u32x4_t{w[4], w[5], w[6], w[7]};
+#endif
             }
         }
     };
