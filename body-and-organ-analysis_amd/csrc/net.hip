@@ -1072,11 +1072,12 @@ struct boa_stash {
         int start[3];
     };
     std::vector<Item> items;
-    // gather form (boa_net_predict_sliding_window_deferred ran the gather head): the deferred planes of the block's first tile row in the
-    // gather head's own stash layout -- [tile][F / 16 planes][dp * P1 * P2 voxels][32 B], the (scale, shift) tables, the walk table -- so that
-    // boa_net_apply_deferred is ONE more k_gather_head launch over planes [x0, x0 + dp), started from the lower rank's sums
+    // gather form (boa_net_predict_sliding_window_deferred ran the gather head): the first dp planes of every deferring tile (the block's
+    // first tile row; with steps below half a patch also the rows behind it, which defer fewer planes) in the gather head's own stash
+    // layout -- [tile][F / 16 planes][dp * P1 * P2 voxels][32 B], the (scale, shift) tables, the walk table -- so that
+    // boa_net_apply_deferred is ONE more k_gather_head launch over planes [x0, x_split), started from the lower rank's sums
     bool gather = false, x3 = false;
-    int dp = 0, x0 = 0, n1 = 0, n2 = 0, n_items = 0;
+    int dp = 0, x0 = 0, x_split = 0, n0 = 0, n1 = 0, n2 = 0, n_items = 0;
     size_t o_ss = 0, o_ssp = 0, o_tab = 0;
 };
 
@@ -1138,7 +1139,11 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
     // lower rank's sums.  Same head arithmetic for every tile (the matrix-core head), whatever the tile origins' alignment.
     static const bool shard_scatter = getenv("BOA_SHARD_SCATTER") != nullptr;   // experiment hook: the round-3 scatter loop
     if (!shard_scatter && !f32 && n_tiles > 0 && boa_net_labels_supported(net, host_origins, n_tiles)) {
+        // dp0 = the deepest deferral (the block's first row); rows that start further up defer fewer planes -- actual steps below
+        // half a patch make the block's second row reach the lower block's last row too.  Every deferred tile keeps dp0 planes (the
+        // later rows more than they defer: valid planes of the tile, never visited by the launch over [x0, x_split)).
         int x_first = host_origins[0], x_split = -1, x_end = 0, dp0 = 0, x0 = 0, n_def = 0;
+        std::vector<int> def_rows;
         bool consistent = true;
         for (int i = 0; i < n_tiles; ++i) {
             const int xo = host_origins[(size_t)i * 3], dpi = host_defer_planes[i];
@@ -1148,9 +1153,10 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
                 if (n_def == 0) {
                     dp0 = dpi;
                     x0 = xo;
+                    x_split = xo + dpi;
                 }
-                consistent = consistent && dpi == dp0 && xo == x0;   // one row, one depth
-                x_split = xo + dpi;
+                consistent = consistent && xo + dpi == x_split && xo >= x0;   // all end at the same plane (canonical order: x0 first)
+                if (def_rows.empty() || def_rows.back() != xo) def_rows.push_back(xo);
                 ++n_def;
             }
         }
@@ -1176,13 +1182,19 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
             st->o_ss = align((size_t)n_def * item_act);
             st->o_ssp = align(st->o_ss + (size_t)n_def * F * 2 * sizeof(float));
             st->o_tab = align(st->o_ssp + (size_t)n_def * 32 * sizeof(unsigned));
-            const size_t gbytes = align(st->o_tab + ((size_t)1 + st->n1 + st->n2 + PV[0] + PV[1] + PV[2] / 32 + 8) * sizeof(int));
+            st->n0 = (int)def_rows.size();
+            st->x_split = x_split;
+            const size_t gbytes = align(st->o_tab + (def_rows.size() + st->n1 + st->n2 + PV[0] + PV[1] + PV[2] / 32 + 8) * sizeof(int));
             if (n_def > 0) {
                 if ((rc = boa_malloc(c, gbytes, (void**)&st->arena)) != BOA_OK) {
                     boa_stash_destroy(st);
                     return rc;
                 }
-                BOA_REQUIRE(n_def == st->n1 * st->n2, "deferred sliding window: %d deferred tiles in a row of %d x %d", n_def, st->n1, st->n2);
+                if (n_def != (int)def_rows.size() * st->n1 * st->n2) {
+                    boa_stash_destroy(st);
+                    boa_set_error("deferred sliding window: %d deferred tiles in %d rows of %d x %d", n_def, (int)def_rows.size(), st->n1, st->n2);
+                    return BOA_EINVAL;
+                }
                 bool ok_copy = true;
                 int item = 0;
                 const int nplanes = x3 ? F / 8 : F / 16;   // 32-byte records per voxel and plane in both layouts
@@ -1207,12 +1219,11 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
                 }
                 // walk table of the one-row tile grid with dp planes per tile
                 std::vector<int> tab;
-                tab.push_back(x0);
+                for (int v : def_rows) tab.push_back(v);
                 for (int v : ts.steps[1]) tab.push_back(v);
                 for (int v : ts.steps[2]) tab.push_back(v);
                 auto cover = [&](int a, int ext, int lo, int hi) {
-                    const std::vector<int> one = {x0};
-                    const std::vector<int>& stp = a == 0 ? one : ts.steps[a];
+                    const std::vector<int>& stp = a == 0 ? def_rows : ts.steps[a];
                     int first = 0, cnt = 0;
                     for (size_t k = 0; k < stp.size(); ++k)
                         if (stp[k] <= hi && stp[k] + ext > lo) {
@@ -1309,8 +1320,8 @@ extern "C" int boa_net_apply_deferred(boa_net* net, const boa_stash* st, const u
     if (st->gather) {
         if (st->n_items == 0) return BOA_OK;
         const int P[3] = {st->dp, d.patch[1], d.patch[2]};
-        const int ntile[3] = {1, st->n1, st->n2};
-        const int xr[2] = {st->x0, std::min(st->x0 + st->dp, PV[0])};
+        const int ntile[3] = {st->n0, st->n1, st->n2};
+        const int xr[2] = {st->x0, std::min(st->x_split, PV[0])};
         return launch_gather_head(net->ctx, (const __half*)st->arena, (const unsigned*)(st->arena + (st->x3 ? st->o_ss : st->o_ssp)), st->head_w, st->head_b,
                                   dev_gauss, d.num_classes, P, PV, ntile, (const int*)(st->arena + st->o_tab), dev_acc, 4, 1, nullptr, 0, nullptr, nullptr,
                                   nullptr, nullptr, d.lrelu_slope, st->n_items, st->x3, xr, dev_n, 1);

@@ -203,3 +203,64 @@ def test_gather_ties_and_small_class_counts(ctx, nc, precision):
         assert not (want == dst).any() or dst < src        # a duplicated higher class never wins a tie
     assert len(np.unique(want)) >= min(nc, 3) - 1
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "fp32"])
+@pytest.mark.parametrize("split_row", [None, 1, 2])
+def test_raw_partial_sums_equal_the_scatter_accumulators(ctx, precision, split_row):
+    """The gather head's raw mode (tile sharding, the resampled label path): the fp16 accumulator planes and the weight plane it writes
+    must be the scatter loop's, bit for bit (tile origins 8-aligned along z: both heads run on the matrix cores).  split_row = r plays
+    the tile-sharded protocol on one GPU: the tiles of the rows below r are accumulated first (the lower rank: its own raw launch),
+    then the upper block with the planes it shares with the lower block deferred, then boa_net_apply_deferred on top of the lower
+    block's sums -- the reference's per-voxel `+=` order (predict_from_raw_data.py:611-614) -- and the planes must again match."""
+    from boa_hip import sliding_window as sw
+    from boa_hip._lib import check, int3
+    patch, shape, nc = (32, 32, 32), (88, 48, 64), 6
+    p = _pred(ctx, patch, nc, 1, 0.5, True, precision=precision)
+    x = np.random.default_rng(5).standard_normal((1, *shape)).astype(np.float32)
+    V, PV, below, origins = p._setup(x)
+    origins = np.ascontiguousarray(origins, dtype=np.int32).reshape(-1, 3)
+    assert (origins[:, 2] % 8 == 0).all()
+    rows = sorted(set(int(v) for v in origins[:, 0]))
+    assert len(rows) >= 4
+    nvox = int(np.prod(PV))
+    dvol = ctx.from_numpy(x)
+    bufs = [ctx.alloc(nc * nvox * 2), ctx.alloc(nvox * 2), ctx.alloc(nc * nvox * 2), ctx.alloc(nvox * 2)]
+    acc_s, n_s, acc_g, n_g = bufs
+    try:
+        ctx.counters(reset=True)
+        p._run_fold(dvol, V, PV, below, origins, acc_s, n_s, 0)             # scatter loop
+        cs = ctx.counters(reset=True)
+        assert cs["head_gather"] == 0 and (cs["head_mfma"] > 0 or cs["x3"] > 0) and cs["head_valu"] == 0, cs
+        p._ensure_net(0)
+        acc_g.zero()
+        n_g.zero()
+        g = p._gaussian()
+
+        def run(tile_mask, defer):
+            org = np.ascontiguousarray(origins[tile_mask], dtype=np.int32)
+            d = np.ascontiguousarray(defer, dtype=np.int32)
+            st = C.c_void_p()
+            check(p.lib.boa_net_predict_sliding_window_deferred(
+                p._net, dvol.vp, int3(V), int3(PV), int3(below), org.ctypes.data_as(C.POINTER(C.c_int)), len(org),
+                g.vp if g else None, acc_g.vp, n_g.vp, d.ctypes.data_as(C.POINTER(C.c_int)), C.byref(st)), "deferred")
+            return st
+
+        if split_row is None:
+            p.lib.boa_stash_destroy(run(np.ones(len(origins), bool), np.zeros(len(origins))))
+        else:
+            lower = origins[:, 0] < rows[split_row]
+            hi = rows[split_row - 1] + patch[0]                              # end of the lower block's last row
+            p.lib.boa_stash_destroy(run(lower, np.zeros(int(lower.sum()))))
+            up = origins[~lower]
+            st = run(~lower, np.clip(hi - up[:, 0], 0, patch[0]))
+            check(p.lib.boa_net_apply_deferred(p._net, st, g.vp if g else None, acc_g.vp, n_g.vp, int3(PV)), "apply")
+            p.lib.boa_stash_destroy(st)
+        cg = ctx.counters(reset=True)
+        assert cg["head_gather"] == (1 if split_row is None else 3) and cg["head_mfma"] == 0 and cg["head_valu"] == 0, cg
+        np.testing.assert_array_equal(acc_g.download((nc, *PV), np.uint16), acc_s.download((nc, *PV), np.uint16))
+        np.testing.assert_array_equal(n_g.download(tuple(PV), np.uint16), n_s.download(tuple(PV), np.uint16))
+    finally:
+        for b in bufs + [dvol]:
+            b.free()
+        p.close()
