@@ -29,8 +29,11 @@
 // The accumulators enter a tile's first chunk holding the bias.
 // X3 (split-precision mode, see k_conv_ws): the chunk is 8 fp32 channels as hi / lo fp16 planes, the weight fragments come in
 // hi / lo pairs (lo = `lo_off` bytes behind hi in the packed array: the part stride Cout * 16) and every (plane, dx) pair is two MFMAs.
-template <int S, int RM, bool X3>
-__device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16 (&acc)[RM], f16x8 (&a)[3][3], f16x8 (&al)[X3 ? 3 : 1][3],
+// NR: slots of the weight ring (3 or 9: a divisor of the 9 groups, so the slot of a group does not depend on the chunk); group g + NR - 1 is
+// fetched while group g is consumed.  NR = 9 for the S = 2, RM = 2 instantiation: its groups are 6 MFMAs (192 cycles) long, two groups ahead
+// was less than an L2 round trip (BOA_WS_TRACE: 3 900 / 2 850 cycles per chunk of 54 MFMAs).
+template <int S, int RM, bool X3, int NR>
+__device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16 (&acc)[RM], f16x8 (&a)[NR][3], f16x8 (&al)[X3 ? NR : 1][3],
                                                 const WS_GLOBAL unsigned char* wb, unsigned vcur, unsigned vnext, unsigned gs, unsigned lo_off) {
     constexpr int NB = S * (RM - 1) + 3;
     constexpr int H1 = 3 * S + 3, H2 = 7 * S + 3;
@@ -54,11 +57,11 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
     __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
 #pragma unroll
     for (int g = 0; g < 9; ++g) {
-        const int slot = g % 3;
-        if (g + 2 < 9)
-            fetch_a(vcur, g + 2, (g + 2) % 3);
+        const int slot = g % NR;
+        if (g + NR - 1 < 9)
+            fetch_a(vcur, g + NR - 1, (g + NR - 1) % NR);
         else
-            fetch_a(vnext, g + 2 - 9, (g + 2) % 3);
+            fetch_a(vnext, g + NR - 1 - 9, (g + NR - 1) % NR);
         __builtin_amdgcn_sched_group_barrier(0x020, 3 * MM, 0);
 #pragma unroll
         for (int jj = 0; jj < NB; ++jj) {
@@ -323,10 +326,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
     const unsigned voff = X3 ? (unsigned)l31 * 16u : ((unsigned)kh * (unsigned)p.Cout + (unsigned)l31) * 16u;   // (X3: both k-halves read the same hi / lo fragments)
     const unsigned lo_off = (unsigned)p.Cout * 16u;
     auto woff = [&](int cc, int ch) -> unsigned { return voff + (unsigned)cc * 27u * gs + (unsigned)ch * 512u; };
-    f16x8 a[3][3];
-    f16x8 al[X3 ? 3 : 1][3];
+    constexpr int NR = (S == 2 && RM == 2 && !X3) ? 9 : 3;
+    f16x8 a[NR][3];
+    f16x8 al[X3 ? NR : 1][3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -334,10 +338,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
                 a[i][j][e] = (_Float16)0.f;
                 if (X3 || i == 0) al[X3 ? i : 0][j][e] = (_Float16)0.f;
             }
-    auto prime = [&](unsigned vchunk) {  // groups 0 and 1 of a chunk into ring slots 0 and 1
+    auto prime = [&](unsigned vchunk) {  // groups 0 .. NR - 2 of a chunk into their ring slots
         const WS_GLOBAL unsigned char* wb = sgpr_ptr(p.wpk);
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < NR - 1; ++g)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 unsigned vo = __umul24((unsigned)(g + 9 * dx), gs) + vchunk;
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
                 const WS_GLOBAL unsigned char* wb = sgpr_ptr(p.wpk);
                 const unsigned vcur = woff(cc, ch);
                 const unsigned vnext = cc + 1 < ncc ? woff(cc + 1, ch) : woff(0, ch_next);
-                consume_chunk_x<S, RM, X3>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
+                consume_chunk_x<S, RM, X3, NR>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
             }
             NS_STAMP(3);
             __syncthreads();
