@@ -502,7 +502,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 // the XCD's L2 (A/B on one box with tools/build_alt.sh, layers repeated at the power cap: 1 780 -> 1 767, 957 -> 946,
                 // 823 -> 817 us; bench step 1 820 -> 1 806 ms; the HBM-bound first conv measured 0 ... -10 % with them and keeps plain stores)
                 __builtin_nontemporal_store(u32x4_t{w[0], w[1], w[2], w[3]}, (WS_GLOBAL u32x4_t*)(dst + ol));
+#if defined(WS_ABL_STORE_HALF)        // ablation: half the bytes, half the store instructions
+#elif defined(WS_ABL_STORE_SAME)      // ablation: both instructions, the same bytes (half the HBM bytes, all the requests)
+                __builtin_nontemporal_store(u32x4_t{w[4], w[5], w[6], w[7]}, (WS_GLOBAL u32x4_t*)(dst + ol));
+#else
                 __builtin_nontemporal_store(u32x4_t{w[4], w[5], w[6], w[7]}, (WS_GLOBAL u32x4_t*)(dst + ol + 16));
+#endif
 #else
                 *(WS_GLOBAL u32x4_t*)(dst + ol) = u32x4_t{w[0], w[1], w[2], w[3]};
                 *(WS_GLOBAL u32x4_t*)(dst + ol + 16) = u32x4_t{w[4], w[5], w[6], w[7]};
