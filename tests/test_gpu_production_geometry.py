@@ -76,6 +76,14 @@ def _compare(ctx, cfg, blob, net, vol, origins, tag):
             assert np.isfinite(got[i]).all()
             assert err <= err_bar * rng_, (prec, err, rng_)
             assert flips <= flip_bar, (prec, flips)
+            # where the flips sit: a label can only change where the oracle's winner leads its runner-up by less than twice the
+            # logit error (near-ties of the random head), never on a confident voxel
+            flipped = got[i].argmax(0) != ref.argmax(0)
+            if flipped.any():
+                top2 = np.partition(ref, -2, axis=0)[-2:]
+                worst = float((top2[1] - top2[0])[flipped].max())
+                print(f"{tag} {prec} tile {i}: largest oracle top-2 margin of a flipped voxel {worst / rng_:.3g} of the range")
+                assert worst <= 2.0 * err + 1e-6 * rng_, (prec, worst, err)
         out[prec] = got
     return out
 
