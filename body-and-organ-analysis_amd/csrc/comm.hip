@@ -13,6 +13,7 @@
 #include <string.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <string>
 
 #include "common.h"
@@ -87,6 +88,27 @@ struct boa_comm {
             return BOA_EHIP;                                                                                    \
         }                                                                                                       \
     } while (0)
+
+// Inside an open ncclGroupStart / ncclGroupEnd pair a failing call must close the group before returning: an open group on this
+// thread would swallow every later RCCL call of the process (the other ranks' matching collectives then hang).
+#define BOA_NCCL_GROUP_TRY(expr)                                                                                \
+    do {                                                                                                        \
+        ncclResult_t _r = (expr);                                                                               \
+        if (_r != ncclSuccess) {                                                                                \
+            (void)R->GroupEnd();                                                                                \
+            (void)fence_out(c);   /* ev_out stays recordable: a later boa_comm_wait must not wait on a stale event */ \
+            boa_set_error("%s failed: %s (%s:%d)", #expr, R->GetErrorString ? R->GetErrorString(_r) : "?", __FILE__, __LINE__); \
+            return BOA_EHIP;                                                                                    \
+        }                                                                                                       \
+    } while (0)
+
+// Messages per direction in one ncclGroup of the point-to-point exchanges ($BOA_COMM_GROUP, default 8; 0 = everything in one group).
+// Every sub-group holds the sends AND the receives of the same piece indices, so the pairs of a sub-group match on both sides of every
+// boundary and the ranks walk the sub-groups in the same order: a line of neighbour exchanges has no cycle, whatever the group size.
+static int comm_group_msgs() {
+    static const int g = getenv("BOA_COMM_GROUP") ? atoi(getenv("BOA_COMM_GROUP")) : 8;
+    return g > 0 ? g : (1 << 30);
+}
 
 extern "C" int boa_comm_available(void) { return rccl() ? 1 : 0; }
 
@@ -187,15 +209,23 @@ extern "C" int boa_comm_exchange(boa_comm* c, int dst, const void* const* send_p
                                  void* const* recv_ptrs, const size_t* recv_bytes, int n_recv) {
     BOA_REQUIRE(c && n_send >= 0 && n_recv >= 0 && dst < c->world && src < c->world,
                 "boa_comm_exchange: bad argument");
+    BOA_REQUIRE(dst < 0 || n_send == 0 || (send_ptrs && send_bytes), "boa_comm_exchange: NULL send arrays");
+    BOA_REQUIRE(src < 0 || n_recv == 0 || (recv_ptrs && recv_bytes), "boa_comm_exchange: NULL receive arrays");
+    for (int i = 0; dst >= 0 && i < n_send; ++i) BOA_REQUIRE(send_ptrs[i] || send_bytes[i] == 0, "boa_comm_exchange: send piece %d is NULL", i);
+    for (int i = 0; src >= 0 && i < n_recv; ++i) BOA_REQUIRE(recv_ptrs[i] || recv_bytes[i] == 0, "boa_comm_exchange: receive piece %d is NULL", i);
     Rccl* R = rccl();
     BOA_TRY(fence_in(c));
-    BOA_NCCL_TRY(R->GroupStart());
-    for (int i = 0; dst >= 0 && i < n_send; ++i) {
-        BOA_NCCL_TRY(R->Send(send_ptrs[i], send_bytes[i], ncclUint8, dst, c->comm, c->stream));
-        c->bytes += (long long)send_bytes[i];
+    const int ns = dst >= 0 ? n_send : 0, nr = src >= 0 ? n_recv : 0, G = comm_group_msgs();
+    for (int g0 = 0; g0 < std::max(ns, nr); g0 += std::min(G, std::max(ns, nr))) {
+        const int g1 = g0 + std::min(G, std::max(ns, nr) - g0);
+        BOA_NCCL_TRY(R->GroupStart());
+        for (int i = g0; i < std::min(g1, ns); ++i) {
+            BOA_NCCL_GROUP_TRY(R->Send(send_ptrs[i], send_bytes[i], ncclUint8, dst, c->comm, c->stream));
+            c->bytes += (long long)send_bytes[i];
+        }
+        for (int i = g0; i < std::min(g1, nr); ++i) BOA_NCCL_GROUP_TRY(R->Recv(recv_ptrs[i], recv_bytes[i], ncclUint8, src, c->comm, c->stream));
+        BOA_NCCL_TRY(R->GroupEnd());
     }
-    for (int i = 0; src >= 0 && i < n_recv; ++i) BOA_NCCL_TRY(R->Recv(recv_ptrs[i], recv_bytes[i], ncclUint8, src, c->comm, c->stream));
-    BOA_NCCL_TRY(R->GroupEnd());
     c->calls++;
     return fence_out(c);
 }
@@ -212,23 +242,22 @@ extern "C" int boa_comm_shift_slab(boa_comm* c, int dst, int send_lo, int send_h
     BOA_REQUIRE(dst < 0 || (send_lo >= 0 && send_lo < send_hi && send_hi <= PV[0]), "boa_comm_shift_slab: send planes [%d, %d)", send_lo, send_hi);
     BOA_REQUIRE(src < 0 || (recv_lo >= 0 && recv_lo < recv_hi && recv_hi <= PV[0]), "boa_comm_shift_slab: recv planes [%d, %d)", recv_lo, recv_hi);
     BOA_TRY(fence_in(c));
-    BOA_NCCL_TRY(R->GroupStart());
-    if (dst >= 0) {
-        const size_t n = (size_t)(send_hi - send_lo) * plane;
-        for (int k = 0; k <= C; ++k) {
+    const size_t n_s = dst >= 0 ? (size_t)(send_hi - send_lo) * plane : 0, n_r = src >= 0 ? (size_t)(recv_hi - recv_lo) * plane : 0;
+    const int G = comm_group_msgs();
+    for (int k0 = 0; k0 <= C; k0 += std::min(G, C + 1)) {   // plane k = class k, plane C = the weight plane n
+        const int k1 = std::min(C + 1, k0 + std::min(G, C + 1));
+        BOA_NCCL_TRY(R->GroupStart());
+        for (int k = k0; dst >= 0 && k < k1; ++k) {
             const uint16_t* p = k < C ? acc + (size_t)k * vv + (size_t)send_lo * plane : nacc + (size_t)send_lo * plane;
-            BOA_NCCL_TRY(R->Send(p, n, ncclFloat16, dst, c->comm, c->stream));
+            BOA_NCCL_GROUP_TRY(R->Send(p, n_s, ncclFloat16, dst, c->comm, c->stream));
         }
-        c->bytes += (long long)(n * 2 * (C + 1));
-    }
-    if (src >= 0) {
-        const size_t n = (size_t)(recv_hi - recv_lo) * plane;
-        for (int k = 0; k <= C; ++k) {
-            uint16_t* p = recv_stage ? recv_stage + (size_t)k * n : (k < C ? acc + (size_t)k * vv + (size_t)recv_lo * plane : nacc + (size_t)recv_lo * plane);
-            BOA_NCCL_TRY(R->Recv(p, n, ncclFloat16, src, c->comm, c->stream));
+        for (int k = k0; src >= 0 && k < k1; ++k) {
+            uint16_t* p = recv_stage ? recv_stage + (size_t)k * n_r : (k < C ? acc + (size_t)k * vv + (size_t)recv_lo * plane : nacc + (size_t)recv_lo * plane);
+            BOA_NCCL_GROUP_TRY(R->Recv(p, n_r, ncclFloat16, src, c->comm, c->stream));
         }
+        BOA_NCCL_TRY(R->GroupEnd());
     }
-    BOA_NCCL_TRY(R->GroupEnd());
+    c->bytes += (long long)(n_s * 2 * (C + 1));
     c->calls++;
     return fence_out(c);
 }

@@ -247,6 +247,11 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
                 const unsigned tile = tile_n, gsel = gsel_n;
                 const bool in = in_n != 0;
                 const bool more = pi + 1 < np;
+                // The DMAs issued next overwrite buffer (pi + 1) & 1 = the buffer pair pi - 1's ordinary LDS reads came from.  The DMA asm
+                // statements name no memory operand, so this compiler-only barrier is what keeps those reads (program order: previous
+                // iteration) in front of them; the hardware side is in order by itself (the reads' values were consumed by that
+                // iteration's MFMAs).  The walk tables live in the constant address space and are not pinned by it.
+                asm volatile("" ::: "memory");
                 if (more) issue((pi + 1) & 1, tile_n, in_n, gsel_n);
                 // the DMAs of pair pi are older than the (2 + GAUSS) of pair pi + 1: in-order completion
                 if (more)

@@ -911,6 +911,17 @@ struct TileStash {
 };
 
 
+// Keeps the context's tile stash out of boa_trim's reach (an allocation that fails under memory pressure trims, and a trim frees an
+// idle stash) from before the tiles are written until the LAST consumer of the TileStash pointers -- the deferred planes' copies, the
+// gather head launch -- is queued on the stream; a later trim synchronises the stream before it frees anything.
+struct StashHold {
+    boa_ctx* c;
+    explicit StashHold(boa_ctx* ctx) : c(ctx) { c->stash_busy = true; }
+    ~StashHold() { c->stash_busy = false; }
+    StashHold(const StashHold&) = delete;
+    StashHold& operator=(const StashHold&) = delete;
+};
+
 // runs the conv stack over all tiles (batches of max_batch), the last decoder conv writing straight into the stash slots of its tiles, and
 // builds the gather head's walk table.  BOA_ENOMEM when the stash does not fit (the caller falls back to the scatter form).
 static int net_forward_into_stash(boa_net* net, const float* dev_volume, const int V[3], const int PV[3], const int* off, const int* host_origins,
@@ -966,7 +977,8 @@ static int net_forward_into_stash(boa_net* net, const float* dev_volume, const i
     float* keep_ss = last.ss;
     unsigned* keep_ss16 = last.ss16;
     int rc = BOA_OK;
-    c->stash_busy = true;   // (boa_trim must not release the stash while tiles are being written into it)
+    // (the caller holds c->stash_busy -- StashHold -- until every use of the returned pointers has been queued: boa_trim must not
+    //  release the stash while tiles are being written into it, nor between this call and the caller's copies / gather launch)
     for (int t0 = 0; t0 < n_tiles && rc == BOA_OK; t0 += net->maxN) {
         const int nb = std::min(net->maxN, n_tiles - t0);
         // the last decoder conv of this batch writes straight into the stash slots of its tiles
@@ -982,7 +994,6 @@ static int net_forward_into_stash(boa_net* net, const float* dev_volume, const i
     last.out32 = keep_out32;
     last.ss = keep_ss;
     last.ss16 = keep_ss16;
-    c->stash_busy = false;   // (everything that uses it from here on is queued on the stream: a trim synchronises first)
     if (rc) return rc;
     if (!x3) BOA_TRY(launch_pack_head_ss(c, s_ss, s_ssp, n_tiles));
     // walk table: tile origins per axis, then per coordinate the first covering tile and the count (x, y), per 32-voxel z run the
@@ -1039,6 +1050,7 @@ extern "C" int boa_net_predict_labels_fold(boa_net* net, const float* dev_volume
         BOA_REQUIRE(PV[a] >= d.patch[a] && off[a] >= 0 && off[a] + V[a] <= PV[a],
                     "fused sliding window: padded dim %d (%d) must cover patch (%d) and volume (%d at %d)", a, PV[a], d.patch[a], V[a], off[a]);
     TileStash ts;
+    StashHold hold(net->ctx);   // until launch_gather_head below is queued
     BOA_TRY(net_forward_into_stash(net, dev_volume, V, PV, off, host_origins, n_tiles, ts));
     float* s_ss = ts.ss;
     unsigned* s_ssp = ts.ssp;
@@ -1166,6 +1178,7 @@ extern "C" int boa_net_predict_sliding_window_deferred(boa_net* net, const float
             consistent = consistent && host_defer_planes[i] == below;
         }
         TileStash ts;
+        StashHold hold(net->ctx);   // across the arena allocation below (it may trim), the stash copies and the raw gather launch
         int grc = consistent ? net_forward_into_stash(net, dev_volume, V, PV, off, host_origins, n_tiles, ts) : BOA_ENOMEM;
         if (grc == BOA_OK) {
             boa_ctx* c = net->ctx;
