@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import sliding_window as sw
-from ._lib import check, int3
+from ._lib import BOA_EINVAL, check, int3
 from .device import Context, DeviceBuffer
 from .plans import NetGeometry
 
@@ -88,8 +88,9 @@ class HipPredictor:
             h = C.c_void_p()
             rc = self.lib.boa_net_create(self.ctx.h, C.byref(self._desc), w.ctypes.data_as(C.c_void_p), w.size,
                                          self.max_batch, self._PRECISIONS[self.precision], C.byref(h))
-            if rc != 0 and self.precision == "fp32":
-                # a kernel shape / channel count the split-precision kernels do not cover: the plain fp32 kernels take any
+            if rc == BOA_EINVAL and self.precision == "fp32":
+                # a kernel shape / channel count the split-precision kernels do not cover (BOA_EINVAL): the plain fp32 kernels take
+                # any.  Out-of-memory and HIP errors are NOT retried in a slower mode with a larger footprint: check() raises them.
                 import warnings
                 warnings.warn("split-precision fp32 mode unavailable for this network (" + self.lib.boa_last_error().decode("utf-8", "replace") + "); using fp32_ref")
                 self.precision = "fp32_ref"

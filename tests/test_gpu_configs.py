@@ -56,19 +56,24 @@ def test_config0_total_fast_128_dropin_vs_oracle(tmp_path, monkeypatch):
     agree = float((got == want).mean())
     print("configs[0] total_fast 128^3 label agreement with the oracle pipeline", agree, "labels", len(np.unique(got)))
     assert agree >= 0.993   # measured 0.9964;           # 118 classes of a random-weight fp16 net; every other step is exact
-    # the same call in the fp32 modes ($BOA_NET_PRECISION=fp32: the reference's CPU arithmetic in split precision on the matrix
-    # cores; fp32_ref: plain fp32 MFMAs): the label file of the CPU path up to fp32 summation-order near-ties.  The network runs at
-    # 3 mm (64^3) and its labels are upsampled by exactly 2 per axis (nearest), so one flipped network voxel is 8 file voxels: the
-    # bar is 2e-5 of the NETWORK's voxels (the bar of tests/test_gpu_production_geometry.py; 118 classes make near-ties ~5x as
-    # likely as the 25 classes there)
+    # the same call in the fp32 modes: the label file of the CPU path up to fp32 summation-order near-ties.  The network runs at
+    # 3 mm (64^3) and its labels are upsampled by exactly 2 per axis (nearest), so one flipped network voxel is 8 file voxels.
+    #   fp32_ref (plain fp32 MFMAs, the cross-check mode): the contract bar, flips <= 1e-5 of the FILE's voxels (20 file voxels =
+    #       2 network voxels at this size).
+    #   fp32 ($BOA_NET_PRECISION=fp32 = the split-precision mode on the f16 matrix cores, INTEGRATION.md "precision modes"): the
+    #       same arithmetic contract evaluated with another summation grouping; measured 2-4 flipped network voxels of 262 144 over
+    #       boxes and builds (118 classes make top-2 near-ties ~5x as likely as the 25 classes of
+    #       tests/test_gpu_production_geometry.py, whose 2e-5 bar this is): 2e-5 of the NETWORK's voxels = 5.
+    bars = {"fp32_ref": max(8, 1e-5 * want.size), "fp32": max(8, 2e-5 * (want.size / 8) * 8)}
     for prec in ("fp32", "fp32_ref"):
         monkeypatch.setenv("BOA_NET_PRECISION", prec)
         out32 = tmp_path / f"seg_{prec}"
         compute_all_models(ct_path, out32, "total", params)
         got32, _, _ = nifti.load(out32 / "total.nii.gz")
         flips = int((got32 != want).sum())
-        print(f"configs[0] {prec} mode: label flips", flips, "of", want.size, "=", flips / 8, "network voxels of", want.size // 8)
-        assert flips / 8 <= max(1, 2e-5 * want.size / 8)
+        print(f"configs[0] {prec} mode: label flips", flips, "of", want.size, "=", flips / 8, "network voxels of", want.size // 8,
+              "bar", bars[prec])
+        assert flips <= bars[prec]
 
 
 def _bca_models(folds):
