@@ -98,6 +98,14 @@ _PROTOS = {
     "boa_mask_assign": (i32, [vp, vp, u64, i32, i32, vp]),
     "boa_label_overlay": (i32, [vp, vp, u64, vp]),
     "boa_median3_inplane": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "boa_bits_words": (u64, [i32, i32, i32]),
+    "boa_bits_select": (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
+    "boa_bits_unpack": (i32, [vp, vp, i32, i32, i32, vp]),
+    "boa_bits_fill_supported": (i32, [i32, i32]),
+    "boa_bits_fill_holes_2d": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "boa_bits_remove_small": (i32, [vp, vp, i32, i32, i32, i32, C.c_uint32, i32]),
+    "boa_bits_filter_largest": (i32, [vp, vp, i32, i32, i32, vp, i32]),
+    "boa_bits_assign_labels": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     "boa_copy3": (i32, [vp, vp, i32, C.c_longlong, C.POINTER(C.c_longlong), ip, vp, i32, C.c_longlong, C.POINTER(C.c_longlong)]),
     "boa_nonzero_bbox": (i32, [vp, vp, i32, ip, ip]),
     "boa_resample_cubic": (i32, [vp, vp, i32, ip, vp, i32, ip]),

@@ -319,8 +319,48 @@ def postprocess_region_segmentation(ctx: Context, seg: np.ndarray) -> np.ndarray
         d_seg.free()
 
 
+def _morph_bytes() -> bool:
+    import os
+    return os.environ.get("BOA_MORPH_BYTES", "") not in ("", "0")
+
+
+def _lut(values=None, positive=False):
+    """256-entry membership table for boa_bits_select: bit 0 set for the label values of the mask."""
+    lut = np.zeros(256, np.uint8)
+    if positive:
+        lut[1:] = 1
+    else:
+        for v in values:
+            lut[int(v)] = 1
+    return lut
+
+
 def postprocess_region_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shape) -> None:
-    """In place on a resident uint8 (z,y,x) label buffer."""
+    """In place on a resident uint8 (z,y,x) label buffer.  The four filters of BCA/body_regions/postprocess.py:18-40 depend on each
+    other through `seg_data` (a voxel set to 255 leaves the later masks), so they run one after the other -- each on a bit mask
+    (csrc/ccl_bits.hip): select (1 B per voxel read), component labelling on tiles (uniform tiles cost nothing), one byte written per
+    removed voxel."""
+    if _morph_bytes():
+        return _postprocess_region_segmentation_device_bytes(ctx, d_seg, shape)
+    Z, Y, X = (int(v) for v in shape)
+    d_bits = ctx.alloc(int(ctx.lib.boa_bits_words(Z, Y, X)) * 4)
+
+    def run(lut):
+        check(ctx.lib.boa_bits_select(ctx.h, d_seg.vp, Z, Y, X, lut.ctypes.data_as(C.c_void_p), 1, d_bits.vp), "boa_bits_select")
+        check(ctx.lib.boa_bits_filter_largest(ctx.h, d_bits.vp, Z, Y, X, d_seg.vp, 255), "boa_bits_filter_largest")
+
+    try:
+        run(_lut(positive=True))
+        run(_lut((REGION["THORACIC_CAVITY"], REGION["MEDIASTINUM"], REGION["PERICARDIUM"])))
+        run(_lut((REGION["PERICARDIUM"],)))
+        run(_lut((REGION["ABDOMINAL_CAVITY"],)))
+    finally:
+        d_bits.free()
+
+
+def _postprocess_region_segmentation_device_bytes(ctx: Context, d_seg: DeviceBuffer, shape) -> None:
+    """The byte-mask form (boa_label_select / boa_ccl26 / boa_ccl_filter_largest per mask): the cross-check of the bit-mask path
+    ($BOA_MORPH_BYTES=1) and what the z-slab sharded variant below is built from."""
     shape = tuple(int(v) for v in shape)
     n = int(np.prod(shape))
     d_mask = ctx.alloc(n)
@@ -450,8 +490,51 @@ def _fill_holes_2d_cropped(ctx: Context, d_mask: DeviceBuffer, shape, d_i32: Dev
     DevArray(ctx, d_s2, (cz, cy, cx), np.uint8).copy_to(DevArray(ctx, d_out, (Z, Y, X), np.uint8).box(box))
 
 
-def postprocess_part_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shape, threshold: int = 3000) -> DeviceBuffer:
-    """Resident uint8 (z,y,x) labels -> new resident buffer with the cleaned labels."""
+def postprocess_part_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shape, threshold: int = 3000, labels=None) -> DeviceBuffer:
+    """Resident uint8 (z,y,x) labels -> new resident buffer with the cleaned labels.
+
+    The per-label passes of remove_small_labeled_objects (BCA/body_parts/postprocess.py:27-50) all start from the ORIGINAL volume
+    (`label_mask = mask == label`) and only meet at `out[filled] = label`, so the labels are one batch of bit masks
+    (csrc/ccl_bits.hip): one select pass, one slice-wise contour fill launch over (label, slice), the small-object and the
+    small-hole filter as two batched component labellings, one assign pass in which the largest label that holds a voxel wins (the
+    reference's ascending overwrite order).  `labels`: the label values to process (absent ones are harmless: an empty mask stays
+    empty and its complement is one large component); None asks the device which labels occur (one small synchronous read)."""
+    shape = tuple(int(v) for v in shape)
+    Z, Y, X = shape
+    if _morph_bytes() or not ctx.lib.boa_bits_fill_supported(Y, X):
+        return _postprocess_part_segmentation_device_bytes(ctx, d_seg, shape, threshold)
+    n = Z * Y * X
+    if labels is None:
+        labels = np.flatnonzero(slice_label_presence(ctx, d_seg, shape).any(axis=0))
+    labels = sorted(int(v) for v in labels if int(v) > 0)
+    words = int(ctx.lib.boa_bits_words(Z, Y, X))
+    d_out = ctx.zeros(n)
+    try:
+        for b0 in range(0, len(labels), 8):          # batches of 8 masks (one byte of membership bits per label value), ascending
+            batch = labels[b0:b0 + 8]
+            m = len(batch)
+            lut = np.zeros(256, np.uint8)
+            for j, v in enumerate(batch):
+                lut[v] = 1 << j
+            d_a, d_b = ctx.alloc(words * 4 * m), ctx.alloc(words * 4 * m)
+            try:
+                check(ctx.lib.boa_bits_select(ctx.h, d_seg.vp, Z, Y, X, lut.ctypes.data_as(C.c_void_p), m, d_a.vp), "boa_bits_select")
+                check(ctx.lib.boa_bits_fill_holes_2d(ctx.h, d_a.vp, Z, Y, X, m, d_b.vp), "boa_bits_fill_holes_2d")
+                check(ctx.lib.boa_bits_remove_small(ctx.h, d_b.vp, Z, Y, X, m, threshold - 1, 0), "boa_bits_remove_small")   # small objects
+                check(ctx.lib.boa_bits_remove_small(ctx.h, d_b.vp, Z, Y, X, m, threshold - 1, 1), "boa_bits_remove_small")   # small holes
+                lab = np.asarray(batch, np.uint8)
+                check(ctx.lib.boa_bits_assign_labels(ctx.h, d_b.vp, Z, Y, X, m, lab.ctypes.data_as(C.c_void_p), d_out.vp), "boa_bits_assign_labels")
+            finally:
+                d_a.free()
+                d_b.free()
+        return d_out
+    except Exception:
+        d_out.free()
+        raise
+
+
+def _postprocess_part_segmentation_device_bytes(ctx: Context, d_seg: DeviceBuffer, shape, threshold: int = 3000) -> DeviceBuffer:
+    """The byte-mask form, one label after the other ($BOA_MORPH_BYTES=1, and slices too large for the LDS flood of the bit path)."""
     shape = tuple(int(v) for v in shape)
     Z, Y, X = shape
     n = Z * Y * X

@@ -127,7 +127,10 @@ class BcaPipelineHip:
             zyx = d_raw.transpose((2, 1, 0)).contiguous(force_copy=True)
             d_raw.free()
             if task_name == "body_parts":
-                buf = bca.postprocess_part_segmentation_device(ctx, zyx.buf, zyx.shape)
+                # (the network's label values are known from its class count: no presence query, no host round trip)
+                task = self.tasks.get(task_name) if raw is None else None
+                labels = range(1, int(task.parts[0][1].geometry.num_classes)) if task is not None and not task.multimodel else None
+                buf = bca.postprocess_part_segmentation_device(ctx, zyx.buf, zyx.shape, labels=labels)
                 zyx.free()
                 zyx = DevArray(ctx, buf, zyx.shape, np.uint8)
             elif task_name == "body_regions":

@@ -47,3 +47,107 @@ def total_part_models(patch=(128, 128, 128), features=(32, 64, 128, 256, 320, 32
         sd = plans.synthetic_state_dict(cfg.geometry, seed=tid)
         out.append((tid, cfg, plans.weight_blob_from_state_dict(cfg.geometry, sd), (pj, dj, sd)))
     return out
+
+
+# ---- structured label phantoms ("a structured phantom (nested ellipsoids -> 117 labels) so histograms are
+# non-degenerate") -- label volumes with the TOPOLOGY of real segmentations (a few large compact components per label, nesting,
+# smooth boundaries, background around the body) for the aggregation / morphology benchmarks.  The argmax of a random-weight net is
+# noise-like (millions of components): the worst case of every component filter and nothing a real volume looks like
+# (BOA/compute/measurements.py:203-241, BCA/body_parts/postprocess.py:7-52, BCA/body_regions/postprocess.py:8-40 all see compact
+# organs).  Array order (x, y, z) like ct_phantom; deterministic (seeded), generated slab-wise.
+def _norm_coords(shape, x0, x1):
+    X, Y, Z = shape
+    xx = ((np.arange(x0, x1, dtype=np.float32) + 0.5) / X * 2 - 1)[:, None, None]
+    yy = ((np.arange(Y, dtype=np.float32) + 0.5) / Y * 2 - 1)[None, :, None]
+    zz = ((np.arange(Z, dtype=np.float32) + 0.5) / Z * 2 - 1)[None, None, :]
+    return xx, yy, zz
+
+
+def label_phantom_total(shape, n_labels=117, seed=20260929):
+    """uint8 (x, y, z): `n_labels` organs = ellipsoids inside the body ellipse of ct_phantom, painted from the largest to the smallest
+    so that small structures sit inside / on top of large ones (nested); ~45 % of the volume is labelled, every label is one compact
+    component of 1e-4 ... 3e-2 of the volume."""
+    X, Y, Z = shape
+    rng = np.random.default_rng(seed)
+    n = int(n_labels)
+    # radii (fractions of the half extents) from large organs to small vessels / vertebrae; centres inside the body ellipse
+    rad = np.sort(rng.uniform(0.03, 1.0, n) ** 2.2)[::-1] * 0.42 + 0.035
+    cen = np.empty((n, 3), np.float32)
+    k = 0
+    while k < n:
+        c = rng.uniform(-0.8, 0.8, 3)
+        if (c[0] / 0.9) ** 2 + (c[1] / 0.8) ** 2 < 0.75:
+            cen[k] = c
+            k += 1
+    asp = rng.uniform(0.6, 1.6, (n, 3)).astype(np.float32)
+    order = rng.permutation(n) + 1                     # label values are not sorted by size
+    out = np.zeros(shape, np.uint8)
+    for x0 in range(0, X, 32):
+        x1 = min(X, x0 + 32)
+        xx, yy, zz = _norm_coords(shape, x0, x1)
+        body = (xx / 0.9) ** 2 + (yy / 0.8) ** 2 < 1.0
+        slab = np.zeros((x1 - x0, Y, Z), np.uint8)
+        for i in range(n):
+            r = rad[i] * asp[i]
+            if abs(cen[i, 0] - (x0 + x1) / X + 1) > r[0] + 32.0 / X + 1e-3:
+                continue
+            m = ((xx - cen[i, 0]) / r[0]) ** 2 + ((yy - cen[i, 1]) / r[1]) ** 2 + ((zz - cen[i, 2]) / r[2]) ** 2 < 1.0
+            slab[m & body] = order[i]
+        for i in range(n):      # a small core of every organ survives whatever was painted over it: all n labels occur
+            m = (xx - cen[i, 0]) ** 2 + (yy - cen[i, 1]) ** 2 + (zz - cen[i, 2]) ** 2 < 0.03 ** 2
+            slab[m] = order[i]
+        out[x0:x1] = slab
+    return out
+
+
+def label_phantom_parts(shape):
+    """uint8 (x, y, z) body_parts labels (BCA/body_parts/definition.py:4-11): torso 1, head 2, legs 3 / 4, arms 5 / 6 -- z is the
+    body axis (head at high z), x left-right."""
+    X, Y, Z = shape
+    out = np.zeros(shape, np.uint8)
+    for x0 in range(0, X, 32):
+        x1 = min(X, x0 + 32)
+        xx, yy, zz = _norm_coords(shape, x0, x1)
+        slab = np.zeros((x1 - x0, Y, Z), np.uint8)
+        torso = ((xx / 0.55) ** 2 + (yy / 0.45) ** 2 < 1.0) & (zz > -0.25) & (zz < 0.62)
+        head = (xx / 0.28) ** 2 + (yy / 0.32) ** 2 + ((zz - 0.8) / 0.2) ** 2 < 1.0
+        neck = ((xx / 0.14) ** 2 + (yy / 0.14) ** 2 < 1.0) & (zz >= 0.6) & (zz < 0.7)
+        for s, lab in ((-1, 3), (1, 4)):
+            leg = (((xx - s * 0.27) / 0.2) ** 2 + (yy / 0.22) ** 2 < 1.0) & (zz <= -0.25)
+            slab[leg] = lab
+        for s, lab in ((-1, 5), (1, 6)):
+            arm = (((xx - s * 0.75) / 0.13) ** 2 + (yy / 0.15) ** 2 < 1.0) & (zz > -0.35) & (zz < 0.55)
+            slab[arm] = lab
+        slab[torso] = 1
+        slab[head | neck] = 2
+        out[x0:x1] = slab
+    return out
+
+
+def label_phantom_regions(shape):
+    """uint8 (x, y, z) body_regions labels (BCA/body_regions/definition.py:4-15), nested as in a body: subcutaneous shell 1 around
+    muscle 2 around the abdominal cavity 3 / thoracic cavity 4 (with mediastinum 9 and pericardium 7 inside), bone 5 (spine, two
+    femurs), glands 6, breast implant 8, brain 10, nervous system 11 (spinal canal inside the spine)."""
+    X, Y, Z = shape
+    out = np.zeros(shape, np.uint8)
+    for x0 in range(0, X, 32):
+        x1 = min(X, x0 + 32)
+        xx, yy, zz = _norm_coords(shape, x0, x1)
+        slab = np.zeros((x1 - x0, Y, Z), np.uint8)
+        r2 = (xx / 0.9) ** 2 + (yy / 0.8) ** 2 + 0 * zz
+        slab[r2 < 1.0] = 1
+        slab[r2 < 0.78] = 2
+        slab[(r2 < 0.5) & (zz > -0.55) & (zz < 0.05)] = 3
+        thor = (r2 < 0.5) & (zz >= 0.12) & (zz < 0.62)
+        slab[thor] = 4
+        slab[thor & ((xx / 0.22) ** 2 + ((yy + 0.05) / 0.3) ** 2 < 1.0)] = 9
+        slab[((xx + 0.05) / 0.16) ** 2 + ((yy + 0.08) / 0.18) ** 2 + ((zz - 0.3) / 0.12) ** 2 < 1.0] = 7
+        slab[((xx / 0.09) ** 2 + ((yy - 0.5) / 0.1) ** 2 < 1.0) & (zz > -0.6) & (zz < 0.75)] = 5          # spine
+        slab[((xx / 0.035) ** 2 + ((yy - 0.5) / 0.04) ** 2 < 1.0) & (zz > -0.6) & (zz < 0.75)] = 11        # spinal canal
+        for s in (-1, 1):
+            slab[(((xx - s * 0.3) / 0.06) ** 2 + (yy / 0.07) ** 2 < 1.0) & (zz <= -0.6)] = 5               # femurs
+            slab[((xx - s * 0.25) / 0.07) ** 2 + ((yy + 0.1) / 0.06) ** 2 + ((zz + 0.15) / 0.07) ** 2 < 1.0] = 6   # glands (kidney-like)
+        slab[((xx - 0.4) / 0.12) ** 2 + ((yy + 0.55) / 0.1) ** 2 + ((zz - 0.35) / 0.1) ** 2 < 1.0] = 8     # implant
+        slab[(xx / 0.3) ** 2 + (yy / 0.36) ** 2 + ((zz - 0.86) / 0.12) ** 2 < 1.0] = 10                    # brain
+        out[x0:x1] = slab
+    return out

@@ -173,8 +173,48 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
 // shared; the producers normalise in fp32 and split into hi / lo fp16 LDS planes, the consumers issue two MFMAs per tap
 // (consume_chunk), the epilogue un-scales the accumulators and stores fp32.  Measured against an fp32 FMA chain the product of
 // split operands is the more accurate of the two (tools/x3_probe.hip: rms error 3.2e-7 vs 5.3e-7 of the output rms at K = 864).
+// Kernel arguments are re-materialisable for hipcc: under SGPR pressure (the struct is ~90 dwords) it re-loads them from the kernarg
+// segment wherever they are needed instead of keeping or spilling them -- found in the ISA of round 5 as chains of dependent
+// `s_load_dwordx8/x16 ...; s_waitcnt lgkmcnt(0)` in the per-tile paths of both roles (tile walk, epilogue addressing: ~1 000 cycles
+// before and ~1 100 cycles after every tile's epilogue on the consumers' critical path, BOA_WS_TRACE stamps 9 / 11).  Passing every
+// scalar through an empty asm makes it an ordinary value: it lives in an SGPR or in a lane of a spill VGPR (v_readlane: one VALU slot).
+#ifdef WS_PIN_ARGS
+#define WS_PIN1(x) asm("" : "+s"(x))
+__device__ __forceinline__ void ws_pin_args(ConvArgs& p) {
+    WS_PIN1(p.C0); WS_PIN1(p.C1); WS_PIN1(p.N); WS_PIN1(p.Di); WS_PIN1(p.Hi); WS_PIN1(p.Wi); WS_PIN1(p.Do); WS_PIN1(p.Ho); WS_PIN1(p.Wo);
+    WS_PIN1(p.Cout); WS_PIN1(p.s0); WS_PIN1(p.s1); WS_PIN1(p.s2); WS_PIN1(p.p0); WS_PIN1(p.p1); WS_PIN1(p.p2);
+    WS_PIN1(p.w0); WS_PIN1(p.w1); WS_PIN1(p.w2); WS_PIN1(p.b0); WS_PIN1(p.b1); WS_PIN1(p.b2); WS_PIN1(p.h0); WS_PIN1(p.h1); WS_PIN1(p.h2);
+    WS_PIN1(p.t0); WS_PIN1(p.t1); WS_PIN1(p.t2); WS_PIN1(p.lw1); WS_PIN1(p.lw2); WS_PIN1(p.lb1); WS_PIN1(p.lb2);
+    WS_PIN1(p.ncy); WS_PIN1(p.cy_fast); WS_PIN1(p.nslots); WS_PIN1(p.vw); WS_PIN1(p.vstep_n); WS_PIN1(p.vstep_j);
+#if WS_PIN_PTRS & 1
+    WS_PIN1(p.out);
+#endif
+#if WS_PIN_PTRS & 16
+    WS_PIN1(p.bias);
+#endif
+#if WS_PIN_PTRS & 32
+    WS_PIN1(p.runs);
+#endif
+#if WS_PIN_PTRS & 2
+    WS_PIN1(p.partials);
+#endif
+#if WS_PIN_PTRS & 4
+    WS_PIN1(p.src0); WS_PIN1(p.src1); WS_PIN1(p.wpk);
+#endif
+#if WS_PIN_PTRS & 8
+    WS_PIN1(p.ss16_0); WS_PIN1(p.ss16_1); WS_PIN1(p.ss0); WS_PIN1(p.ss1);
+#endif
+}
+#endif
+
 template <int R, int K0, int K1, int K2, bool YR, bool X3>
-__global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_tiles, int resident_w, int dbg) {
+__global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p_in, int total_tiles, int resident_w, int dbg) {
+#ifdef WS_PIN_ARGS
+    ConvArgs p = p_in;
+    ws_pin_args(p);
+#else
+    const ConvArgs& p = p_in;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -205,6 +245,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         // visibility to the consumers is ordered by the first chunk barrier below
     }
     int tr_n = 0;
+    const int tr_blk = p.trace ? (int)p.trace[WS_TRACE_SLOTS - 5] : -1;   // (debug) the traced block
 
     if (producer) {
         // ---- producer waves: chunk g + 1 is committed to LDS while the consumers work on chunk g; its global loads
@@ -418,8 +459,14 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         // chunk-planar output [N][Cout/16][voxel][16]: this lane writes the 16 couts of plane (cout0 / 16 + kh) of its voxel
         const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + (((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * 16;
         const unsigned olane = ((unsigned)kh * (unsigned)out_vox + (unsigned)srel0) * 32u;
+#ifdef WS_TRACE_EPILOGUE
+        WS_STAMP(9);
+#endif
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+#ifdef WS_TRACE_EPILOGUE
+            if (r) WS_STAMP(10);
+#endif
             const int m = cw * R + r;  // wave-uniform M-tile origin within the block tile
             const int mx = (m >> (p.lb2 + p.lb1)) * p.w0, my = ((m >> p.lb2) & (p.b1 - 1)) * p.w1, mz = (m & (p.b2 - 1)) * p.w2;
             const int mrel = (mx * p.Ho + my) * p.Wo + mz;
@@ -441,11 +488,22 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     stB.q[i] = __builtin_fmaf(vm, vm, stB.q[i]);
                 }
             } else {
+#ifdef WS_FULL_FAST
+                if (full) {   // (wave-uniform) the common case: no mask multiply
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float vm = full ? v[i] : v[i] * dm;
-                    stA.s[i] += vm;
-                    stA.q[i] = __builtin_fmaf(vm, vm, stA.q[i]);
+                    for (int i = 0; i < 16; ++i) {
+                        stA.s[i] += v[i];
+                        stA.q[i] = __builtin_fmaf(v[i], v[i], stA.q[i]);
+                    }
+                } else
+#endif
+                {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float vm = full ? v[i] : v[i] * dm;
+                        stA.s[i] += vm;
+                        stA.q[i] = __builtin_fmaf(vm, vm, stA.q[i]);
+                    }
                 }
             }
             if constexpr (X3) {
@@ -514,6 +572,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 #endif
             }
         }
+#ifdef WS_TRACE_EPILOGUE
+        WS_STAMP(11);
+#endif
     };
     f32x16 biasv;
 #pragma unroll
@@ -526,10 +587,16 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     for (int k = 0; k < my_tiles + WS_DEFER_EPILOGUE; ++k) {
         bool new_run = true;
         const bool more = k < my_tiles;
+#ifdef WS_TRACE_EPILOGUE
+        WS_STAMP(13);
+#endif
         if (k == 0)
             seq_first(p, cseq);
         else if (more)
             new_run = seq_next(p, cseq);
+#ifdef WS_TRACE_EPILOGUE
+        WS_STAMP(14);
+#endif
 #if WS_DEFER_EPILOGUE
         if (k > 0 && !(dbg & 8)) epilogue(done_tc);  // the previous tile's (its statistics belong to the previous run: before the flush)
         if (!more) break;
@@ -554,6 +621,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 for (int i = 0; i < 16; ++i) biasv[i] *= p.wscale;
             }
         }
+#ifdef WS_TRACE_EPILOGUE
+        WS_STAMP(12);
+#endif
         for (int cc = 0; cc < ncc; ++cc) {
             const int g = k * ncc + cc;
             const unsigned char* cur = bufs + (g & 1) * buf_bytes;
@@ -737,6 +807,9 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     if (want_trace) {
         hipMalloc(&a.trace, WS_TRACE_SLOTS * 8);
         hipMemsetAsync(a.trace, 0, WS_TRACE_SLOTS * 8, ctx->stream);
+        const unsigned long long blk = (unsigned long long)std::min(std::max(atoi(getenv("BOA_WS_TRACE")), 0), grid - 1);
+        hipMemcpyAsync(a.trace + WS_TRACE_SLOTS - 5, &blk, 8, hipMemcpyHostToDevice, ctx->stream);
+        hipStreamSynchronize(ctx->stream);
     }
     KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);
     ctx->counters[x3 ? BOA_CNT_CONV_X3 : BOA_CNT_CONV_WS]++;
@@ -766,7 +839,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
         for (int role = 0; role < 2; ++role) {
             const unsigned long long* h = host + role * (WS_TRACE_SLOTS / 2);
             fprintf(stderr, "[ws-trace] %s Cin=%d Cout=%d in=%d R=%d:", role ? "producer" : "consumer", a0.C0 + a0.C1, a0.Cout, a0.Di, t.R);
-            const int lo = 40, hi = 40 + (role ? 50 : 36);
+            const int lo = 40, hi = 40 + (role ? 50 : 80);
             for (int i = lo; i < hi && h[i]; ++i)
                 fprintf(stderr, " %d:%llu", (int)(h[i] >> 56), (h[i] & 0x00ffffffffffffffull) - (h[i - 1] & 0x00ffffffffffffffull));
             fprintf(stderr, "\n");

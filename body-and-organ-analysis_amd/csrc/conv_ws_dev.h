@@ -12,10 +12,11 @@
 #endif
 #define WS_WB ((27 * 64 + WS_PROD - 1) / WS_PROD)  // weight items per producer thread (taps * 64 items, <= 27 taps)
 #define WS_TRACE_SLOTS 4096
-// timeline stamps (debug only): slot = event counter of the calling wave; wave 0 (consumer) and wave 4 (producer) of block 0
+// timeline stamps (debug only): slot = event counter of the calling wave; wave 0 (consumer) and wave 4 (producer) of block tr_blk
+// (BOA_WS_TRACE=<block>: block 0 only sees tiles on the tensor's y = z = 0 edge, i.e. the producers' slow bounds-checked path)
 #define WS_STAMP(code)                                                                          \
     do {                                                                                        \
-        if (p.trace && blockIdx.x == 0 && lane == 0 && ((wave & 3) == 0) && tr_n < WS_TRACE_SLOTS / 2) { \
+        if (p.trace && (int)blockIdx.x == tr_blk && lane == 0 && ((wave & 3) == 0) && tr_n < WS_TRACE_SLOTS / 2) { \
             p.trace[(producer ? WS_TRACE_SLOTS / 2 : 0) + tr_n] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
             ++tr_n;                                                                             \
         }                                                                                       \

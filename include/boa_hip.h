@@ -377,6 +377,33 @@ int boa_binary_dilate_cross(boa_ctx* ctx, const uint8_t* dev_mask, uint8_t* dev_
                             int iterations);
 /* `out[filled] = label` (BCA/body_parts/postprocess.py:50): out[i] = value where (mask[i] != 0) != invert. */
 int boa_mask_assign(boa_ctx* ctx, const uint8_t* dev_mask, size_t n, int invert, int value, uint8_t* dev_out);
+/* ---- bit-mask morphology (csrc/ccl_bits.hip, round 5): the same filters on BIT-PACKED masks, batched over independent masks ----
+ * A mask is [Z][Y][W] uint32 words, W = ceil(X / 32), bit i of word w <-> x = 32 w + i (bits beyond X are 0); a batch of M masks is
+ * M consecutive masks (boa_bits_words words each).  Replaces, for the BCA post-processing (BCA/body_parts/postprocess.py:7-52,
+ * BCA/body_regions/postprocess.py:8-40), the per-label chains of boa_label_select / boa_fill_holes_2d / boa_ccl26 /
+ * boa_ccl_remove_small / boa_mask_assign: the per-label passes of remove_small_labeled_objects all read the ORIGINAL mask
+ * (`label_mask = mask == label`) and are independent until `out[filled] = label`.  Components are 26-connected; a component's size and
+ * first voxel (raster order: the tie-break of the largest-component filter) are those of boa_ccl26.
+ *   boa_bits_words          words per mask
+ *   boa_bits_select         mask m = { voxel : host_lut[label] bit m } for m < n_masks <= 8, one pass over the uint8 label volume
+ *                           (`mask == label`, `seg > 0`, `seg in {a, b, c}` are all such look-ups)
+ *   boa_bits_unpack         one mask -> uint8 0 / 1 volume (tests, interop with the byte-mask kernels)
+ *   boa_bits_fill_holes_2d  per (mask, z slice): cv2.findContours(RETR_EXTERNAL) + drawContours(FILLED) = foreground + background not
+ *                           4-connected to the slice border; in and out may not alias; boa_bits_fill_supported(Y, X) == 0: the slice
+ *                           does not fit the LDS flood (use boa_fill_holes_2d on bytes)
+ *   boa_bits_remove_small   remove_small_objects(max_size, connectivity = 3) in place on every mask; invert != 0: on the complements
+ *                           (np.invert / remove_small_objects / np.invert: small holes are filled)
+ *   boa_bits_filter_largest _filter_largest_unique_segment on ONE mask: seg = fill_value outside its largest component
+ *   boa_bits_assign_labels  out[v] = host_labels[m] for the largest m whose mask holds v (`out[filled] = label`, ascending); voxels in no
+ *                           mask of the batch keep their value: zero `out` first, apply batches of <= 8 labels in ascending order */
+size_t boa_bits_words(int Z, int Y, int X);
+int boa_bits_select(boa_ctx* ctx, const uint8_t* dev_seg, int Z, int Y, int X, const uint8_t host_lut[256], int n_masks, uint32_t* dev_bits);
+int boa_bits_unpack(boa_ctx* ctx, const uint32_t* dev_bits, int Z, int Y, int X, uint8_t* dev_out);
+int boa_bits_fill_supported(int Y, int X);
+int boa_bits_fill_holes_2d(boa_ctx* ctx, const uint32_t* dev_in, int Z, int Y, int X, int n_masks, uint32_t* dev_out);
+int boa_bits_remove_small(boa_ctx* ctx, uint32_t* dev_bits, int Z, int Y, int X, int n_masks, uint32_t max_size, int invert);
+int boa_bits_filter_largest(boa_ctx* ctx, const uint32_t* dev_bits, int Z, int Y, int X, uint8_t* dev_seg, int fill_value);
+int boa_bits_assign_labels(boa_ctx* ctx, const uint32_t* dev_bits, int Z, int Y, int X, int n_masks, const uint8_t* host_labels, uint8_t* dev_out);
 /* the part -> combined merge `seg_combined[seg == jdx] = class_map_inv[name]` (TS/nnunet.py:553-556) on label volumes that
  * already carry global labels: out[i] = part[i] where part[i] != 0 (tile-sharded mode merges after the label exchange). */
 int boa_label_overlay(boa_ctx* ctx, const uint8_t* dev_part, size_t n, uint8_t* dev_out);
