@@ -12,10 +12,10 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
 GIT=${GIT_REV:-unknown}
 rm -rf $OUT $SUM; mkdir -p $OUT $SUM
-CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-parity --no-h2h --no-lanes --no-exact --no-c3"
+CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-parity --no-h2h --no-lanes --no-exact --no-c3 --no-phantom"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $CMD > $SUM/${TAG}_bench512_rocprof_run.log 2>&1)
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $SUM/${TAG}_bench512_kernel_stats.csv
-PMCCMD="python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-parity --no-h2h --no-lanes --no-exact --no-c3"   # the total+bca workload the bench line reports
+PMCCMD="python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-parity --no-h2h --no-lanes --no-exact --no-c3 --no-phantom"   # the total+bca workload the bench line reports
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 1200 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o $TAG -- $PMCCMD > $OUT/pmc_$c.log 2>&1)
 done
