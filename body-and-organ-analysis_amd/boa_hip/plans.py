@@ -354,9 +354,15 @@ def legacy_plans_from(plans: dict, dataset_json: dict, configuration: str = "3d_
     return pj, dj
 
 
-def synthetic_state_dict(geom: NetGeometry, seed: int = 0) -> Dict[str, np.ndarray]:
+def synthetic_state_dict(geom: NetGeometry, seed: int = 0, structured: float = 0.0) -> Dict[str, np.ndarray]:
     """Seeded random weights with the upstream key names (Kaiming-normal convs a=0.01, bias 0 for convs as
-    nnU-Net's InitWeights_He does; IN gamma/beta perturbed so the affine path is exercised)."""
+    nnU-Net's InitWeights_He does; IN gamma/beta perturbed so the affine path is exercised).
+
+    `structured` > 0: the closest stand-in for a TRAINED net this image allows (no checkpoints offline).  Every spatial conv kernel is a
+    random channel mixing times a smoothing stencil (binomial 1-2-1 per axis) plus `structured`-scaled Kaiming noise: the stack then
+    computes smooth features of the input, the random 1x1x1 head turns them into class maps that are piecewise smooth -- most voxels
+    have a clear winner (top-2 margin of several per cent of the logit range), near-ties only along the class boundaries, which is
+    how a real segmentation's logits look and what the fp16 label-flip bound has to be measured on."""
     rng = np.random.default_rng(seed)
     sd = {}
 
@@ -364,7 +370,17 @@ def synthetic_state_dict(geom: NetGeometry, seed: int = 0) -> Dict[str, np.ndarr
         fan_in = (cout if transposed else cin) * int(np.prod(k))
         std = np.sqrt(2.0 / (1 + 0.01 ** 2)) / np.sqrt(fan_in)
         shape = (cin, cout, *k) if transposed else (cout, cin, *k)
-        sd[key + ".weight"] = (rng.standard_normal(shape) * std).astype(np.float32)
+        w = rng.standard_normal(shape) * std
+        if structured > 0 and int(np.prod(k)) > 1:
+            st = np.ones(1)
+            for kk in k:     # separable binomial stencil (a transposed conv with kernel == stride gets the box)
+                ax = {1: [1.0], 2: [1.0, 1.0], 3: [1.0, 2.0, 1.0]}.get(int(kk), [1.0] * int(kk))
+                st = np.multiply.outer(st, np.asarray(ax))
+            st = st.reshape([int(v) for v in k])
+            st = st / np.sqrt((st ** 2).sum())
+            mix = rng.standard_normal(shape[:2]) * std * np.sqrt(float(np.prod(k)))
+            w = mix[..., None, None, None] * st + structured * w
+        sd[key + ".weight"] = w.astype(np.float32)
         sd[key + ".bias"] = (rng.standard_normal(cout) * 0.02).astype(np.float32)
 
     def norm(key, c):

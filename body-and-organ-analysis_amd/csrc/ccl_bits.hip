@@ -461,6 +461,12 @@ __device__ __forceinline__ void cb_border_voxel(const unsigned* __restrict__ bit
         if (my < 0) my = cb_gid(g, T, m, x, y, z);
         return my;
     };
+    // (two all-foreground tiles are linked once per tile pair by k_cb_border_tiles, not once per touching voxel pair)
+    const bool me_full = T.ncomp[(size_t)m * g.tiles + ((z / CB_TZ) * g.ty + (y / CB_TY)) * g.tx + (x / CB_TX)] < 0;
+    auto link = [&](int xx, int yy, int zz) {
+        if (me_full && T.ncomp[(size_t)m * g.tiles + ((zz / CB_TZ) * g.ty + (yy / CB_TY)) * g.tx + (xx / CB_TX)] < 0) return;
+        cb_union(P, mine(), cb_gid(g, T, m, xx, yy, zz));
+    };
     // the three neighbour bits x - 1, x, x + 1 of a row from ONE mask word (a second one only on the word's first / last bit)
     auto row3 = [&](int yy, int zz, bool& b0, bool& b1, bool& b2) {
         const unsigned wc = cb_word(bits, g, m, zz, yy, w, inv);
@@ -471,7 +477,7 @@ __device__ __forceinline__ void cb_border_voxel(const unsigned* __restrict__ bit
     };
     bool own0, own1, own2;
     row3(y, z, own0, own1, own2);
-    if (lx == CB_TX - 1 && own2) cb_union(P, mine(), cb_gid(g, T, m, x + 1, y, z));
+    if (lx == CB_TX - 1 && own2) link(x + 1, y, z);
     const bool left = own0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -485,41 +491,65 @@ __device__ __forceinline__ void cb_border_voxel(const unsigned* __restrict__ bit
         if (row_other) {
             if (!left) {
                 if (m1) {
-                    cb_union(P, mine(), cb_gid(g, T, m, x, yy, zz));
+                    link(x, yy, zz);
                 } else {
-                    if (m0) cb_union(P, mine(), cb_gid(g, T, m, x - 1, yy, zz));
-                    if (m2) cb_union(P, mine(), cb_gid(g, T, m, x + 1, yy, zz));
+                    if (m0) link(x - 1, yy, zz);
+                    if (m2) link(x + 1, yy, zz);
                 }
             } else if (m2 && !m1) {
-                cb_union(P, mine(), cb_gid(g, T, m, x + 1, yy, zz));
+                link(x + 1, yy, zz);
             }
         } else if (!m1) {
-            if (m0 && lx == 0) cb_union(P, mine(), cb_gid(g, T, m, x - 1, yy, zz));
-            if (m2 && lx == CB_TX - 1) cb_union(P, mine(), cb_gid(g, T, m, x + 1, yy, zz));
+            if (m0 && lx == 0) link(x - 1, yy, zz);
+            if (m2 && lx == CB_TX - 1) link(x + 1, yy, zz);
         }
     }
 }
 
-// mode 0: rows of the planes lz = TZ - 1; mode 1: rows ly = 0 / TY - 1 of the other planes; mode 2: x-face voxels of the remaining
-// rows.  blockIdx.z carries (mask, plane).
-__global__ __launch_bounds__(256) void k_cb_border(const unsigned* __restrict__ bits, CbGeom g, int inv, CbTab T, int mode, int planes) {
-    const int m = (int)blockIdx.z / planes, pz = (int)blockIdx.z % planes;
-    if (mode == 0) {
-        const int x = (int)blockIdx.x * 256 + (int)threadIdx.x, y = (int)blockIdx.y, z = pz * CB_TZ + CB_TZ - 1;
-        if (x >= g.X || z >= g.Z) return;
-        cb_border_voxel(bits, g, T, m, inv, x, y, z);
-    } else if (mode == 1) {
-        const int x = (int)blockIdx.x * 256 + (int)threadIdx.x, z = pz;
-        const int y = ((int)blockIdx.y >> 1) * CB_TY + (((int)blockIdx.y & 1) ? CB_TY - 1 : 0);
-        if (x >= g.X || y >= g.Y || (z % CB_TZ) == CB_TZ - 1) return;
-        cb_border_voxel(bits, g, T, m, inv, x, y, z);
-    } else {
-        const int t = (int)blockIdx.x * 256 + (int)threadIdx.x, z = pz;
-        const int f = t % (2 * g.tx), y = t / (2 * g.tx);
-        const int x = (f >> 1) * CB_TX + ((f & 1) ? CB_TX - 1 : 0);
-        if (y >= g.Y || x >= g.X) return;
-        const int ly = y % CB_TY;
-        if ((z % CB_TZ) == CB_TZ - 1 || ly == 0 || ly == CB_TY - 1) return;
+// One workgroup per (tile, mask): empty tiles return at once; an all-foreground tile links itself to its all-foreground forward
+// neighbour tiles (13 of the 26) with one union each and walks its face voxels only if some forward neighbour tile is mixed; a mixed
+// tile walks its 1 892 face voxels (plane lz = TZ - 1, rows ly = 0 / TY - 1 of the other planes, x faces of the remaining rows).
+__global__ __launch_bounds__(256) void k_cb_border_tiles(const unsigned* __restrict__ bits, CbGeom g, int inv, CbTab T) {
+    const int m = blockIdx.y, tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % g.tx;
+    t /= g.tx;
+    const int ty = t % g.ty, tz = t / g.ty;
+    const int nc = T.ncomp[(size_t)m * g.tiles + blockIdx.x];
+    if (nc == 0) return;
+    if (nc < 0) {
+        // forward neighbour tiles: (dz, dy, dx) > (0, 0, 0) in raster order
+        int mixed = 0;
+        if (tid < 13) {
+            const int k = tid + 14;                      // offsets 14 .. 26 of the 3 x 3 x 3 neighbourhood = the forward half
+            const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+            const int nx = tx + dx, ny = ty + dy, nz = tz + dz;
+            if (nx >= 0 && nx < g.tx && ny >= 0 && ny < g.ty && nz < g.tz) {
+                const int nt = (nz * g.ty + ny) * g.tx + nx;
+                const int nn = T.ncomp[(size_t)m * g.tiles + nt];
+                if (nn < 0)
+                    cb_union(T.parent + (size_t)m * g.tiles * CB_CAP, (int)blockIdx.x * CB_CAP, nt * CB_CAP);
+                else if (nn > 0)
+                    mixed = 1;
+            }
+        }
+        if (!__syncthreads_or(mixed)) return;
+    }
+    const int x0 = tx * CB_TX, y0 = ty * CB_TY, z0 = tz * CB_TZ;
+    constexpr int N0 = CB_TX * CB_TY, N1 = 2 * (CB_TZ - 1) * CB_TX, N2 = 2 * (CB_TY - 2) * (CB_TZ - 1);
+    for (int i = tid; i < N0 + N1 + N2; i += 256) {
+        int lx, ly, lz;
+        if (i < N0) {
+            lx = i % CB_TX; ly = i / CB_TX; lz = CB_TZ - 1;
+        } else if (i < N0 + N1) {
+            const int j = i - N0;
+            lx = j % CB_TX; lz = (j / CB_TX) % (CB_TZ - 1); ly = (j / (CB_TX * (CB_TZ - 1))) ? CB_TY - 1 : 0;
+        } else {
+            const int j = i - N0 - N1;
+            lx = (j & 1) ? CB_TX - 1 : 0; ly = 1 + (j >> 1) % (CB_TY - 2); lz = (j >> 1) / (CB_TY - 2);
+        }
+        const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+        if (x >= g.X || y >= g.Y || z >= g.Z) continue;
         cb_border_voxel(bits, g, T, m, inv, x, y, z);
     }
 }
@@ -781,9 +811,7 @@ struct CbScratch {
 // labelling of n_masks masks (objects, or with inv the components of the complements): local pass, face unions, root resolution
 static void cb_label(boa_ctx* c, const uint32_t* bits, const CbGeom& g, int n_masks, int inv, const CbTab& T) {
     hipLaunchKernelGGL(k_cb_local, dim3((unsigned)g.tiles, (unsigned)n_masks), dim3(256), 0, c->stream, bits, g, inv, T);
-    hipLaunchKernelGGL(k_cb_border, dim3((unsigned)((g.X + 255) / 256), (unsigned)g.Y, (unsigned)(g.tz * n_masks)), dim3(256), 0, c->stream, bits, g, inv, T, 0, g.tz);
-    hipLaunchKernelGGL(k_cb_border, dim3((unsigned)((g.X + 255) / 256), (unsigned)(2 * g.ty), (unsigned)(g.Z * n_masks)), dim3(256), 0, c->stream, bits, g, inv, T, 1, g.Z);
-    hipLaunchKernelGGL(k_cb_border, dim3((unsigned)(((size_t)2 * g.tx * g.Y + 255) / 256), 1, (unsigned)(g.Z * n_masks)), dim3(256), 0, c->stream, bits, g, inv, T, 2, g.Z);
+    hipLaunchKernelGGL(k_cb_border_tiles, dim3((unsigned)g.tiles, (unsigned)n_masks), dim3(256), 0, c->stream, bits, g, inv, T);
     const size_t waves = g.tiles * (size_t)n_masks;
     hipLaunchKernelGGL(k_cb_resolve, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, c->stream, g, T, n_masks);
 }

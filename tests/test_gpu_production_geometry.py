@@ -8,8 +8,11 @@ and the 8^3 / 4^3 bottleneck tiles that the 32^3 toy nets of test_gpu_seams.py n
 production kernels (not the fallbacks) ran.  Bars = measured on MI355X + margin (printed by the test):
   exact mode : max |logit error| <= 2e-5 of the logit range (measured 1.9e-6 .. 3.6e-6), label flips <= 2e-5 of the voxels
                (measured 4.3e-6 .. 8.6e-6 = 9 .. 18 of 2 097 152 voxels: fp32 summation-order near-ties of random-weight nets)
-  fp16 mode  : max |logit error| <= 5e-3 of the logit range (measured 1.2e-3 .. 2.1e-3), label flips <= 8e-3 (measured
-               2.5e-3 .. 5.7e-3; random weights put far more voxels at near-ties than trained nets)."""
+  fp16 mode  : max |logit error| <= 2.7e-3 of the logit range (measured 1.2e-3 .. 2.1e-3: worst case + 25 %), label flips <= 7e-3
+               (measured 2.5e-3 .. 5.7e-3; random weights put far more voxels at near-ties than trained nets); every flipped voxel's
+               oracle top-2 margin is below twice the logit error, and the test prints the margin histogram of the flipped voxels.
+test_structured_net_* repeats the fp16 comparison on the closest stand-in for a TRAINED net this image allows (smooth features, a
+confident head): see there."""
 import numpy as np
 import pytest
 
@@ -17,6 +20,8 @@ pytestmark = pytest.mark.gpu
 
 PATCH = (128, 128, 128)
 FEATURES = (32, 64, 128, 256, 320, 320)
+# fp16 flips of the structured (confident) net: bar = measured on MI355X + margin (the test prints the measured value)
+STRUCTURED_FP16_FLIP_BAR = 1e-3
 
 
 @pytest.fixture(scope="module")
@@ -56,7 +61,7 @@ def _compare(ctx, cfg, blob, net, vol, origins, tag):
     for o in origins:
         refs.append(fn(vol[:, o[0]:o[0] + PATCH[0], o[1]:o[1] + PATCH[1], o[2]:o[2] + PATCH[2]][None])[0])
     out = {}
-    for prec, err_bar, flip_bar in (("fp32", 2e-5, 2e-5), ("fp32_ref", 2e-5, 2e-5), ("fp16", 5e-3, 8e-3)):
+    for prec, err_bar, flip_bar in (("fp32", 2e-5, 2e-5), ("fp32_ref", 2e-5, 2e-5), ("fp16", 2.7e-3, 7e-3)):
         ctx.counters(reset=True)
         p = HipPredictor(ctx, cfg.geometry, max_batch=len(origins), precision=prec)
         p.set_parameters([blob])
@@ -84,6 +89,13 @@ def _compare(ctx, cfg, blob, net, vol, origins, tag):
                 worst = float((top2[1] - top2[0])[flipped].max())
                 print(f"{tag} {prec} tile {i}: largest oracle top-2 margin of a flipped voxel {worst / rng_:.3g} of the range")
                 assert worst <= 2.0 * err + 1e-6 * rng_, (prec, worst, err)
+                if prec == "fp16":   # where the flips sit, and how many voxels live there at all
+                    mg = (top2[1] - top2[0]) / rng_
+                    edges = [0, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 1.0]
+                    hf, _ = np.histogram(mg[flipped], bins=edges)
+                    ha, _ = np.histogram(mg, bins=edges)
+                    print(f"{tag} fp16 tile {i}: flipped / all voxels by oracle top-2 margin (units of the logit range): "
+                          + ", ".join(f"[{edges[k]:g}, {edges[k + 1]:g}) {hf[k]} / {ha[k]}" for k in range(len(hf))))
         out[prec] = got
     return out
 
@@ -100,6 +112,57 @@ def test_bca_geometry_tile_vs_oracle(ctx):
     cfg, blob, net = _model(7, 543, spacing=(5.0, 1.5, 1.5))
     vol = np.random.default_rng(543).standard_normal((1, 128, 136, 144)).astype(np.float32)
     _compare(ctx, cfg, blob, net, vol, [(0, 8, 16)], "body_parts")
+
+
+def test_structured_net_fp16_flips_vs_oracle(ctx):
+    """The fp16 label-flip fraction on a net whose logits look like a segmentation's rather than like noise (the real
+    checkpoints are not available offline): `plans.synthetic_state_dict(structured=0.05)` -- every spatial kernel is a random channel
+    mixing times a smoothing stencil, so the last decoder features are smooth multi-scale functions of the CT -- and a CONFIDENT
+    two-class head (w1 = -w0: one template, for and against), 128^3 production geometry, a tile that crosses the body surface.
+    Measured on the torch-CPU oracle: 99 % of the voxels have a top-2 margin above 1e-3 of the logit range, 97 % above 3e-3, 90 %
+    above 1e-2 (the random 25-class head of the bench: 90 / 74 / 37 %).  Asserted: the margin distribution (so that the test keeps
+    measuring what it says), the fp16 logit error bar of the production test, NO flip above twice the logit error, and a flip
+    fraction an order of magnitude below the random-head net's.  What this does not give is the flip rate of a trained checkpoint:
+    LeakyReLU nets with synthetic weights have unimodal logit margins, trained ones push the margin density at zero down further."""
+    import torch
+    from boa_hip import plans
+    from boa_hip.predictor import HipPredictor
+    from oracle.network import build_from_arch, network_fn_from_module
+    pj, dj = plans.synthetic_plans(patch=PATCH, features=FEATURES, num_classes=2)
+    cfg = plans.model_config_from_plans(pj, dj)
+    sd = plans.synthetic_state_dict(cfg.geometry, 291, structured=0.05)
+    head = max(int(k.split(".")[2]) for k in sd if k.startswith("decoder.seg_layers.") and k.endswith(".weight"))
+    q = np.random.default_rng(1).standard_normal(FEATURES[0]).astype(np.float32)
+    q /= np.linalg.norm(q)
+    sd[f"decoder.seg_layers.{head}.weight"] = np.stack([q, -q]).reshape(2, FEATURES[0], 1, 1, 1)
+    sd[f"decoder.seg_layers.{head}.bias"] = np.zeros(2, np.float32)
+    blob = plans.weight_blob_from_state_dict(cfg.geometry, sd)
+    net = build_from_arch(pj["configurations"]["3d_fullres"]["architecture"]["arch_kwargs"], 1, 2)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    vol = _normalised_phantom(cfg, (160, 160, 192), seed=7)
+    o = (16, 16, 32)
+    ref = network_fn_from_module(net, threads=8)(vol[:, o[0]:o[0] + 128, o[1]:o[1] + 128, o[2]:o[2] + 128][None])[0]
+    rng_ = float(ref.max() - ref.min())
+    mg = np.abs(ref[1] - ref[0]) / rng_
+    frac = {t: float((mg > t).mean()) for t in (1e-3, 3e-3, 1e-2)}
+    print("structured net: fraction of voxels with oracle top-2 margin above 1e-3 / 3e-3 / 1e-2 of the range:", frac)
+    assert frac[1e-3] >= 0.98 and frac[3e-3] >= 0.95 and frac[1e-2] >= 0.85, frac
+    res = {}
+    for prec in ("fp16", "fp32"):
+        p = HipPredictor(ctx, cfg.geometry, max_batch=1, precision=prec)
+        p.set_parameters([blob])
+        got = p.network_forward(vol, np.asarray([o], dtype=np.int32))[0]
+        p.close()
+        err = float(np.abs(got - ref).max())
+        flipped = got.argmax(0) != ref.argmax(0)
+        worst = float(mg[flipped].max()) if flipped.any() else 0.0
+        res[prec] = (err / rng_, float(flipped.mean()), worst)
+        print(f"structured net {prec}: max|err| {err / rng_:.3g} of the range {rng_:.4g}, label flips {flipped.mean():.3g}, "
+              f"largest margin of a flipped voxel {worst:.3g} of the range")
+        assert worst * rng_ <= 2.0 * err + 1e-6 * rng_, (prec, worst, err)
+    assert res["fp16"][0] <= 2.7e-3 and res["fp32"][0] <= 2e-5, res
+    assert res["fp32"][1] <= 2e-5, res
+    assert res["fp16"][1] <= STRUCTURED_FP16_FLIP_BAR, res
 
 
 def test_tile_batch_16_and_25_bit_identical_to_1(ctx):

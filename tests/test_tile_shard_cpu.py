@@ -352,3 +352,95 @@ def test_unit_sharded_eight_ranks_over_gloo():
                 np.testing.assert_array_equal(nn.view(np.uint16), single.n[lo:hi].view(np.uint16))
         assert covered == shape[0]
     assert active == set(range(world))
+
+
+def _simulate_rendezvous(calls):
+    """`calls[rank]` = the rank's communication-stream program: a list of groups, each a list of ("send" | "recv", peer, tag).  RCCL
+    semantics of one ncclGroupStart/End: the group is ONE launch on the rank's communication stream; its point-to-point operations
+    progress independently, each meeting its counterpart as soon as the peer's stream is EXECUTING the group that holds the
+    counterpart (stream order: a rank's groups run one after the other, a group ends when all of its operations are done).
+    Returns the number of rounds until every rank has finished, or raises on a deadlock (a round without progress)."""
+    pos = [0] * len(calls)
+    done = [[set() for _ in c] for c in calls]
+    rounds = 0
+    while any(p < len(c) for p, c in zip(pos, calls)):
+        progress = False
+        for r, c in enumerate(calls):
+            if pos[r] >= len(c):
+                continue
+            for j, (kind, peer, tag) in enumerate(c[pos[r]]):
+                if j in done[r][pos[r]] or pos[peer] >= len(calls[peer]):
+                    continue
+                want = ("recv" if kind == "send" else "send", r, tag)
+                grp = calls[peer][pos[peer]]
+                if want in grp and grp.index(want) not in done[peer][pos[peer]]:
+                    done[r][pos[r]].add(j)
+                    done[peer][pos[peer]].add(grp.index(want))
+                    progress = True
+        for r, c in enumerate(calls):
+            while pos[r] < len(c) and len(done[r][pos[r]]) == len(c[pos[r]]):
+                pos[r] += 1
+                progress = True
+        if not progress:
+            raise AssertionError(f"deadlock: ranks wait at groups {pos}")
+        rounds += 1
+    return rounds
+
+
+@pytest.mark.parametrize("group_msgs", [1, 8, 26, 1 << 30])
+def test_grouped_slab_exchange_cannot_deadlock_with_both_neighbours(group_msgs):
+    """boa_comm_shift_slab (csrc/comm.hip) sends the (C + 1) planes of a boundary slab as (C + 1) ncclSend / ncclRecv, in sub-groups
+    of $BOA_COMM_GROUP messages per direction; a rank in the middle of a model's blocks sends up AND receives from below in the same
+    call.  The communication-stream programs of all 8 ranks for one 512^3 `total` volume (5 models x 5 tile rows as (model, row)
+    units, models in order, every model's boundaries in one call per rank) are played under rendezvous semantics: every sub-group
+    size completes -- the pairs of a sub-group are the same piece indices on both sides of every boundary, and a line of neighbour
+    exchanges has no cycle -- while a program that pairs the pieces differently on the two sides is caught by the same simulator."""
+    from boa_hip import sliding_window as sw
+    from boa_hip import tile_shard as ts
+    world, C_ = 8, 25
+
+    def program(PV, plans):
+        calls = [[] for _ in range(world)]
+        n_b = 0
+        for m, plan in enumerate(plans):
+            for r in range(world):
+                i = plan.index(r)
+                if i is None:
+                    continue
+                up = plan.ranks[i + 1] if plan.boundary(i) is not None else None
+                dn = plan.ranks[i - 1] if plan.boundary(i - 1) is not None else None
+                if up is None and dn is None:
+                    continue
+                n_b += up is not None
+                for k0 in range(0, C_ + 1, min(group_msgs, C_ + 1)):
+                    ks = range(k0, min(C_ + 1, k0 + min(group_msgs, C_ + 1)))
+                    grp = [("send", up, (m, k)) for k in ks] if up is not None else []
+                    grp += [("recv", dn, (m, k)) for k in ks] if dn is not None else []
+                    calls[r].append(grp)
+        return calls, n_b
+
+    # (a) 512^3, (model, row) units: 25 units in 8 contiguous runs -> 7 cuts, those inside a model are slab boundaries
+    PV = [512, 512, 512]
+    origins = np.array(sw.get_sliding_window_origins(PV, [128] * 3, 0.8))
+    units = ts.plan_units([5] * 5, world)
+    calls_a, nb_a = program(PV, [ts.plan_rows(origins, 128, PV[0], world, assignment=units[m]) for m in range(5)])
+    assert nb_a >= 4
+    _simulate_rendezvous(calls_a)
+    # (b) configs[2]'s 768 planes: 8 tile rows -> all 8 ranks in ONE line per model, the six inner ranks send up and receive from
+    #     below in the same call; three models one after the other
+    PV = [768, 512, 512]
+    origins = np.array(sw.get_sliding_window_origins(PV, [128] * 3, 0.8))
+    plan = ts.plan_rows(origins, 128, PV[0], world)
+    assert plan.active == 8
+    calls, n_boundaries = program(PV, [plan] * 3)
+    assert n_boundaries == 21 and all(calls[r] for r in range(world))
+    both = sum(1 for c in calls for g in c if any(o[0] == "send" for o in g) and any(o[0] == "recv" for o in g))
+    assert both > 0
+    _simulate_rendezvous(calls)
+    # the simulator does catch a broken pairing: one rank walking its sub-groups in the opposite order
+    if min(group_msgs, C_ + 1) < C_ + 1:
+        bad = [list(c) for c in calls]
+        victim = next(r for r in range(world) if len(bad[r]) > 1)
+        bad[victim] = bad[victim][::-1]
+        with pytest.raises(AssertionError, match="deadlock"):
+            _simulate_rendezvous(bad)
