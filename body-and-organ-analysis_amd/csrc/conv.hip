@@ -168,7 +168,7 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out, bool x3) {
                             if (variant == 1 && !conv_ws_supported(g.k, (int)HV)) continue;
                             const size_t lds = variant == 1 ? conv_ws_lds_bytes((int)HV, taps, ncc, g.Cout)
                                                             : conv_lds_bytes((int)HV, taps);
-                            if (lds > 160 * 1024) continue;
+                            if (lds > 160 * 1024 - 2048) continue;   // (2 KiB stay free for the split-precision kernel's bias table)
                             const long long nblocks = tiles * (g.Cout / 32) * g.N;
                             // experiment hook: BOA_CONV_TILE="w0,w1,w2,b0,b1,b2" forces that shape wherever it is legal
                             static int ft[6] = {0, 0, 0, 0, 0, 0};

@@ -237,6 +237,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p_in, int total
     for (int v = (int)blockIdx.x; v < p.N * p.vw; v += (int)gridDim.x) my_tiles += p.runs[(v % p.vw) * 8];
     const int my_chunks = my_tiles * ncc;
 
+    // X3: the (scaled) bias in the D-fragment order lives in LDS behind the buffers and is read straight INTO the accumulators at
+    // a tile's first chunk -- a persistent 16-register bias fragment made the 256-register kernel spill (11 / 5 VGPRs, round 4)
+    float* const s_bias = (float*)(bufs + 2 * buf_bytes);
+    if constexpr (X3) {
+        for (int i = tid; i < p.Cout; i += WS_THREADS) s_bias[i] = p.bias[i] * p.wscale;   // (ordered by the first chunk barrier)
+    }
     if (resident_w) {
         // (only used when Cout == 32: every tile of the launch uses the same weights)
         const int nw = ncc * taps * 64;
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p_in, int total
             st_n = -1;
             slot = cseq.j * 4 + cw;
         }
-        if (tc.cy != bias_cy) {  // this lane's 16 biases of the cout chunk, D-fragment layout (entry 4 gq + e <-> cout 8 gq + 4 kh + e)
+        if (!X3 && tc.cy != bias_cy) {  // this lane's 16 biases of the cout chunk, D-fragment layout (entry 4 gq + e <-> cout 8 gq + 4 kh + e)
             bias_cy = tc.cy;
             const WS_GLOBAL unsigned char* bbase = sgpr_ptr(p.bias + tc.cy * 32);
             unsigned bl = (unsigned)kh * 16u;
@@ -637,7 +643,23 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p_in, int total
             }
             const unsigned char* ap = (resident_w ? smem + cc * taps * 1024 : cur + 2 * plane) + (X3 ? l31 : kh * 32 + l31) * 16;
             WS_STAMP(4);
-            if constexpr (YR) {
+            if constexpr (X3) {
+                if (cc == 0) {   // accumulators start at bias * wscale (LDS table, D-fragment order: entry 4 gq + e <-> cout 8 gq + 4 kh + e)
+                    const float* sb = s_bias + tc.cy * 32 + 4 * kh;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x4_t bv = *(const f32x4_t*)(sb + 8 * gq);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            acc[r][gq * 4 + 0] = bv[0]; acc[r][gq * 4 + 1] = bv[1]; acc[r][gq * 4 + 2] = bv[2]; acc[r][gq * 4 + 3] = bv[3];
+                        }
+                    }
+                }
+                if constexpr (YR)
+                    consume_chunk_y<R, K0, K2, false, X3>(bp[0], ap, p.h1, p.h2, acc, biasv);
+                else
+                    consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.h1, p.h2, acc, biasv);
+            } else if constexpr (YR) {
                 if (cc == 0)
                     consume_chunk_y<R, K0, K2, true, X3>(bp[0], ap, p.h1, p.h2, acc, biasv);
                 else
@@ -673,7 +695,7 @@ static size_t ws_plane_host(int HV) { return ((size_t)(HV + WS_PROD / 2 - 1) / (
 
 // resident weights need every tile of the launch to use the same weights: Cout == 32 (one cout chunk)
 bool conv_ws_resident(int HV, int taps, int ncc, int Cout) {
-    return Cout == 32 && (size_t)ncc * taps * 1024 + 4 * ws_plane_host(HV) <= 160 * 1024;
+    return Cout == 32 && (size_t)ncc * taps * 1024 + 4 * ws_plane_host(HV) <= 160 * 1024 - 2048;
 }
 
 size_t conv_ws_lds_bytes(int HV, int taps, int ncc, int Cout) {
@@ -700,7 +722,7 @@ template <int R, int K0, int K1, int K2, bool YR, bool X3>
 static void launch_ws_y(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
     static bool once = (hipFuncSetAttribute((const void*)k_conv_ws<R, K0, K1, K2, YR, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR, X3>), dim3(grid), dim3(WS_THREADS), t.lds_bytes, ctx->stream, a, total, resident,
+    hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR, X3>), dim3(grid), dim3(WS_THREADS), t.lds_bytes + (X3 ? 2048 : 0), ctx->stream, a, total, resident,
                        getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0);
 }
 

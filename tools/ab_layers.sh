@@ -16,7 +16,7 @@ def load(fn):
     order=[]
     cnt={}
     for l in open(fn):
-        m=re.search(r'\[layer\] (\S+)\s+N=\d+ in=(\S+) cin=(\d+) cout=(\d+) k=(\d+) s=(\d+).*? ([\d.]+) us', l)
+        m=re.search(r'\[layer\] (?:x3 )?(\S+)\s+N=\d+ in=(\S+) cin=(\d+) cout=(\d+) k=(\d+) s=(\d+).*? ([\d.]+) us', l)
         if not m: continue
         key0=m.group(1,2,3,4,6)
         # the same shape occurs twice in a forward (encoder / decoder): number the occurrences within a run
