@@ -173,48 +173,12 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
 // shared; the producers normalise in fp32 and split into hi / lo fp16 LDS planes, the consumers issue two MFMAs per tap
 // (consume_chunk), the epilogue un-scales the accumulators and stores fp32.  Measured against an fp32 FMA chain the product of
 // split operands is the more accurate of the two (tools/x3_probe.hip: rms error 3.2e-7 vs 5.3e-7 of the output rms at K = 864).
-// Kernel arguments are re-materialisable for hipcc: under SGPR pressure (the struct is ~90 dwords) it re-loads them from the kernarg
-// segment wherever they are needed instead of keeping or spilling them -- found in the ISA of round 5 as chains of dependent
-// `s_load_dwordx8/x16 ...; s_waitcnt lgkmcnt(0)` in the per-tile paths of both roles (tile walk, epilogue addressing: ~1 000 cycles
-// before and ~1 100 cycles after every tile's epilogue on the consumers' critical path, BOA_WS_TRACE stamps 9 / 11).  Passing every
-// scalar through an empty asm makes it an ordinary value: it lives in an SGPR or in a lane of a spill VGPR (v_readlane: one VALU slot).
-#ifdef WS_PIN_ARGS
-#define WS_PIN1(x) asm("" : "+s"(x))
-__device__ __forceinline__ void ws_pin_args(ConvArgs& p) {
-    WS_PIN1(p.C0); WS_PIN1(p.C1); WS_PIN1(p.N); WS_PIN1(p.Di); WS_PIN1(p.Hi); WS_PIN1(p.Wi); WS_PIN1(p.Do); WS_PIN1(p.Ho); WS_PIN1(p.Wo);
-    WS_PIN1(p.Cout); WS_PIN1(p.s0); WS_PIN1(p.s1); WS_PIN1(p.s2); WS_PIN1(p.p0); WS_PIN1(p.p1); WS_PIN1(p.p2);
-    WS_PIN1(p.w0); WS_PIN1(p.w1); WS_PIN1(p.w2); WS_PIN1(p.b0); WS_PIN1(p.b1); WS_PIN1(p.b2); WS_PIN1(p.h0); WS_PIN1(p.h1); WS_PIN1(p.h2);
-    WS_PIN1(p.t0); WS_PIN1(p.t1); WS_PIN1(p.t2); WS_PIN1(p.lw1); WS_PIN1(p.lw2); WS_PIN1(p.lb1); WS_PIN1(p.lb2);
-    WS_PIN1(p.ncy); WS_PIN1(p.cy_fast); WS_PIN1(p.nslots); WS_PIN1(p.vw); WS_PIN1(p.vstep_n); WS_PIN1(p.vstep_j);
-#if WS_PIN_PTRS & 1
-    WS_PIN1(p.out);
-#endif
-#if WS_PIN_PTRS & 16
-    WS_PIN1(p.bias);
-#endif
-#if WS_PIN_PTRS & 32
-    WS_PIN1(p.runs);
-#endif
-#if WS_PIN_PTRS & 2
-    WS_PIN1(p.partials);
-#endif
-#if WS_PIN_PTRS & 4
-    WS_PIN1(p.src0); WS_PIN1(p.src1); WS_PIN1(p.wpk);
-#endif
-#if WS_PIN_PTRS & 8
-    WS_PIN1(p.ss16_0); WS_PIN1(p.ss16_1); WS_PIN1(p.ss0); WS_PIN1(p.ss1);
-#endif
-}
-#endif
-
 template <int R, int K0, int K1, int K2, bool YR, bool X3>
-__global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p_in, int total_tiles, int resident_w, int dbg) {
-#ifdef WS_PIN_ARGS
-    ConvArgs p = p_in;
-    ws_pin_args(p);
-#else
-    const ConvArgs& p = p_in;
-#endif
+__global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_tiles, int resident_w, int dbg) {
+    // (round 5, measured and not kept: hipcc re-loads kernel arguments from the kernarg segment in the per-tile paths instead of keeping
+    //  them -- chains of s_load_dwordx8/x16 + s_waitcnt in the tile walk and the epilogue addressing; passing every argument through an
+    //  empty asm removed all of those loads from the loops (16 instead of 38 s_load, 480 instead of 314 v_readlane) and made every
+    //  layer 2 ... 16 % SLOWER, 7 % over a forward: profiles/r05_conv_ws_experiments.txt)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -494,15 +458,6 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p_in, int total
                     stB.q[i] = __builtin_fmaf(vm, vm, stB.q[i]);
                 }
             } else {
-#ifdef WS_FULL_FAST
-                if (full) {   // (wave-uniform) the common case: no mask multiply
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        stA.s[i] += v[i];
-                        stA.q[i] = __builtin_fmaf(v[i], v[i], stA.q[i]);
-                    }
-                } else
-#endif
                 {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -722,7 +677,7 @@ template <int R, int K0, int K1, int K2, bool YR, bool X3>
 static void launch_ws_y(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
     static bool once = (hipFuncSetAttribute((const void*)k_conv_ws<R, K0, K1, K2, YR, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR, X3>), dim3(grid), dim3(WS_THREADS), t.lds_bytes + (X3 ? 2048 : 0), ctx->stream, a, total, resident,
+    hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR, X3>), dim3(grid), dim3(WS_THREADS), t.lds_bytes + 2048, ctx->stream, a, total, resident,
                        getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0);
 }
 
