@@ -360,6 +360,19 @@ class _ShardedJob:
         self.pending = None
         self.lo = self.hi = 0
         self.done = False
+        # (fold, tile row) units -- a model ensemble on a grid with fewer tile rows than ranks (the BCA nets: 5 folds, 2 rows at 5 mm
+        # slices): rows alone keep `plan.active` ranks busy.  The folds are independent until `prediction += fold` (fp16, in fold
+        # order, predict_from_raw_data.py:494-500), so the unit list (fold-major) is cut into one contiguous run per rank
+        # (tile_shard.plan_units), every fold runs the exact row protocol among ITS ranks, the normalised fp16 logits of a fold --
+        # plane-disjoint over its ranks -- are summed over all ranks (x + 0 is exact), and every rank then adds the folds IN ORDER on
+        # its share of the planes: the same fp16 operations in the same order as on one GPU -> bit-identical labels.
+        import os as _os
+        self.fold_plans = None
+        if (self.nf > 1 and self.direct and shard.mode == "exact" and getattr(shard, "assignment", None) is None
+                and shard.comm.world > self.plan.active and not _os.environ.get("BOA_NO_FOLD_UNITS")):
+            units = ts.plan_units([len(self.plan.rows)] * self.nf, shard.comm.world)
+            self.fold_plans = [ts.plan_rows(self.origins, pred.geom.patch_size[0], self.PV[0], shard.comm.world, assignment=units[f])
+                               for f in range(self.nf)]
 
     def _buf(self, name, nbytes):
         b = self.work.get(name)
@@ -373,11 +386,56 @@ class _ShardedJob:
     def _lut_p(self):
         return self.lut_arr.ctypes.data_as(C.c_void_p) if self.lut_arr is not None else None
 
+    def _begin_fold_units(self, after_first_start):
+        ts, comm, rank = self.ts, self.shard.comm, self.shard.comm.rank
+        self.part = self._buf("part", self.nv)
+        self.flogits = []
+        member = 0
+        for f, plan_f in enumerate(self.fold_plans):
+            F = self._buf(f"flog{f}", self.C_ * self.nvox * 2)       # fold f's normalised logits, complete on every rank after the sum
+            lo = hi = 0
+            if plan_f.index(rank) is not None:
+                self.p._ensure_net(f)
+                nacc = self._buf(f"fn{member}", self.nvox * 2)
+                member += 1
+                eng = ts.HipShardEngine(self.p, comm, self.dvol, self.V, self.PV, self.below, self.origins, F, nacc)
+                try:
+                    lo, hi = ts.finish_fold_sharded(ts.start_fold_sharded(eng, plan_f, comm, self.shard.mode))
+                finally:
+                    eng.close()
+                # acc / n -> normalised fp16 logits in place on the planes this rank owns (inf check included)
+                check(self.lib.boa_finalize_labels_planes(self.ctx.h, F.vp, nacc.vp, self.C_, int3(self.PV), None, 0, 0, 1, None, 0, None,
+                                                          None, None, self.flag.vp, lo, hi), "boa_finalize_labels_planes")
+            self.flogits.append((F, lo, hi))
+            if f == 0 and after_first_start is not None:
+                after_first_start()
+        for F, lo, hi in self.flogits:      # every rank, every fold, in fold order (non-members contribute zeros)
+            ts.all_reduce_logit_planes(self.ctx, comm, F, self.C_, self.PV, lo, hi)
+
+    def _finish_fold_units(self):
+        comm = self.shard.comm
+        P0, P1 = (self.PV[0] * comm.rank) // comm.world, (self.PV[0] * (comm.rank + 1)) // comm.world
+        ones = self.work.get("ones")
+        if ones is None or ones.nbytes < self.nvox * 2:
+            if ones is not None:
+                ones.free()
+            ones = self.ctx.from_numpy(np.full(self.nvox, 0x3C00, np.uint16))       # fp16 1.0: x / 1 == x, the fold logits are normalised already
+            self.work["ones"] = ones
+        fold = self._buf("fold", self.C_ * self.nvox * 2)
+        for f, (F, _, _) in enumerate(self.flogits):
+            last = f == self.nf - 1
+            check(self.lib.boa_finalize_labels_planes(
+                self.ctx.h, F.vp, ones.vp, self.C_, int3(self.PV), fold.vp, 0 if f == 0 else 1, self.nf if last else 0, 0, self._lut_p(), 0,
+                self.part.vp if last else None, int3(self.below) if self.crop else None, int3(self.V) if self.crop else None, self.flag.vp,
+                P0, P1), "boa_finalize_labels_planes")
+
     def begin(self, after_first_start=None):
         job_slot = self.work.get("_job", 0) & 1
         self.work["_job"] = self.work.get("_job", 0) + 1
         self.flag = self._buf(f"flag{job_slot}", 4)
         self.flag.zero()
+        if self.fold_plans is not None:
+            return self._begin_fold_units(after_first_start)
         self.fold = self._buf("fold", self.C_ * self.nvox * 2) if self.nf > 1 else None
         self.part = self._buf("part", self.nv)
         for f in range(self.nf):
@@ -414,6 +472,8 @@ class _ShardedJob:
         self.done = True
         ts, comm, nv = self.ts, self.shard.comm, self.nv
         check(self.lib.boa_memset(self.ctx.h, self.part.vp, 0, nv), "boa_memset")
+        if self.fold_plans is not None:
+            self._finish_fold_units()
         if self.pending is not None:
             self._finish_fold(*self.pending)
             self.pending = None

@@ -385,3 +385,88 @@ def test_bench_eight_ranks_wiring_over_gloo(shard):
     # whole-job aggregate: 8 volumes per step in the weak mode, one shared volume otherwise
     per_step = line["value"] * line["ms_per_step"] / 1e3
     assert abs(per_step - (8 if shard == "volumes" else 1)) < 1e-6
+
+
+# ---- (fold, tile row) units: an ensemble on a grid with fewer tile rows than ranks (the BCA nets: 5 folds, 2 rows at 5 mm) --------
+FOLD_SHAPE = (40, 44, 48)                 # patch 32, step 0.5 -> 2 tile rows along axis 0
+
+
+def _fold_task(ctx, folds=3):
+    from boa_hip import plans
+    from boa_hip.task import SegmentationTask
+    pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=7, spacing=(1.5, 1.5, 1.5))
+    cfg = plans.model_config_from_plans(pj, dj)
+    blobs = [plans.weight_blob_from_state_dict(cfg.geometry, plans.synthetic_state_dict(cfg.geometry, seed=900 + 13 * f)) for f in range(folds)]
+    task = SegmentationTask(ctx, "body_parts", [(900, cfg, blobs)], resample=None, multimodel=False, max_batch=3)
+    task.step_size = 0.5
+    for _, _, p, _ in task.parts:
+        p.tile_step_size = 0.5
+    return task
+
+
+def _fold_predict(ctx, shard=None):
+    task = _fold_task(ctx)
+    task.shard = shard
+    ct = np.random.default_rng(6).normal(0, 300, size=FOLD_SHAPE).astype(np.int16)
+    ct[ct == 0] = 1
+    d_ct = ctx.from_numpy(ct)
+    d_lab = ctx.alloc(int(np.prod(FOLD_SHAPE)))
+    try:
+        task.predict_zyx_device(d_ct, FOLD_SHAPE, d_lab, in_dtype=0)
+        return d_lab.download(FOLD_SHAPE, np.uint8)
+    finally:
+        d_ct.free()
+        d_lab.free()
+        task.close()
+
+
+def _fold_worker(rank, world, port, q):
+    sys.path[:0] = [HERE, os.path.join(HERE, "body-and-organ-analysis_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from boa_hip import distributed as D
+    from boa_hip import tile_shard as ts
+    from boa_hip.device import Context
+    dist = D.init("gloo", rank, world)
+    ctx = Context(0)
+    comm = ts.ShardComm(dist, rank, world, "cpu")
+    ctx.counters(reset=True)
+    lab = _fold_predict(ctx, ts.TileShard(comm, "exact"))
+    cnt = ctx.counters()
+    q.put((rank, (lab, cnt["conv_ws"] + cnt["first_mfma"])))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 6])
+def test_fold_units_keep_every_rank_busy_and_labels_bit_identical(world):
+    """Three folds x two tile rows = six (fold, row) units: with tile rows alone two ranks would work, with the units every rank up
+    to six runs conv launches; the ordered fp16 fold sum is evaluated on every rank's plane share from the all-reduced (plane-disjoint)
+    normalised logits, so the labels equal the one-process run's bit for bit.  Ranks share cuda:0, slabs / logits travel over gloo."""
+    import torch.multiprocessing as mp
+    from boa_hip import sliding_window as sw
+    from boa_hip import tile_shard as ts
+    from boa_hip.device import Context
+    c = Context(0)
+    want = _fold_predict(c)
+    c.close()
+    assert len(np.unique(want)) > 3
+    origins = sw.get_sliding_window_origins(list(FOLD_SHAPE), [32, 32, 32], 0.5)
+    assert ts.plan_rows(origins, 32, FOLD_SHAPE[0], world).active == 2          # rows alone: two active ranks
+    units = ts.plan_units([2] * 3, world)
+    assert sorted({r for blocks in units for r, _ in blocks}) == list(range(world))
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_fold_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(world):
+        lab, launches = got[r]
+        np.testing.assert_array_equal(lab, want)
+        assert launches > 0, f"rank {r} ran no network launch"

@@ -444,3 +444,33 @@ def test_grouped_slab_exchange_cannot_deadlock_with_both_neighbours(group_msgs):
         bad[victim] = bad[victim][::-1]
         with pytest.raises(AssertionError, match="deadlock"):
             _simulate_rendezvous(bad)
+
+
+def test_fold_units_keep_eight_ranks_busy_on_the_bca_nets():
+    """The BCA half of `total+bca` at 512^3: both nets run at (5 mm, 1.5, 1.5) -> a 154 x 512 x 512 grid, patch 128^3, step 0.5: TWO
+    tile rows along axis 0 (7 x 7 tiles each) and five folds.  Tile rows alone give two active ranks; the (fold, row) units of
+    predictor._ShardedJob (plan_units over [rows] * folds) give every one of 8 ranks work, each fold's rows stay on at most two ranks
+    (one slab boundary per fold), and every (fold, row) unit is owned exactly once."""
+    from boa_hip import sliding_window as sw
+    from boa_hip import tile_shard as ts
+    world, folds = 8, 5
+    PV, _ = sw.pad_amounts([154, 512, 512], [128, 128, 128])
+    origins = np.array(sw.get_sliding_window_origins(PV, [128] * 3, 0.5))
+    rows = sorted(set(int(o[0]) for o in origins))
+    assert len(rows) == 2 and len(origins) == 2 * 49
+    assert ts.plan_rows(origins, 128, PV[0], world).active == 2
+    units = ts.plan_units([len(rows)] * folds, world)
+    busy = sorted({r for blocks in units for r, _ in blocks})
+    assert busy == list(range(world)), busy
+    load = {r: 0 for r in range(world)}
+    for f, blocks in enumerate(units):
+        assert sum(n for _, n in blocks) == len(rows) and len(blocks) <= 2
+        plan = ts.plan_rows(origins, 128, PV[0], world, assignment=blocks)
+        seen = np.zeros(len(origins), int)
+        for r, _ in blocks:
+            seen[plan.tiles(r)] += 1
+            load[r] += len(plan.tiles(r))
+        assert (seen == 1).all()
+        lo_hi = [plan.owned_planes(r) for r, _ in blocks]
+        assert lo_hi[0][0] == 0 and lo_hi[-1][1] == PV[0] and all(a[1] == b[0] for a, b in zip(lo_hi, lo_hi[1:]))
+    assert max(load.values()) <= 2 * 49 and min(load.values()) >= 49     # 490 tile forwards over 8 ranks: 49 .. 98 each (2 ranks alone: 245)
