@@ -99,6 +99,7 @@ _PROTOS = {
     "boa_label_overlay": (i32, [vp, vp, u64, vp]),
     "boa_median3_inplane": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "boa_bits_words": (u64, [i32, i32, i32]),
+    "boa_bits_erode_u8": (i32, [vp, vp, vp, i32, i32, i32, i32, i32]),
     "boa_bits_select": (i32, [vp, vp, i32, i32, i32, vp, i32, vp]),
     "boa_bits_unpack": (i32, [vp, vp, i32, i32, i32, vp]),
     "boa_bits_fill_supported": (i32, [i32, i32]),

@@ -124,7 +124,10 @@ extern "C" int boa_tissue_aggregate(boa_ctx* c, const int16_t* dev_ct, const int
     const bool vec8 = (sv % 8 == 0) && (((uintptr_t)dev_ct) % 16 == 0) && (((uintptr_t)dev_regions) % 8 == 0) &&
                       (((uintptr_t)dev_parts) % 8 == 0) && (((uintptr_t)dev_tissues_out) % 8 == 0);
     const int nvec = vec8 ? sv / 8 : sv;
-    int gx = std::min(ceil_div(nvec, 256), 64);
+    // workgroups per slice: 16 (each thread reduces >= 64 voxels before the wave / block reduction and its 14 global atomics; 64
+    // workgroups per slice measured 0.43 ms per 512^3 volume, 8 ... 32: 0.35 ms); $BOA_TISSUE_GX: experiment hook
+    static const int gx_cap = getenv("BOA_TISSUE_GX") ? atoi(getenv("BOA_TISSUE_GX")) : 16;
+    int gx = std::min(ceil_div(nvec, 256), gx_cap);
     const double vox = (double)Z * sv;
     KernelTimer t(c, BOA_K_AGG, 0, vox * (3.0 + (dev_ct_rules ? 2 : 0) + (dev_parts ? 1 : 0) + (dev_tissues_out ? 1 : 0)));
     if (vec8)
@@ -518,6 +521,8 @@ __global__ __launch_bounds__(256) void k_erode_axis(const unsigned char* __restr
     out[i] = r;
 }
 
+extern "C" int boa_bits_erode_u8(boa_ctx* c, const uint8_t* dev_mask, uint8_t* dev_out, int Z, int Y, int X, int lo, int hi);
+
 extern "C" int boa_binary_erode(boa_ctx* c, const uint8_t* dev_mask, uint8_t* dev_out, uint8_t* dev_tmp, int Z, int Y,
                                 int X, int kernel_value) {
     BOA_REQUIRE(c && dev_mask && dev_out && dev_tmp && kernel_value >= 1, "boa_binary_erode: bad argument");
@@ -526,6 +531,10 @@ extern "C" int boa_binary_erode(boa_ctx* c, const uint8_t* dev_mask, uint8_t* de
     const int center = (k % 2 == 0) ? (k + 1) / 2 : k / 2;  // centre of the (padded) footprint
     const int lo = -center, hi = k - 1 - center;
     const size_t n = (size_t)Z * Y * X;
+    // bit-mask form (csrc/ccl_bits.hip): 1 byte read + 1 byte written per voxel and three passes over 1 / 8 byte per voxel, instead of
+    // three byte passes of one thread per voxel (1.9 ms -> 0.2 ms per 512^3 mask); $BOA_ERODE_BYTES=1 keeps the byte passes
+    static const bool bytes_only = getenv("BOA_ERODE_BYTES") != nullptr;
+    if (!bytes_only && lo > -32 && hi < 32) return boa_bits_erode_u8(c, dev_mask, dev_out, Z, Y, X, lo, hi);
     unsigned grid = (unsigned)((n + 255) / 256);
     KernelTimer t(c, BOA_K_AGG, 0, (double)n * 6.0);
     hipLaunchKernelGGL(k_erode_axis, dim3(grid), dim3(256), 0, c->stream, dev_mask, dev_out, Z, Y, X, 2, lo, hi);

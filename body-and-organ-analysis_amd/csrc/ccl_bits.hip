@@ -99,7 +99,56 @@ __global__ __launch_bounds__(256) void k_bits_unpack(const unsigned* __restrict_
     const unsigned v = bits[wi];
     unsigned char* p = out + row * g.X + (size_t)w * 32;
     const int cnt = min(32, g.X - w * 32);
-    for (int i = 0; i < cnt; ++i) p[i] = (unsigned char)((v >> i) & 1u);
+    if (cnt == 32 && (((uintptr_t)p) & 15) == 0) {
+        unsigned ww[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned n4 = (v >> (4 * k)) & 0xfu;
+            ww[k] = (n4 & 1u) | ((n4 & 2u) << 7) | ((n4 & 4u) << 14) | ((n4 & 8u) << 21);
+        }
+        *(uint4*)p = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        *(uint4*)(p + 16) = make_uint4(ww[4], ww[5], ww[6], ww[7]);
+    } else {
+        for (int i = 0; i < cnt; ++i) p[i] = (unsigned char)((v >> i) & 1u);
+    }
+}
+
+// ---- binary erosion with a box footprint on bit masks (erode_region, BOA/compute/measurements.py:61-71: skimage binary_erosion
+// with the 6^3 footprint, pad_footprint for even sizes): AND over the offsets [lo, hi] along one axis, positions outside the volume
+// count as set.  Three separable passes move 3 x 2 bits per voxel instead of 3 x 2 bytes.
+__global__ __launch_bounds__(256) void k_bits_erode_axis(const unsigned* __restrict__ in, CbGeom g, int axis, int lo, int hi, unsigned* __restrict__ out) {
+    const size_t wi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (wi >= g.words) return;
+    const int w = (int)(wi % g.W);
+    const size_t row = wi / g.W;
+    const int y = (int)(row % g.Y), z = (int)(row / g.Y);
+    unsigned r = 0xFFFFFFFFu;
+    if (axis == 2) {
+        auto word = [&](int ww) -> unsigned {   // bits beyond the volume are set
+            if (ww < 0 || ww >= g.W) return 0xFFFFFFFFu;
+            return in[row * g.W + ww] | ~cb_valid_word(g.X, ww);
+        };
+        const unsigned prev = word(w - 1), cur = word(w), next = word(w + 1);
+        for (int d = lo; d <= hi; ++d) {
+            unsigned v;
+            if (d == 0)
+                v = cur;
+            else if (d < 0)
+                v = (cur << (-d)) | (prev >> (32 + d));      // bit i <- voxel x + d
+            else
+                v = (cur >> d) | (next << (32 - d));
+            r &= v;
+        }
+    } else {
+        const int pos = axis == 0 ? z : y, len = axis == 0 ? g.Z : g.Y;
+        const long long st = axis == 0 ? (long long)g.Y * g.W : (long long)g.W;
+        for (int d = lo; d <= hi; ++d) {
+            const int q = pos + d;
+            if (q < 0 || q >= len) continue;
+            r &= in[(long long)wi + d * st];
+        }
+    }
+    out[wi] = r & cb_valid_word(g.X, w);
 }
 
 // out[v] = labels[m] for the LARGEST m whose mask has the voxel (`out[filled] = label` in ascending label order); voxels in no mask
@@ -766,6 +815,35 @@ extern "C" int boa_bits_assign_labels(boa_ctx* c, const uint32_t* dev_bits, int 
     hipLaunchKernelGGL(k_bits_assign, dim3((unsigned)((g.words + 255) / 256)), dim3(256), 0, c->stream, dev_bits, g, n_masks, lb, dev_out);
     t.stop();
     BOA_HIP_TRY(hipGetLastError());
+    return BOA_OK;
+}
+
+// dev_mask (uint8, != 0 = set) -> dev_out (uint8 0 / 1): three separable passes on bit masks; offsets [lo, hi] per axis (|offset| < 32)
+extern "C" int boa_bits_erode_u8(boa_ctx* c, const uint8_t* dev_mask, uint8_t* dev_out, int Z, int Y, int X, int lo, int hi) {
+    BOA_REQUIRE(c && dev_mask && dev_out && Z > 0 && Y > 0 && X > 0 && lo <= 0 && hi >= 0 && lo > -32 && hi < 32, "boa_bits_erode_u8: bad argument");
+    const CbGeom g = cb_geom(Z, Y, X);
+    unsigned* a = nullptr;
+    unsigned* b = nullptr;
+    BOA_TRY(boa_malloc(c, g.words * 4, (void**)&a));
+    if (int rc = boa_malloc(c, g.words * 4, (void**)&b)) {
+        boa_free(c, a);
+        return rc;
+    }
+    CbLut lut;
+    lut.v[0] = 0;
+    for (int i = 1; i < 256; ++i) lut.v[i] = 1;
+    const unsigned grid = (unsigned)((g.words + 255) / 256);
+    KernelTimer t(c, BOA_K_AGG, 0, 2.0 * (double)g.vox);
+    hipLaunchKernelGGL(k_bits_select, dim3(grid), dim3(256), 0, c->stream, dev_mask, g, lut, 1, a);
+    hipLaunchKernelGGL(k_bits_erode_axis, dim3(grid), dim3(256), 0, c->stream, a, g, 2, lo, hi, b);
+    hipLaunchKernelGGL(k_bits_erode_axis, dim3(grid), dim3(256), 0, c->stream, b, g, 1, lo, hi, a);
+    hipLaunchKernelGGL(k_bits_erode_axis, dim3(grid), dim3(256), 0, c->stream, a, g, 0, lo, hi, b);
+    hipLaunchKernelGGL(k_bits_unpack, dim3(grid), dim3(256), 0, c->stream, b, g, dev_out);
+    t.stop();
+    const hipError_t e = hipGetLastError();
+    boa_free(c, a);
+    boa_free(c, b);
+    BOA_HIP_TRY(e);
     return BOA_OK;
 }
 

@@ -395,8 +395,11 @@ int boa_mask_assign(boa_ctx* ctx, const uint8_t* dev_mask, size_t n, int invert,
  *                           (np.invert / remove_small_objects / np.invert: small holes are filled)
  *   boa_bits_filter_largest _filter_largest_unique_segment on ONE mask: seg = fill_value outside its largest component
  *   boa_bits_assign_labels  out[v] = host_labels[m] for the largest m whose mask holds v (`out[filled] = label`, ascending); voxels in no
- *                           mask of the batch keep their value: zero `out` first, apply batches of <= 8 labels in ascending order */
+ *                           mask of the batch keep their value: zero `out` first, apply batches of <= 8 labels in ascending order
+ *   boa_bits_erode_u8       uint8 mask -> uint8 0 / 1 mask eroded by the box of offsets [lo, hi] per axis (outside the volume counts as
+ *                           set): what boa_binary_erode runs (pack, three separable passes on bits, unpack) */
 size_t boa_bits_words(int Z, int Y, int X);
+int boa_bits_erode_u8(boa_ctx* ctx, const uint8_t* dev_mask, uint8_t* dev_out, int Z, int Y, int X, int lo, int hi);
 int boa_bits_select(boa_ctx* ctx, const uint8_t* dev_seg, int Z, int Y, int X, const uint8_t host_lut[256], int n_masks, uint32_t* dev_bits);
 int boa_bits_unpack(boa_ctx* ctx, const uint32_t* dev_bits, int Z, int Y, int X, uint8_t* dev_out);
 int boa_bits_fill_supported(int Y, int X);

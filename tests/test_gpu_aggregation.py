@@ -112,6 +112,11 @@ def test_erosion_vs_oracle(ctx):
         np.testing.assert_array_equal(M.erode_region(ctx, m), OM.erode_region(m))
     m = rng.random((16, 16, 16)) < 0.98
     np.testing.assert_array_equal(M.erode_region(ctx, m, 3), OM.erode_region(m, 3))
+    # rows that span several mask words and end inside one (the bit-mask passes carry bits across word boundaries), other footprints
+    for shape, p, k in [((7, 9, 70), 0.99, 6), ((4, 5, 100), 0.98, 5), ((3, 33, 65), 0.99, 2), ((6, 6, 97), 0.995, 9), ((2, 3, 33), 1.0, 6),
+                        ((3, 4, 64), 0.97, 1)]:
+        m = rng.random(shape) < p
+        np.testing.assert_array_equal(M.erode_region(ctx, m, k), OM.erode_region(m, k), err_msg=f"{shape} k={k}")
 
 
 def test_total_measurements_vs_oracle(ctx):

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Wall time of the aggregation scan stages on the structured phantoms at 512^3 (median of 5 synchronised calls): tissue aggregate,
+label HU histogram, 6^3 erosion.  Development aid for the HBM fractions that bench.py reports as `phantom_stages`."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "body-and-organ-analysis_amd")]
+import numpy as np  # noqa: E402
+from boa_hip import bca, synthetic  # noqa: E402
+from boa_hip import measurements as M  # noqa: E402
+from boa_hip.device import Context  # noqa: E402
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+shape = (size,) * 3
+n = size ** 3
+ctx = Context(0)
+ct = np.ascontiguousarray(synthetic.ct_phantom(shape, seed=3).transpose(2, 1, 0))
+d_ct = ctx.from_numpy(ct)
+d = {k: ctx.from_numpy(np.ascontiguousarray(f(shape).transpose(2, 1, 0))) for k, f in (("total", synthetic.label_phantom_total),
+                                                                                      ("parts", synthetic.label_phantom_parts),
+                                                                                      ("regions", synthetic.label_phantom_regions))}
+
+
+def timed(name, fn, nbytes):
+    ts = []
+    for _ in range(6):
+        ctx.sync()
+        t = time.perf_counter()
+        r = fn()
+        ctx.sync()
+        ts.append(time.perf_counter() - t)
+        if hasattr(r, "free"):
+            r.free()
+    ms = float(np.median(ts[1:])) * 1e3
+    print(f"{name:24s} {ms:7.3f} ms  {nbytes / ms / 1e6:8.1f} GB/s  {nbytes / ms / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
+
+
+timed("tissue_aggregate", lambda: bca.tissue_aggregate(ctx, d_ct, d["regions"], d["parts"], shape)[0], 5.0 * n)
+timed("label_hu_histogram", lambda: M.label_hu_histogram(ctx, d_ct, d["total"], n) is None, 3.0 * n)
+d_m, d_o, d_t = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+M.label_hu_mask(ctx, d_ct, d["total"], range(1, 30), 0, n, d_m)
+timed("binary_erode_6", lambda: M.binary_erode(ctx, d_m, d_o, d_t, shape, 6), 2.0 * n)
+timed("slice_label_presence", lambda: bca.slice_label_presence(ctx, d["regions"], shape) is None, 1.0 * n)
+ctx.close()
