@@ -5,7 +5,7 @@
 #      total+bca workload at 512^3 (one volume, 1 605 tile forwards) -> <tag>_pmc_fetch_write_512.json
 #   3. matrix-core counters (SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE) on one 8-tile batch   -> <tag>_pmc_mfma.json
 # Results land in gpurun_out/prof_<tag>/, the summaries to commit in gpurun_out/profiles_<tag>/ (copy them into profiles/).
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
