@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 HBM_PEAK_GBPS = 8000.0               # same guide: 8 TB/s spec (6.3 TB/s measured for a float4 copy)
 HBM_COPY_GBPS = 6300.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_fetch_write_512.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_fetch_write_512.json")
 
 
 def parse_args():
