@@ -384,45 +384,8 @@ __global__ __launch_bounds__(256) void k_cb_local(const unsigned* __restrict__ b
         lab[r2 * CB_TX + lx] = ((me >> lx) & 1u) ? r2 * CB_TX + (31 - __clz((int)upto)) : -1;
     }
     __syncthreads();
-#ifdef CB_FLATTEN
-    // (experiment) one neighbour-row class per phase, with a pointer-jumping pass over all foreground voxels in between: the chains
-    // that the unions of a phase leave behind are flattened before the next phase walks them
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        for (int r2 = tid >> 5; r2 < CB_TY * CB_TZ; r2 += 8) {
-            const int lx = tid & 31, ly = r2 % CB_TY, lz = r2 / CB_TY;
-            const unsigned int me = rowbits[r2];
-            if (!((me >> lx) & 1u)) continue;
-            const int i = r2 * CB_TX + lx;
-            const bool a_l = lx > 0 && ((me >> (lx - 1)) & 1u), a_r = lx + 1 < CB_TX && ((me >> (lx + 1)) & 1u);
-            const int dz = r == 0 ? 0 : 1, dy = r == 0 ? 1 : r - 2;
-            const int zz = lz + dz, yy = ly + dy;
-            if (zz >= CB_TZ || yy < 0 || yy >= CB_TY) continue;
-            const int rr = zz * CB_TY + yy;
-            const unsigned int w = rowbits[rr];
-            const bool m0 = lx > 0 && ((w >> (lx - 1)) & 1u), m1 = (w >> lx) & 1u, m2 = lx + 1 < CB_TX && ((w >> (lx + 1)) & 1u);
-            const int row = rr * CB_TX;
-            if (m1) {
-                if (!(a_l && m0)) cb_lds_union(lab, i, row + lx);
-            } else {
-                if (m2 && !a_r) cb_lds_union(lab, i, row + lx + 1);
-                if (m0 && !a_l) cb_lds_union(lab, i, row + lx - 1);
-            }
-        }
-        __syncthreads();
-        if (r < 3) {
-            for (int r2 = tid >> 5; r2 < CB_TY * CB_TZ; r2 += 8) {
-                const int lx = tid & 31;
-                if ((rowbits[r2] >> lx) & 1u) {
-                    const int i = r2 * CB_TX + lx;
-                    const int rt = cb_lds_find(lab, i);
-                    if (rt != i) lab[i] = rt;
-                }
-            }
-            __syncthreads();
-        }
-    }
-#else
+    // (measured and not kept: one neighbour-row class per phase with a pointer-jumping pass in between -- 42.8 -> 50.6 ms on the 512^3
+    //  noise labels: the chains are short, the extra passes are not)
     for (int r2 = tid >> 5; r2 < CB_TY * CB_TZ; r2 += 8) {
         const int lx = tid & 31, ly = r2 % CB_TY, lz = r2 / CB_TY;
         const unsigned int me = rowbits[r2];
@@ -446,7 +409,6 @@ __global__ __launch_bounds__(256) void k_cb_local(const unsigned* __restrict__ b
             }
         }
     }
-#endif
     __syncthreads();
     int myroot[CB_TILE / 256];
 #pragma unroll
