@@ -41,6 +41,10 @@ import numpy as np  # noqa: E402
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 HBM_PEAK_GBPS = 8000.0               # same guide: 8 TB/s spec (6.3 TB/s measured for a float4 copy)
 HBM_COPY_GBPS = 6300.0
+# tools/write_bw.hip on the bench's MI355X (round 5): pure 16-byte-per-lane WRITE stream 4.0 - 5.5 TB/s by grid (4.7 at 4 workgroups per
+# CU), pure read 6.37, copy 4.6 - 5.3: what the write-dominated kernels (first conv: 94 % of its bytes are stores, transposed conv: 89 %)
+# can be priced against besides the 8 TB/s data-sheet figure
+HBM_WRITE_GBPS = 4700.0
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_fetch_write_512.json")
 
 
@@ -718,6 +722,8 @@ def main():
                                "frac": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6 / HBM_PEAK_GBPS,
                                # against what a plain float4 copy reaches on this part (MI355X_MICROARCH.md: 6.3 TB/s measured)
                                "frac_of_measured_copy": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6 / HBM_COPY_GBPS,
+                               "frac_of_measured_write_stream": (prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6 / HBM_WRITE_GBPS
+                                                                 if k in ("convT_mfma", "conv_first") else None),
                                "ms": prof[k]["ms"], "launches": prof[k]["launches"]}
                            for k in ("head_accum", "finalize_argmax", "convT_mfma", "conv_first") if prof[k]["launches"]},
             # (head_accum: since round 3 the gather form of the tile loop -- stash read + labels, no accumulator planes, no separate

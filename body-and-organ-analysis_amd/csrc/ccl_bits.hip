@@ -902,7 +902,6 @@ extern "C" int boa_bits_remove_small(boa_ctx* c, uint32_t* dev_bits, int Z, int 
     BOA_REQUIRE(c && dev_bits && Z > 0 && Y > 0 && X > 0 && n_masks >= 1 && n_masks <= 64, "boa_bits_remove_small: bad argument");
     const CbGeom g = cb_geom(Z, Y, X);
     BOA_REQUIRE(g.vox < (1ull << 31) && g.tiles * CB_CAP < (1ull << 31), "boa_bits_remove_small: volume too large for int32 indices");
-    BOA_REQUIRE((size_t)g.Z * n_masks <= 65535 && (size_t)g.tz * n_masks <= 65535, "boa_bits_remove_small: too many planes for one launch");
     CbScratch s;
     BOA_TRY(s.alloc(c, g, n_masks));
     KernelTimer t(c, BOA_K_MORPH, 0, (double)n_masks * (8.0 * (double)g.words + 4.0 * (double)g.vox));
@@ -918,7 +917,6 @@ extern "C" int boa_bits_filter_largest(boa_ctx* c, const uint32_t* dev_bits, int
     BOA_REQUIRE(c && dev_bits && dev_seg && Z > 0 && Y > 0 && X > 0, "boa_bits_filter_largest: bad argument");
     const CbGeom g = cb_geom(Z, Y, X);
     BOA_REQUIRE(g.vox < (1ull << 31) && g.tiles * CB_CAP < (1ull << 31), "boa_bits_filter_largest: volume too large for int32 indices");
-    BOA_REQUIRE((size_t)g.Z <= 65535, "boa_bits_filter_largest: too many planes for one launch");
     CbScratch s;
     BOA_TRY(s.alloc(c, g, 1));
     unsigned long long* d_best = nullptr;
