@@ -329,3 +329,68 @@ def test_cubic_resampling_large_vs_scipy(ctx):
     assert out.shape == ref.shape == (512, 512, 77)
     np.testing.assert_array_equal(out.view(np.uint64), ref.view(np.uint64))
     np.testing.assert_array_equal(out.astype(np.int32), ref.astype(np.int32))
+
+
+def test_bits_morphology_full_size(ctx, monkeypatch):
+    """The bit-mask post-processing (csrc/ccl_bits.hip) at full size.  (a) remove_small_objects on 256 x 512 x 512 (8 192 tiles, a batch of
+    the blobby mask and two noise densities; objects and holes) against scipy.ndimage.label; (b) the product functions on the 512^3
+    structured phantoms (6 body parts, 11 nested regions) and on a speckled copy: bit path == byte path ($BOA_MORPH_BYTES=1, the boa_ccl26
+    chain pinned against scipy above and in tests/test_gpu_aggregation.py)."""
+    import ctypes as C
+    from scipy import ndimage
+    from boa_hip import bca, synthetic
+    from boa_hip._lib import check
+    from boa_hip.device import BufferView
+    shape = (256, 512, 512)
+    n = int(np.prod(shape))
+    rng = np.random.default_rng(23)
+    coarse = ndimage.gaussian_filter(rng.standard_normal((64, 128, 128)).astype(np.float32), 1.5)
+    sm = ndimage.zoom(coarse, 4, order=1)
+    sm += 0.02 * rng.standard_normal(shape).astype(np.float32)
+    masks = [sm > 0.01, rng.random(shape) < 0.06]      # (26-connected site percolation sets in near 0.1: 0.06 keeps many finite clusters)
+    seg = np.zeros(shape, np.uint8)
+    for j, m in enumerate(masks):
+        seg |= m.astype(np.uint8) << j
+    lut = np.arange(256, dtype=np.uint8)
+    words = int(ctx.lib.boa_bits_words(*shape))
+    d_seg = ctx.from_numpy(seg)
+    d_bits, d_o = ctx.alloc(words * 4 * len(masks)), ctx.alloc(n)
+    S = np.ones((3, 3, 3), bool)
+    removed = kept = 0
+    try:
+        for invert, max_size in ((0, 2999), (1, 2999)):
+            check(ctx.lib.boa_bits_select(ctx.h, d_seg.vp, *shape, lut.ctypes.data_as(C.c_void_p), len(masks), d_bits.vp), "boa_bits_select")
+            check(ctx.lib.boa_bits_remove_small(ctx.h, d_bits.vp, *shape, len(masks), max_size, invert), "boa_bits_remove_small")
+            for j, m in enumerate(masks):
+                check(ctx.lib.boa_bits_unpack(ctx.h, BufferView(d_bits, j * words * 4, words * 4).vp, *shape, d_o.vp), "boa_bits_unpack")
+                got = d_o.download(shape, np.uint8).astype(bool)
+                src = ~m if invert else m
+                lab, k = ndimage.label(src, structure=S)
+                small = np.bincount(lab.ravel()) <= max_size
+                small[0] = False
+                want = src & ~small[lab]
+                np.testing.assert_array_equal(got, ~want if invert else want, err_msg=f"mask {j} invert {invert}")
+                removed += int(small[1:].sum())
+                kept += int((~small[1:]).sum())
+    finally:
+        for b in (d_seg, d_bits, d_o):
+            b.free()
+    assert removed > 1000 and kept >= 3      # thousands of small components went, the giant ones stayed
+    # (b) product functions: bit path == byte path on the structured phantoms and on a speckled copy
+    p3 = (512, 512, 512)
+    parts = np.ascontiguousarray(synthetic.label_phantom_parts(p3).transpose(2, 1, 0))
+    regions = np.ascontiguousarray(synthetic.label_phantom_regions(p3).transpose(2, 1, 0))
+    speck = rng.random(p3) < 0.003
+    parts_s, regions_s = parts.copy(), regions.copy()
+    parts_s[speck] = rng.integers(0, 7, int(speck.sum())).astype(np.uint8)
+    regions_s[speck] = rng.integers(0, 12, int(speck.sum())).astype(np.uint8)
+    for a, fn in ((parts, bca.postprocess_part_segmentation), (parts_s, bca.postprocess_part_segmentation),
+                  (regions, bca.postprocess_region_segmentation), (regions_s, bca.postprocess_region_segmentation)):
+        monkeypatch.delenv("BOA_MORPH_BYTES", raising=False)
+        got = fn(ctx, a)
+        monkeypatch.setenv("BOA_MORPH_BYTES", "1")
+        want = fn(ctx, a)
+        np.testing.assert_array_equal(got, want)
+    monkeypatch.delenv("BOA_MORPH_BYTES", raising=False)
+    assert (bca.postprocess_part_segmentation(ctx, parts) == parts).all()           # the clean phantom is a fixed point
+    assert (bca.postprocess_region_segmentation(ctx, regions_s) == 255).any()        # the specks are filtered
