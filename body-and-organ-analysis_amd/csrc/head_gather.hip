@@ -586,8 +586,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GH_WAVES, 8
 }
 
 // prefetching variant of the fp16 head: 20 KB of LDS slots per block + the (scale, shift) table: four blocks per CU
+#ifndef GH_PF_MULTI_WAVES
+#define GH_PF_MULTI_WAVES 4   // experiment hook.  3 waves per EU (round 5, tools/gh_fold_time.py, five-fold 154 x 512 x 512): 157 VGPRs
+                              // and no spills for the fold variants instead of 128 with 2 - 4 spilled, but 18.4 vs 17.3 ms per
+                              // five fold launches: the occupancy is worth more than the spills, 4 stays.
+#endif
 template <bool GAUSS, bool SSLDS, bool MULTI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_gather_head_pf(GatherArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MULTI ? GH_PF_MULTI_WAVES : 4, 8))) void k_gather_head_pf(GatherArgs p) {
     gather_head_body<GAUSS, SSLDS, MULTI, false, true>(p);
 }
 
