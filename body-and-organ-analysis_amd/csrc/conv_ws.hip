@@ -27,7 +27,35 @@
 
 #include "conv.h"
 
+#ifndef WS_DESC
+#define WS_DESC 1   // per-tile descriptors from a precomputed table (conv_ws_dev.h) instead of the in-kernel tile walk
+#endif
+
 #include "conv_ws_dev.h"
+
+// Builds the descriptor rows of a launch: thread b walks physical workgroup b's tile sequence with the kernels' own code.
+__global__ __launch_bounds__(64) void k_ws_build_desc(ConvArgs p, int grid, int row, int* __restrict__ out) {
+    const int b = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    if (b >= grid) return;
+    int* r = out + (size_t)b * row * 8;
+    int my = 0;
+    for (int v = b; v < p.N * p.vw; v += grid) my += p.runs[(v % p.vw) * 8];
+    if (my > row - 1) my = row - 1;   // (cannot happen: the host sizes the rows with an upper bound; checked there)
+    r[0] = my;
+    for (int i = 1; i < 8; ++i) r[i] = 0;
+    TileSeq s;
+    s.n = s.left = s.j = 0;
+    for (int k = 0; k < my; ++k) {
+        bool new_run = true;
+        if (k == 0)
+            seq_first_of(p, s, b);
+        else
+            new_run = seq_next(p, s);
+        const TileDesc d = make_desc(p, s, new_run);
+        int* e = r + (size_t)(k + 1) * 8;
+        e[0] = d.tc.n; e[1] = d.tc.cy; e[2] = d.tc.ox0; e[3] = d.tc.oy0; e[4] = d.tc.oz0; e[5] = d.flags; e[6] = d.vo; e[7] = d.ibase;
+    }
+}
 
 // ---- consumer ----------------------------------------------------------------------------------------
 // One 16-channel chunk: acc[r] += W[tap] x X[tap][r] for all taps.  bp[r]: LDS address of this lane's voxel of
@@ -174,7 +202,8 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
 // (consume_chunk), the epilogue un-scales the accumulators and stores fp32.  Measured against an fp32 FMA chain the product of
 // split operands is the more accurate of the two (tools/x3_probe.hip: rms error 3.2e-7 vs 5.3e-7 of the output rms at K = 864).
 template <int R, int K0, int K1, int K2, bool YR, bool X3>
-__global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_tiles, int resident_w, int dbg) {
+__global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_tiles, int resident_w, int dbg, const int* __restrict__ desc,
+                                                        int desc_row) {
     // (round 5, measured and not kept: hipcc re-loads kernel arguments from the kernarg segment in the per-tile paths instead of keeping
     //  them -- chains of s_load_dwordx8/x16 + s_waitcnt in the tile walk and the epilogue addressing; passing every argument through an
     //  empty asm removed all of those loads from the loops (16 instead of 38 s_load, 480 instead of 314 v_readlane) and made every
@@ -197,8 +226,13 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     unsigned char* bufs = smem + wres_bytes;
 
     // this workgroup's tiles: the runs of the virtual workgroups b, b + G, ...
+#if WS_DESC
+    const int* __restrict__ drow = desc + (size_t)blockIdx.x * desc_row * 8;
+    const int my_tiles = drow[0];
+#else
     int my_tiles = 0;
     for (int v = (int)blockIdx.x; v < p.N * p.vw; v += (int)gridDim.x) my_tiles += p.runs[(v % p.vw) * 8];
+#endif
     const int my_chunks = my_tiles * ncc;
 
     // X3: the (scaled) bias in the D-fragment order lives in LDS behind the buffers and is read straight INTO the accumulators at
@@ -225,9 +259,16 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         // (measured +8 % on the 32 -> 64 stride-2 layer); the stride-1 kernels give the consumers the higher priority
         if (R == 1 && !(dbg & 256)) __builtin_amdgcn_s_setprio(3);
         const ProdConst pc = prod_const(p, q, HV);
+#if WS_DESC
+        TileDesc pd;
+        pd.flags = pd.vo = pd.ibase = 0;
+        TileCoord& ptc = pd.tc;
+        int pk = 0;   // tile whose chunks are being issued
+#else
         TileSeq pseq;
         pseq.n = pseq.left = pseq.j = 0;
         TileCoord& ptc = pseq.tc;
+#endif
         ptc.n = ptc.cy = ptc.ox0 = ptc.oy0 = ptc.oz0 = ptc.sp = 0;
         ProdItems items;
 #pragma unroll
@@ -248,8 +289,13 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         int w_cc = 0, w_cy = 0;  // (chunk, cout chunk) of the chunk issued last = the one committed next (its weights go by DMA)
         const bool live = !(dbg & 2);
         if (live && my_chunks > 0) {
+#if WS_DESC
+            pd = load_desc(drow, 0);
+            prod_setup_desc(p, pd, pc, items);
+#else
             seq_first(p, pseq);
             prod_setup(p, ptc, pc, items);
+#endif
             prod_issue(p, ptc, items, pc.in_halo, 0, false, q, dbg, rg);
             w_cy = ptc.cy;
             if (++pcc == ncc) pcc = 0;
@@ -265,9 +311,15 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 // reads `rg`, the DMA the (chunk, cout chunk) saved at issue time.)
                 const bool do_issue = g + 2 < my_chunks;
                 if (do_issue && pcc == 0) {
+#if WS_DESC
+                    pd = load_desc(drow, ++pk);
+                    reuse = (pd.flags & WS_DF_REUSE) != 0;  // same spatial tile as the previous tile of this run
+                    if (!reuse) prod_setup_desc(p, pd, pc, items);
+#else
                     const bool new_run = seq_next(p, pseq);
                     reuse = p.cy_fast && ptc.cy != 0 && !new_run;  // same spatial tile as the previous tile of this run
                     if (!reuse) prod_setup(p, ptc, pc, items);
+#endif
                     WS_STAMP(8);
                 }
                 if (p.trace) {
@@ -285,7 +337,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 #pragma unroll
                     for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(rg.ssw[j]));
                     // (unconditionally: at the join behind a conditional use hipcc would wait again)
-                    if (want_w) dma_weights(p, w_cc, w_cy, nxt + 2 * plane, q, taps);
+                    if (want_w) dma_weights(p, __builtin_amdgcn_readfirstlane(w_cc), __builtin_amdgcn_readfirstlane(w_cy), nxt + 2 * plane, q, taps);
                 }
                 if constexpr (X3)
                     prod_commit_x3(p, rg, nxt, q, HV, plane, dbg);
@@ -400,9 +452,16 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         }
     };
 
+#if WS_DESC
+    TileDesc cd;
+    cd.flags = cd.vo = cd.ibase = 0;
+    TileCoord& tc = cd.tc;
+    int done_fl = 0, done_vo = 0;
+#else
     TileSeq cseq;
     cseq.n = cseq.left = cseq.j = 0;
     TileCoord& tc = cseq.tc;
+#endif
     tc.n = tc.cy = tc.ox0 = tc.oy0 = tc.oz0 = tc.sp = 0;
     if (p.trace && blockIdx.x == 0 && tid == 0) {
         p.trace[WS_TRACE_SLOTS - 4] = __builtin_readcyclecounter();
@@ -414,7 +473,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     // issue the HBM-cold loads of the tile after next), the interval of a tile's last chunk their short one, so the roles'
     // long and short intervals now coincide instead of alternating in opposite phase.
     f32x16 acc[R];
-    auto epilogue = [&](const TileCoord& tc) {
+    auto epilogue = [&](const TileCoord& tc, int dfl, int dvo) {
+        (void)dfl;
+        (void)dvo;
         // ---- epilogue: + bias, InstanceNorm partial sums (fp32), register transpose (v_permlane32_swap), fp16
         // convert, two 16-byte stores per lane (32 contiguous bytes of the voxel's record)
         const bool two = TWO_SETS && p.cy_fast;
@@ -424,10 +485,16 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             st_cy = tc.cy;
         }
         const int cout0 = tc.cy * 32;
+#if WS_DESC
+        const bool full = (dfl & WS_DF_FULL) != 0;
+        const size_t ovox = (size_t)(unsigned)dvo;
+#else
         const bool full = tc.ox0 + p.b0 * p.w0 <= p.Do && tc.oy0 + p.b1 * p.w1 <= p.Ho && tc.oz0 + p.b2 * p.w2 <= p.Wo;
+        const size_t ovox = ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0;
+#endif
         // wave-uniform base + 32-bit lane offset (scalar-base global_store / global_load forms, see prod_issue)
         // chunk-planar output [N][Cout/16][voxel][16]: this lane writes the 16 couts of plane (cout0 / 16 + kh) of its voxel
-        const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + (((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * 16;
+        const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + ovox * 16;
         const unsigned olane = ((unsigned)kh * (unsigned)out_vox + (unsigned)srel0) * 32u;
 #ifdef WS_TRACE_EPILOGUE
         WS_STAMP(9);
@@ -473,7 +540,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 if (ok && !(dbg & 4)) {
                     // (wave-uniform by construction; the explicit readfirstlane keeps hipcc's divergence analysis from rejecting the
                     //  SGPR pin inside this branch: "illegal VGPR to SGPR copy")
-                    const size_t doff = ((size_t)tc.n * p.Cout + cout0) * out_vox * 4 + ((((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) + (size_t)mrel) * 32;
+                    const size_t doff = ((size_t)tc.n * p.Cout + cout0) * out_vox * 4 + (ovox + (size_t)mrel) * 32;
                     const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)doff), dhi = __builtin_amdgcn_readfirstlane((unsigned)(doff >> 32));
                     WS_GLOBAL unsigned char* dst = sgpr_ptr((const unsigned char*)p.out + (((size_t)dhi << 32) | dlo));
 #pragma unroll
@@ -551,25 +618,40 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 #ifdef WS_TRACE_EPILOGUE
         WS_STAMP(13);
 #endif
+#if WS_DESC
+        if (more) {
+            cd = load_desc(drow, k);
+            new_run = (cd.flags & WS_DF_NEWRUN) != 0;
+        }
+#else
         if (k == 0)
             seq_first(p, cseq);
         else if (more)
             new_run = seq_next(p, cseq);
+#endif
 #ifdef WS_TRACE_EPILOGUE
         WS_STAMP(14);
 #endif
 #if WS_DEFER_EPILOGUE
-        if (k > 0 && !(dbg & 8)) epilogue(done_tc);  // the previous tile's (its statistics belong to the previous run: before the flush)
+#if WS_DESC
+        if (k > 0 && !(dbg & 8)) epilogue(done_tc, done_fl, done_vo);  // the previous tile's (its statistics belong to the previous run: before the flush)
+#else
+        if (k > 0 && !(dbg & 8)) epilogue(done_tc, 0, 0);  // the previous tile's (its statistics belong to the previous run: before the flush)
+#endif
         if (!more) break;
 #endif
         if (new_run) {  // the partial sums of a virtual workgroup go to its own slot
             flush_stats();
             st_n = -1;
+#if WS_DESC
+            slot = (int)((unsigned)cd.flags >> 16) * 4 + cw;
+#else
             slot = cseq.j * 4 + cw;
+#endif
         }
         if (!X3 && tc.cy != bias_cy) {  // this lane's 16 biases of the cout chunk, D-fragment layout (entry 4 gq + e <-> cout 8 gq + 4 kh + e)
             bias_cy = tc.cy;
-            const WS_GLOBAL unsigned char* bbase = sgpr_ptr(p.bias + tc.cy * 32);
+            const WS_GLOBAL unsigned char* bbase = sgpr_ptr(p.bias + __builtin_amdgcn_readfirstlane(tc.cy) * 32);
             unsigned bl = (unsigned)kh * 16u;
             asm volatile("" : "+v"(bl));
 #pragma unroll
@@ -625,7 +707,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.h1, p.h2, acc, biasv);
             WS_STAMP(5);
 #if !WS_DEFER_EPILOGUE
-            if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc);
+#if WS_DESC
+            if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc, cd.flags, cd.vo);
+#else
+            if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc, 0, 0);
+#endif
 #endif
             WS_STAMP(6);
             __syncthreads();
@@ -637,6 +723,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         done_tc.ox0 = __builtin_amdgcn_readfirstlane(tc.ox0);
         done_tc.oy0 = __builtin_amdgcn_readfirstlane(tc.oy0);
         done_tc.oz0 = __builtin_amdgcn_readfirstlane(tc.oz0);
+#if WS_DESC
+        done_fl = __builtin_amdgcn_readfirstlane(cd.flags);
+        done_vo = __builtin_amdgcn_readfirstlane(cd.vo);
+#endif
     }
     if (p.trace && blockIdx.x == 0 && tid == 0) {
         p.trace[WS_TRACE_SLOTS - 2] = __builtin_readcyclecounter();
@@ -674,31 +764,31 @@ bool conv_ws_supported(const int k[3], int HV) {
 }
 
 template <int R, int K0, int K1, int K2, bool YR, bool X3>
-static void launch_ws_y(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
+static void launch_ws_y(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident, const int* desc, int desc_row) {
     static bool once = (hipFuncSetAttribute((const void*)k_conv_ws<R, K0, K1, K2, YR, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
     hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR, X3>), dim3(grid), dim3(WS_THREADS), t.lds_bytes + 2048, ctx->stream, a, total, resident,
-                       getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0);
+                       getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0, desc, desc_row);
 }
 
 template <int R, int K0, int K1, int K2, bool X3>
-static void launch_ws_t(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
+static void launch_ws_t(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident, const int* desc, int desc_row) {
     // row reuse: the R M-tiles of a wave are consecutive output rows (m = cw * R + r, my = m & (b1 - 1) when b2 == 1),
     // one voxel high, stride 1 along y
     static const bool off = getenv("BOA_WS_NO_YREUSE") != nullptr;
     const bool yr = R > 1 && K1 == 3 && a.s1 == 1 && a.w1 == 1 && a.b2 == 1 && a.b1 % R == 0 && !off;
     if (R > 1 && yr)
-        launch_ws_y<R, K0, K1, K2, (R > 1), X3>(ctx, a, t, total, grid, resident);
+        launch_ws_y<R, K0, K1, K2, (R > 1), X3>(ctx, a, t, total, grid, resident, desc, desc_row);
     else
-        launch_ws_y<R, K0, K1, K2, false, X3>(ctx, a, t, total, grid, resident);
+        launch_ws_y<R, K0, K1, K2, false, X3>(ctx, a, t, total, grid, resident, desc, desc_row);
 }
 
 template <int R, bool X3>
-static int launch_ws_r(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident) {
+static int launch_ws_r(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident, const int* desc, int desc_row) {
     if (a.k0 == 3 && a.k1 == 3 && a.k2 == 3)
-        launch_ws_t<R, 3, 3, 3, X3>(ctx, a, t, total, grid, resident);
+        launch_ws_t<R, 3, 3, 3, X3>(ctx, a, t, total, grid, resident, desc, desc_row);
     else if (a.k0 == 1 && a.k1 == 3 && a.k2 == 3)
-        launch_ws_t<R, 1, 3, 3, X3>(ctx, a, t, total, grid, resident);
+        launch_ws_t<R, 1, 3, 3, X3>(ctx, a, t, total, grid, resident, desc, desc_row);
     else {
         boa_set_error("conv_ws: kernel %dx%dx%d not instantiated", a.k0, a.k1, a.k2);
         return BOA_EINVAL;
@@ -754,6 +844,24 @@ const int* ws_run_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, i
     return (const int*)dev;
 }
 
+// Descriptor table of a launch (WS_DESC): a function of the layer geometry, the batch and the grid; built once per key on the
+// device by k_ws_build_desc and kept for the context's lifetime (8 samples of the 128^3 layers: 32 768 tiles = 1 MiB).
+static const int* ws_desc_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, int grid, int* row_out) {
+    std::vector<int> key = {-1,   a.t0, a.t1, a.t2, a.b0, a.b1, a.b2, a.w0, a.w1, a.w2, a.Cout, a.cy_fast, a.vw, a.ncy, a.N,  grid,
+                            a.Do, a.Ho, a.Wo, a.Di, a.Hi, a.Wi, a.s0, a.s1, a.s2, a.p0, a.p1,   a.p2,      a.h0, a.h1,  a.h2};
+    // rows: an upper bound of a workgroup's tiles (runs differ by at most one tile within an XCD range and by one more between ranges)
+    const int vper = (a.N * a.vw + grid - 1) / grid;
+    const int row = vper * (tiles_per_sample / a.vw + 2) + 1;
+    *row_out = row;
+    for (auto& e : ctx->ws_runs)
+        if (e.first == key) return (const int*)e.second;
+    void* dev = nullptr;
+    if (hipMalloc(&dev, (size_t)grid * row * 8 * sizeof(int)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(k_ws_build_desc, dim3((grid + 63) / 64), dim3(64), 0, ctx->stream, a, grid, row, (int*)dev);
+    ctx->ws_runs.emplace_back(std::move(key), dev);
+    return (const int*)dev;
+}
+
 int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes, bool x3) {
     const ConvArgs& a0 = a_in;
     // tiles of one sample; its virtual workgroups (batch-invariant statistics, see tile_walk); physical grid
@@ -779,6 +887,12 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     a.cy_fast = ((a.C0 + a.C1) == 32 && a.Cout == 64 && t.R == 1 && !getenv("BOA_WS_NO_CYFAST")) ? 1 : 0;
     a.runs = ws_run_table(ctx, a, total, vw);
     BOA_REQUIRE(a.runs != nullptr, "conv_ws: could not allocate the run table");
+    const int* desc = nullptr;
+    int desc_row = 0;
+#if WS_DESC
+    desc = ws_desc_table(ctx, a, total, grid, &desc_row);
+    BOA_REQUIRE(desc != nullptr, "conv_ws: could not allocate the tile descriptor table");
+#endif
     // a.partials must be all zero on entry: the callers zero it once (allocation / test seam) and k_norm_finalize
     // clears what it has read, so no per-launch memset is needed
     if (want_trace) {
@@ -792,12 +906,14 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     ctx->counters[x3 ? BOA_CNT_CONV_X3 : BOA_CNT_CONV_WS]++;
     int rc;
     switch (t.R + (x3 ? 8 : 0)) {
-        case 4: rc = launch_ws_r<4, false>(ctx, a, t, total, grid, resident); break;
-        case 2: rc = launch_ws_r<2, false>(ctx, a, t, total, grid, resident); break;
-        case 1: rc = launch_ws_r<1, false>(ctx, a, t, total, grid, resident); break;
-        case 12: rc = launch_ws_r<4, true>(ctx, a, t, total, grid, resident); break;
-        case 10: rc = launch_ws_r<2, true>(ctx, a, t, total, grid, resident); break;
-        case 9: rc = launch_ws_r<1, true>(ctx, a, t, total, grid, resident); break;
+        case 4: rc = launch_ws_r<4, false>(ctx, a, t, total, grid, resident, desc, desc_row); break;
+#ifndef WS_BISECT
+        case 2: rc = launch_ws_r<2, false>(ctx, a, t, total, grid, resident, desc, desc_row); break;
+        case 1: rc = launch_ws_r<1, false>(ctx, a, t, total, grid, resident, desc, desc_row); break;
+        case 12: rc = launch_ws_r<4, true>(ctx, a, t, total, grid, resident, desc, desc_row); break;
+        case 10: rc = launch_ws_r<2, true>(ctx, a, t, total, grid, resident, desc, desc_row); break;
+        case 9: rc = launch_ws_r<1, true>(ctx, a, t, total, grid, resident, desc, desc_row); break;
+#endif
         default:
             boa_set_error("conv_ws: unsupported R=%d", t.R);
             rc = BOA_EINVAL;

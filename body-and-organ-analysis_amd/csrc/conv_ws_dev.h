@@ -120,11 +120,12 @@ __device__ __forceinline__ void seq_run(const ConvArgs& p, TileSeq& s) {
     s.tc.oz0 = r[5];
 }
 
-__device__ __forceinline__ void seq_first(const ConvArgs& p, TileSeq& s) {
-    s.n = (int)blockIdx.x / p.vw;
-    s.j = (int)blockIdx.x - s.n * p.vw;
+__device__ __forceinline__ void seq_first_of(const ConvArgs& p, TileSeq& s, int blk) {
+    s.n = blk / p.vw;
+    s.j = blk - s.n * p.vw;
     seq_run(p, s);
 }
+__device__ __forceinline__ void seq_first(const ConvArgs& p, TileSeq& s) { seq_first_of(p, s, (int)blockIdx.x); }
 
 // next tile of this workgroup's sequence; true when it is the first tile of a new virtual workgroup
 __device__ __forceinline__ bool seq_next(const ConvArgs& p, TileSeq& s) {
@@ -140,6 +141,60 @@ __device__ __forceinline__ bool seq_next(const ConvArgs& p, TileSeq& s) {
     }
     seq_run(p, s);
     return true;
+}
+
+// ---- tile descriptors (WS_DESC) -------------------------------------------------------------------------
+// The walk above costs each role ~700 .. 1 100 cycles per tile of dependent scalar work (kernel-argument and run-table loads with
+// their waits, SGPR spills through v_readlane: round-5 trace of an interior workgroup), on the consumers' critical path in a tile's
+// first interval.  Its result is a pure function of (layer geometry, batch, grid), so it is run ONCE per such key by k_ws_build_desc
+// (the same seq_first / seq_next code, one thread per physical workgroup) into a table the roles read with one scalar load per tile:
+//   row b (desc_row entries of 8 ints): entry 0 = {tiles of workgroup b, ...}, entry 1 + k = descriptor of its k-th tile
+//   descriptor = {n, cy, ox0, oy0, oz0, flags, vo, ibase}
+//     flags  bit 0 first tile of a virtual workgroup (statistics slot changes), bit 1 output tile inside the tensor, bit 2 same
+//            spatial tile as the previous tile (halo reuse, cy_fast), bits 4-5 halo class (0 inside the tensor, 1 out by one
+//            voxel layer on the faces of bits 8-13, 2 general), bits 16.. virtual workgroup index j
+//     vo     (ox0 * Ho + oy0) * Wo + oz0;  ibase  (ix0 * Hi + iy0) * Wi + iz0 of the halo origin
+#define WS_DF_NEWRUN 1
+#define WS_DF_FULL 2
+#define WS_DF_REUSE 4
+
+struct TileDesc {
+    TileCoord tc;
+    int flags, vo, ibase;
+};
+
+__device__ __forceinline__ TileDesc make_desc(const ConvArgs& p, const TileSeq& s, bool new_run) {
+    TileDesc d;
+    d.tc = s.tc;
+    const TileCoord& tc = s.tc;
+    int fl = new_run ? WS_DF_NEWRUN : 0;
+    if (tc.ox0 + p.b0 * p.w0 <= p.Do && tc.oy0 + p.b1 * p.w1 <= p.Ho && tc.oz0 + p.b2 * p.w2 <= p.Wo) fl |= WS_DF_FULL;
+    if (p.cy_fast && tc.cy != 0 && !new_run) fl |= WS_DF_REUSE;
+    const int ix0 = tc.ox0 * p.s0 - p.p0, iy0 = tc.oy0 * p.s1 - p.p1, iz0 = tc.oz0 * p.s2 - p.p2;
+    if (ix0 >= 0 && iy0 >= 0 && iz0 >= 0 && ix0 + p.h0 <= p.Di && iy0 + p.h1 <= p.Hi && iz0 + p.h2 <= p.Wi) {
+    } else if (ix0 >= -1 && iy0 >= -1 && iz0 >= -1 && ix0 + p.h0 <= p.Di + 1 && iy0 + p.h1 <= p.Hi + 1 && iz0 + p.h2 <= p.Wi + 1) {
+        fl |= 1 << 4;
+        fl |= (ix0 < 0 ? 1 : 0) << 8 | (ix0 + p.h0 > p.Di ? 1 : 0) << 9 | (iy0 < 0 ? 1 : 0) << 10 | (iy0 + p.h1 > p.Hi ? 1 : 0) << 11 |
+              (iz0 < 0 ? 1 : 0) << 12 | (iz0 + p.h2 > p.Wi ? 1 : 0) << 13;
+    } else {
+        fl |= 2 << 4;
+    }
+    fl |= s.j << 16;
+    d.flags = fl;
+    d.vo = (tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0;
+    d.ibase = (ix0 * p.Hi + iy0) * p.Wi + iz0;
+    return d;
+}
+
+// one descriptor = two 16-byte scalar loads (desc is a __restrict__ const kernel argument and the address is wave-uniform)
+__device__ __forceinline__ TileDesc load_desc(const int* __restrict__ row, int k) {
+    const int4 a = *(const int4*)(row + (size_t)(k + 1) * 8), b = *(const int4*)(row + (size_t)(k + 1) * 8 + 4);
+    TileDesc d;
+#define WS_U(x) __builtin_amdgcn_readfirstlane(x)   // (no instruction when the load was scalar; keeps the "s" asm operands legal otherwise)
+    d.tc.n = WS_U(a.x); d.tc.cy = WS_U(a.y); d.tc.ox0 = WS_U(a.z); d.tc.oy0 = WS_U(a.w); d.tc.oz0 = WS_U(b.x); d.tc.sp = 0;
+    d.flags = WS_U(b.y); d.vo = WS_U(b.z); d.ibase = WS_U(b.w);
+#undef WS_U
+    return d;
 }
 
 // ---- producer ----------------------------------------------------------------------------------------
@@ -226,6 +281,27 @@ __device__ __forceinline__ void prod_setup(const ConvArgs& p, const TileCoord& t
     }
 }
 
+// the same with the tile's descriptor: the halo class and the faces that stick out were decided when the table was built
+__device__ __forceinline__ void prod_setup_desc(const ConvArgs& p, const TileDesc& d, const ProdConst& k, ProdItems& it) {
+    const int cls = (d.flags >> 4) & 3;
+    const int base = d.ibase;
+    if (cls == 0) {
+        it.ok = k.in_halo;
+#pragma unroll
+        for (int j = 0; j < WS_MAXV; ++j) it.gi[j] = base + k.rel[j];
+    } else if (cls == 1) {
+        unsigned out = 0;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) out |= (d.flags >> (8 + f)) & 1 ? k.face[f] : 0u;
+        const unsigned okm = k.in_halo & ~out;
+        it.ok = okm;
+#pragma unroll
+        for (int j = 0; j < WS_MAXV; ++j) it.gi[j] = ((okm >> j) & 1u) ? base + k.rel[j] : 0;
+    } else {
+        prod_setup(p, d.tc, k, it);
+    }
+}
+
 // Global-memory accesses in the scalar-base form `global_{load,store} v_off, ..., s[base:base+1]`: a wave-uniform pointer
 // pinned in an SGPR pair (the empty asm also keeps hipcc from folding the lane offset into one 64-bit VGPR address, which
 // selects the slow VGPR-pair form again) + a 32-bit lane offset.
@@ -233,7 +309,11 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define WS_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ WS_GLOBAL unsigned char* sgpr_ptr(const void* p) {
-    WS_GLOBAL unsigned char* g = (WS_GLOBAL unsigned char*)p;  // explicit global address space: the asm hides the provenance
+    // (readfirstlane: free when the value already lives in SGPRs; when hipcc has moved a wave-uniform chain to the VALU -- it does
+    //  with the descriptor fields -- the "+s" operand below is otherwise an "illegal VGPR to SGPR copy")
+    const size_t v = (size_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    WS_GLOBAL unsigned char* g = (WS_GLOBAL unsigned char*)(((size_t)hi << 32) | lo);  // explicit global address space: the asm hides the provenance
     asm volatile("" : "+s"(g));
     return g;
 }
