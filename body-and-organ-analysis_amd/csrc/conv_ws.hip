@@ -517,23 +517,57 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             float v[16];  // conv + bias: the accumulators were started at the bias
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = X3 ? acc[r][i] * p.winv : acc[r][i];
-            if (TWO_SETS && two && tc.cy != 0) {
+            // Statistics of this M-tile, BEFORE its registers are transposed in place.  Two things hipcc did to the plain loop
+            // (round-5 ISA): it turned the wave-uniform `full ? v : v * dm` into a multiply + two selects per pair (5 VALU per pair
+            // instead of 2), and it sank all four M-tiles' statistics behind the last store -- which kept the accumulators alive
+            // across the destructive v_permlane32_swap and cost 16 register copies per M-tile.  The two arms are real branches
+            // (markers), and the empty asm at the end pins the partial sums here.
+            // (pairs: the partial sums live in 64-bit register pairs for v_pk_add_f32 / v_pk_fma_f32; pinning the 32 floats one by one
+            //  made hipcc drop the packed forms)
+            auto stats = [&](StatSet& st) {
+                f2_t ps[8], pq[8], pv[8];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float vm = full ? v[i] : v[i] * dm;
-                    stB.s[i] += vm;
-                    stB.q[i] = __builtin_fmaf(vm, vm, stB.q[i]);
+                for (int j = 0; j < 8; ++j) {
+                    ps[j] = f2_t{st.s[2 * j], st.s[2 * j + 1]};
+                    pq[j] = f2_t{st.q[2 * j], st.q[2 * j + 1]};
+                    pv[j] = f2_t{v[2 * j], v[2 * j + 1]};
                 }
-            } else {
-                {
+                if (full) {
+                    asm volatile("; stats: tile inside the tensor");
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float vm = full ? v[i] : v[i] * dm;
-                        stA.s[i] += vm;
-                        stA.q[i] = __builtin_fmaf(vm, vm, stA.q[i]);
+                    for (int j = 0; j < 8; ++j) {
+                        ps[j] += pv[j];
+                        pq[j] = __builtin_elementwise_fma(pv[j], pv[j], pq[j]);
                     }
+                    // (pinned inside the arm: behind the join hipcc shares the additions of both arms, unpacked)
+                    asm volatile("" : "+v"(ps[0]), "+v"(ps[1]), "+v"(ps[2]), "+v"(ps[3]), "+v"(ps[4]), "+v"(ps[5]), "+v"(ps[6]), "+v"(ps[7]));
+                    asm volatile("" : "+v"(pq[0]), "+v"(pq[1]), "+v"(pq[2]), "+v"(pq[3]), "+v"(pq[4]), "+v"(pq[5]), "+v"(pq[6]), "+v"(pq[7]));
+                } else {
+                    asm volatile("; stats: tile sticks out");
+                    const f2_t dm2 = f2_t{dm, dm};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f2_t vm = pv[j] * dm2;
+                        ps[j] += vm;
+                        pq[j] = __builtin_elementwise_fma(vm, vm, pq[j]);
+                    }
+                    asm volatile("" : "+v"(ps[0]), "+v"(ps[1]), "+v"(ps[2]), "+v"(ps[3]), "+v"(ps[4]), "+v"(ps[5]), "+v"(ps[6]), "+v"(ps[7]));
+                    asm volatile("" : "+v"(pq[0]), "+v"(pq[1]), "+v"(pq[2]), "+v"(pq[3]), "+v"(pq[4]), "+v"(pq[5]), "+v"(pq[6]), "+v"(pq[7]));
                 }
-            }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    st.s[2 * j] = ps[j][0]; st.s[2 * j + 1] = ps[j][1];
+                    st.q[2 * j] = pq[j][0]; st.q[2 * j + 1] = pq[j][1];
+                }
+            };
+            if (TWO_SETS && two && tc.cy != 0)
+                stats(stB);
+            else
+                stats(stA);
+            // the accumulators are dead from here (the next tile's first MFMA / bias load overwrites them), which hipcc cannot see through
+            // the chunk loop's `cc == 0` test: an empty asm "defines" them, so that v IS the accumulator registers and the swaps
+            // below work in place (16 v_mov per M-tile otherwise)
+            asm volatile("" : "=v"(acc[r]));
             if constexpr (X3) {
                 // fp32 octet planes [N][Cout/8][voxel][8]: this lane's entries 4 gq .. 4 gq + 3 are couts 8 gq + 4 kh .. + 3 of its
                 // voxel = 16 contiguous bytes of plane cout0 / 8 + gq; the two k-halves of a voxel fill its 32-byte record
