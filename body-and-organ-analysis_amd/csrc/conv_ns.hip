@@ -93,7 +93,13 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
 // S: conv stride (all axes); WN: consumer waves along the cout axis (cout group = WN chunks), 4 / WN wave rows along x;
 // RM: M-tiles (x-planes of 4 x 8 output voxels) per wave.  Block tile = (4 / WN) * RM planes.
 template <int S, int WN, int RM, bool X3>
-__global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
+__global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg) {
+#ifdef WS_WITH_TRACE
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;   // (ablation switches: traced build only, see k_conv_ws)
+    (void)dbg_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
         // 2 chunk committed, 3 next loads issued
 #define NS_PSTAMP(code)                                                                                                          \
     do {                                                                                                                         \
-        if (p.trace && blockIdx.x == 0 && wave == 4 && lane == 0 && ptr_n < WS_TRACE_SLOTS / 2) {                                  \
+        if (WS_TRACING && blockIdx.x == 0 && wave == 4 && lane == 0 && ptr_n < WS_TRACE_SLOTS / 2) {                                  \
             p.trace[WS_TRACE_SLOTS / 2 + ptr_n] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
             ++ptr_n;                                                                                                             \
         }                                                                                                                        \
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
                     prod_setup(p, ptc, pc, items);
                     NS_PSTAMP(8);
                 }
-                if (p.trace) {
+                if (WS_TRACING) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     NS_PSTAMP(7);
                 }
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg) {
     // debug timeline (BOA_WS_TRACE): consumer wave 0 of block 0; codes 1 tile start, 2 before the first chunk, 3 chunk done, 4 barrier passed
 #define NS_STAMP(code)                                                                                                   \
     do {                                                                                                                 \
-        if (p.trace && blockIdx.x == 0 && wave == 0 && lane == 0 && tr_n < WS_TRACE_SLOTS) {                              \
+        if (WS_TRACING && blockIdx.x == 0 && wave == 0 && lane == 0 && tr_n < WS_TRACE_SLOTS) {                              \
             p.trace[tr_n] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
             ++tr_n;                                                                                                      \
         }                                                                                                                \
@@ -501,7 +507,11 @@ int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     BOA_REQUIRE((double)a.Di * a.Hi * a.Wi * std::max(a.C0, a.C1) * 2.0 < 4294967296.0,
                 "conv_ns: one sample of the input exceeds 4 GiB (32-bit voxel offsets)");
     BOA_REQUIRE(2 * t.h[0] * t.h[1] * t.h[2] <= WS_PROD * WS_MAXV, "conv_ns: halo too large");
+#ifdef WS_WITH_TRACE
     static const bool want_trace = getenv("BOA_WS_TRACE") != nullptr;
+#else
+    static const bool want_trace = false;   // (the stamps are compiled out of the production build: conv_ws_dev.h)
+#endif
     a.trace = nullptr;
     if (want_trace) {
         hipMalloc(&a.trace, WS_TRACE_SLOTS * 8);

@@ -202,12 +202,20 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
 // (consume_chunk), the epilogue un-scales the accumulators and stores fp32.  Measured against an fp32 FMA chain the product of
 // split operands is the more accurate of the two (tools/x3_probe.hip: rms error 3.2e-7 vs 5.3e-7 of the output rms at K = 864).
 template <int R, int K0, int K1, int K2, bool YR, bool X3>
-__global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_tiles, int resident_w, int dbg, const int* __restrict__ desc,
+__global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_tiles, int resident_w, int dbg_arg, const int* __restrict__ desc,
                                                         int desc_row) {
     // (round 5, measured and not kept: hipcc re-loads kernel arguments from the kernarg segment in the per-tile paths instead of keeping
     //  them -- chains of s_load_dwordx8/x16 + s_waitcnt in the tile walk and the epilogue addressing; passing every argument through an
     //  empty asm removed all of those loads from the loops (16 instead of 38 s_load, 480 instead of 314 v_readlane) and made every
     //  layer 2 ... 16 % SLOWER, 7 % over a forward: profiles/r05_conv_ws_experiments.txt)
+    // (the BOA_WS_DBG ablation switches exist in the traced build only: in the production build they are compile-time zero, which
+    //  removes their tests and their wave-uniform masks from the role loops)
+#ifdef WS_WITH_TRACE
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         // visibility to the consumers is ordered by the first chunk barrier below
     }
     int tr_n = 0;
-    const int tr_blk = p.trace ? (int)p.trace[WS_TRACE_SLOTS - 5] : -1;   // (debug) the traced block
+    const int tr_blk = WS_TRACING ? (int)p.trace[WS_TRACE_SLOTS - 5] : -1;   // (debug) the traced block
 
     if (producer) {
         // ---- producer waves: chunk g + 1 is committed to LDS while the consumers work on chunk g; its global loads
@@ -258,6 +266,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         // R = 1 kernels (stride-2 and thin deep layers) are producer-bound: the producers win issue arbitration there
         // (measured +8 % on the 32 -> 64 stride-2 layer); the stride-1 kernels give the consumers the higher priority
         if (R == 1 && !(dbg & 256)) __builtin_amdgcn_s_setprio(3);
+        if (R > 1 && (dbg & 2048)) __builtin_amdgcn_s_setprio(3);   // (experiment: producers first on the stride-1 kernels too)
         const ProdConst pc = prod_const(p, q, HV);
 #if WS_DESC
         TileDesc pd;
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 #endif
                     WS_STAMP(8);
                 }
-                if (p.trace) {
+                if (WS_TRACING) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     WS_STAMP(7);
                 }
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     }
 
     // ---- consumer waves --------------------------------------------------------------------------------
-    if (R > 1 && !(dbg & 1024)) __builtin_amdgcn_s_setprio(3);  // MFMA / fragment-read issue before the SIMD's producer wave (+1-6 %)
+    if (R > 1 && !(dbg & (1024 | 2048))) __builtin_amdgcn_s_setprio(3);  // MFMA / fragment-read issue before the SIMD's producer wave (+1-6 %)
     // per-lane constants (tile independent)
     const int cw = wave & 3;
     int hoff[R];
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     TileCoord& tc = cseq.tc;
 #endif
     tc.n = tc.cy = tc.ox0 = tc.oy0 = tc.oz0 = tc.sp = 0;
-    if (p.trace && blockIdx.x == 0 && tid == 0) {
+    if (WS_TRACING && blockIdx.x == 0 && tid == 0) {
         p.trace[WS_TRACE_SLOTS - 4] = __builtin_readcyclecounter();
         p.trace[WS_TRACE_SLOTS - 3] = __builtin_amdgcn_s_memrealtime();
     }
@@ -714,7 +723,8 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             }
             const unsigned char* ap = (resident_w ? smem + cc * taps * 1024 : cur + 2 * plane) + (X3 ? l31 : kh * 32 + l31) * 16;
             WS_STAMP(4);
-            if constexpr (X3) {
+            if (dbg & 4096) {   // (ablation: consumers without fragment reads and MFMAs -- the producers' stand-alone pace)
+            } else if constexpr (X3) {
                 if (cc == 0) {   // accumulators start at bias * wscale (LDS table, D-fragment order: entry 4 gq + e <-> cout 8 gq + 4 kh + e)
                     const float* sb = s_bias + tc.cy * 32 + 4 * kh;
 #pragma unroll
@@ -762,7 +772,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         done_vo = __builtin_amdgcn_readfirstlane(cd.vo);
 #endif
     }
-    if (p.trace && blockIdx.x == 0 && tid == 0) {
+    if (WS_TRACING && blockIdx.x == 0 && tid == 0) {
         p.trace[WS_TRACE_SLOTS - 2] = __builtin_readcyclecounter();
         p.trace[WS_TRACE_SLOTS - 1] = __builtin_amdgcn_s_memrealtime();
     }
@@ -909,7 +919,13 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
                 "conv_ws: more than 2^24 input voxels per sample (24-bit offset multiply)");
     BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi * std::max(a0.C0, a0.C1) * 2.0 < 4294967296.0,
                 "conv_ws: one sample of the input exceeds 4 GiB (32-bit voxel offsets)");
+#ifdef WS_WITH_TRACE
     static const bool want_trace = getenv("BOA_WS_TRACE") != nullptr;
+#else
+    static const bool want_trace = false;
+    static const bool trace_note = getenv("BOA_WS_TRACE") != nullptr && (fprintf(stderr, "[boa_hip] BOA_WS_TRACE needs a library built with -DWS_WITH_TRACE (tools/build_alt.sh trace -DWS_WITH_TRACE)\n"), true);
+    (void)trace_note;
+#endif
     ConvArgs a = a_in;
     a.trace = nullptr;
     // statistics slots: one per (workgroup, consumer wave); waves that never touch an (n, cout chunk) leave zeros

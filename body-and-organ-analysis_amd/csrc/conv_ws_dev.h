@@ -14,6 +14,13 @@
 #define WS_TRACE_SLOTS 4096
 // timeline stamps (debug only): slot = event counter of the calling wave; wave 0 (consumer) and wave 4 (producer) of block tr_blk
 // (BOA_WS_TRACE=<block>: block 0 only sees tiles on the tensor's y = z = 0 edge, i.e. the producers' slow bounds-checked path)
+// The production build compiles the stamps OUT (each site is ~6 instructions of a single-wave role loop that runs at ~12 cycles per
+// instruction: A/B -1.9 % per forward without them); `tools/build_alt.sh trace -DWS_WITH_TRACE` + BOA_HIP_LIB builds the traced copy.
+#ifndef WS_WITH_TRACE
+#define WS_STAMP(code) do { } while (0)
+#define WS_TRACING false
+#else
+#define WS_TRACING (p.trace != nullptr)
 #define WS_STAMP(code)                                                                          \
     do {                                                                                        \
         if (p.trace && (int)blockIdx.x == tr_blk && lane == 0 && ((wave & 3) == 0) && tr_n < WS_TRACE_SLOTS / 2) { \
@@ -21,6 +28,7 @@
             ++tr_n;                                                                             \
         }                                                                                       \
     } while (0)
+#endif
 
 // one k-octet plane of the halo: whole producer rounds of WS_PROD / 2 voxels (lanes past the halo store into the padding
 // instead of being masked: no per-item exec juggling), + 64 bytes of bank skew between the two planes
