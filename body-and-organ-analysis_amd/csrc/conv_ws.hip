@@ -31,6 +31,10 @@
 #define WS_DESC 1   // per-tile descriptors from a precomputed table (conv_ws_dev.h) instead of the in-kernel tile walk
 #endif
 
+#ifndef WS_EARLY_SETUP
+#define WS_EARLY_SETUP WS_DESC   // the producers set up the next tile right after a tile's last issue (the short interval), see below
+#endif
+
 #include "conv_ws_dev.h"
 
 // Builds the descriptor rows of a launch: thread b walks physical workgroup b's tile sequence with the kernels' own code.
@@ -307,7 +311,16 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 #endif
             prod_issue(p, ptc, items, pc.in_halo, 0, false, q, dbg, rg);
             w_cy = ptc.cy;
-            if (++pcc == ncc) pcc = 0;
+            if (++pcc == ncc) {
+                pcc = 0;
+#if WS_EARLY_SETUP
+                if (1 < my_chunks) {
+                    pd = load_desc(drow, ++pk);
+                    reuse = (pd.flags & WS_DF_REUSE) != 0;
+                    if (!reuse) prod_setup_desc(p, pd, pc, items);
+                }
+#endif
+            }
         }
         for (int g = -1; g < my_chunks; ++g) {
             if (live && g + 1 < my_chunks) {
@@ -319,7 +332,14 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 // producers' critical path, s_memtime trace) before the next loads could be issued.  (The commit only
                 // reads `rg`, the DMA the (chunk, cout chunk) saved at issue time.)
                 const bool do_issue = g + 2 < my_chunks;
+#if WS_EARLY_SETUP
+                // (WS_EARLY_SETUP: the set-up of the next tile happens right after the issue of a tile's LAST chunk instead -- round-5
+                //  trace: the interval of a tile's first chunk is the long one for both roles (epilogue + commit share the VALU), in
+                //  the interval of its last chunk the producers waited 500 .. 1 900 cycles at the barrier)
+                if (false) {
+#else
                 if (do_issue && pcc == 0) {
+#endif
 #if WS_DESC
                     pd = load_desc(drow, ++pk);
                     reuse = (pd.flags & WS_DF_REUSE) != 0;  // same spatial tile as the previous tile of this run
@@ -361,7 +381,17 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     prod_issue(p, ptc, items, pc.in_halo, pcc, reuse, q, dbg, rg);
                     w_cc = pcc;
                     w_cy = ptc.cy;
-                    if (++pcc == ncc) pcc = 0;
+                    if (++pcc == ncc) {
+                        pcc = 0;
+#if WS_EARLY_SETUP
+                        if (g + 3 < my_chunks) {   // the next issue starts another tile
+                            pd = load_desc(drow, ++pk);
+                            reuse = (pd.flags & WS_DF_REUSE) != 0;  // same spatial tile as the previous tile of this run
+                            if (!reuse) prod_setup_desc(p, pd, pc, items);
+                            WS_STAMP(8);
+                        }
+#endif
+                    }
                 }
                 WS_STAMP(3);
             }
