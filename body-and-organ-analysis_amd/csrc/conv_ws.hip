@@ -27,12 +27,9 @@
 
 #include "conv.h"
 
-#ifndef WS_DESC
-#define WS_DESC 1   // per-tile descriptors from a precomputed table (conv_ws_dev.h) instead of the in-kernel tile walk
-#endif
 
-#ifndef WS_EARLY_SETUP
-#define WS_EARLY_SETUP WS_DESC   // the producers set up the next tile right after a tile's last issue (the short interval), see below
+#ifndef WS_PF2
+#define WS_PF2 0   // (experiment, measured slower) two producer register sets: halo loads issued a whole chunk interval ahead
 #endif
 
 #include "conv_ws_dev.h"
@@ -238,13 +235,8 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     unsigned char* bufs = smem + wres_bytes;
 
     // this workgroup's tiles: the runs of the virtual workgroups b, b + G, ...
-#if WS_DESC
     const int* __restrict__ drow = desc + (size_t)blockIdx.x * desc_row * 8;
     const int my_tiles = drow[0];
-#else
-    int my_tiles = 0;
-    for (int v = (int)blockIdx.x; v < p.N * p.vw; v += (int)gridDim.x) my_tiles += p.runs[(v % p.vw) * 8];
-#endif
     const int my_chunks = my_tiles * ncc;
 
     // X3: the (scaled) bias in the D-fragment order lives in LDS behind the buffers and is read straight INTO the accumulators at
@@ -272,131 +264,109 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         if (R == 1 && !(dbg & 256)) __builtin_amdgcn_s_setprio(3);
         if (R > 1 && (dbg & 2048)) __builtin_amdgcn_s_setprio(3);   // (experiment: producers first on the stride-1 kernels too)
         const ProdConst pc = prod_const(p, q, HV);
-#if WS_DESC
-        TileDesc pd;
+        TileDesc pd;   // the tile whose chunks are being issued
         pd.flags = pd.vo = pd.ibase = 0;
         TileCoord& ptc = pd.tc;
-        int pk = 0;   // tile whose chunks are being issued
-#else
-        TileSeq pseq;
-        pseq.n = pseq.left = pseq.j = 0;
-        TileCoord& ptc = pseq.tc;
-#endif
+        int pk = 0;
         ptc.n = ptc.cy = ptc.ox0 = ptc.oy0 = ptc.oz0 = ptc.sp = 0;
         ProdItems items;
 #pragma unroll
         for (int j = 0; j < WS_MAXV; ++j) items.gi[j] = 0;
         items.ok = 0;
-        ChunkRegs rg;
+        // One register set: the loads of chunk g + 2 are issued behind the commit of chunk g + 1 and have the rest of the interval
+        // and the barrier to land.  WS_PF2 (round 5, measured and not adopted) issues them at the HEAD of the interval into a second
+        // set, a whole interval ahead (interval loop unrolled by two so that the sets alternate without copies): the 128^3 layers,
+        // whose halos are HBM-cold, did not move (+0.2 / -1.5 %), the streamed-weight layers lost 4 .. 9 % (their end-of-commit
+        // vmcnt(0) for the weight DMA then also waits for the twelve fresh halo loads): +3.1 % per forward.
+        ChunkRegs rgA, rgB;
+        auto clear_regs = [&](ChunkRegs& rg) {
 #pragma unroll
-        for (int j = 0; j < WS_MAXV; ++j) rg.d[j] = make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < WS_MAXV; ++j) rg.d[j] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rg.ssw[j] = 0;
-        rg.ok = rg.live = 0;
-        rg.has_ss = 0;
-        rg.skip_halo = 0;
+            for (int j = 0; j < 8; ++j) rg.ssw[j] = 0;
+            rg.ok = rg.live = 0;
+            rg.has_ss = 0;
+            rg.skip_halo = 0;
+            rg.cc = rg.cy = 0;
+        };
+        clear_regs(rgA);
+        clear_regs(rgB);
         // halo reuse across the cout chunks of one spatial tile (cy-fast order, 2 chunks = both stay resident)
         bool reuse = false;
         const bool want_w = !(resident_w || (dbg & 16));
         int pcc = 0;  // chunk within the tile of the next chunk to issue
-        int w_cc = 0, w_cy = 0;  // (chunk, cout chunk) of the chunk issued last = the one committed next (its weights go by DMA)
         const bool live = !(dbg & 2);
-        if (live && my_chunks > 0) {
-#if WS_DESC
-            pd = load_desc(drow, 0);
-            prod_setup_desc(p, pd, pc, items);
-#else
-            seq_first(p, pseq);
-            prod_setup(p, ptc, pc, items);
-#endif
-            prod_issue(p, ptc, items, pc.in_halo, 0, false, q, dbg, rg);
-            w_cy = ptc.cy;
+        // issue the next chunk into `rg`; behind a tile's LAST chunk the next tile is set up straight away (descriptor load + halo
+        // addresses: the interval of a tile's last chunk is the producers' short one -- setting up at the head of the long one, where
+        // the consumers' epilogue and the commit share the VALU, measured 2.3 % slower per forward)
+        auto issue_next = [&](ChunkRegs& rg, bool tile_after) {
+            prod_issue(p, ptc, items, pc.in_halo, pcc, reuse, q, dbg, rg);
+            rg.cc = pcc;   // (the weights of the chunk go by DMA when it is committed)
+            rg.cy = ptc.cy;
             if (++pcc == ncc) {
                 pcc = 0;
-#if WS_EARLY_SETUP
-                if (1 < my_chunks) {
-                    pd = load_desc(drow, ++pk);
-                    reuse = (pd.flags & WS_DF_REUSE) != 0;
-                    if (!reuse) prod_setup_desc(p, pd, pc, items);
-                }
-#endif
-            }
-        }
-        for (int g = -1; g < my_chunks; ++g) {
-            if (live && g + 1 < my_chunks) {
-                unsigned char* nxt = bufs + ((g + 1) & 1) * buf_bytes;
-                WS_STAMP(1);
-                // The next tile's address setup runs BEFORE the commit, while the loads of the chunk to commit are still in
-                // flight: its scalar loads (run table, kernel arguments) wait on lgkmcnt, the counter the commit's ds_writes
-                // share -- placed after the commit the setup waited for all of them to drain (~1 500 cycles per tile on the
-                // producers' critical path, s_memtime trace) before the next loads could be issued.  (The commit only
-                // reads `rg`, the DMA the (chunk, cout chunk) saved at issue time.)
-                const bool do_issue = g + 2 < my_chunks;
-#if WS_EARLY_SETUP
-                // (WS_EARLY_SETUP: the set-up of the next tile happens right after the issue of a tile's LAST chunk instead -- round-5
-                //  trace: the interval of a tile's first chunk is the long one for both roles (epilogue + commit share the VALU), in
-                //  the interval of its last chunk the producers waited 500 .. 1 900 cycles at the barrier)
-                if (false) {
-#else
-                if (do_issue && pcc == 0) {
-#endif
-#if WS_DESC
+                if (tile_after) {
                     pd = load_desc(drow, ++pk);
                     reuse = (pd.flags & WS_DF_REUSE) != 0;  // same spatial tile as the previous tile of this run
                     if (!reuse) prod_setup_desc(p, pd, pc, items);
-#else
-                    const bool new_run = seq_next(p, pseq);
-                    reuse = p.cy_fast && ptc.cy != 0 && !new_run;  // same spatial tile as the previous tile of this run
-                    if (!reuse) prod_setup(p, ptc, pc, items);
-#endif
                     WS_STAMP(8);
                 }
-                if (WS_TRACING) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    WS_STAMP(7);
-                }
-                {
-                    // The halo registers of the chunk to commit are made "used" HERE: hipcc does not see the LDS-DMA loads of the
-                    // inline asm below, so the s_waitcnt it places in front of the first use of rg.d is vmcnt(0) -- placed after the
-                    // DMA issue it also waited for the seven DMA round trips (L2 latency on the producers' critical path in every
-                    // chunk of every streamed-weight layer; found in the ISA in round 4).  The halo loads were issued an interval ago.
+            }
+        };
+        auto commit = [&](ChunkRegs& rg, unsigned char* dst) {
+            if (WS_TRACING) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WS_STAMP(7);
+            }
+            // The halo registers of the chunk to commit are made "used" HERE: hipcc does not see the LDS-DMA loads of the
+            // inline asm below, so the s_waitcnt it places in front of the first use of rg.d is vmcnt(0) -- placed after the
+            // DMA issue it also waited for the seven DMA round trips (L2 latency on the producers' critical path in every
+            // chunk of every streamed-weight layer; found in the ISA in round 4).
 #pragma unroll
-                    for (int j = 0; j < WS_MAXV; ++j) touch128(rg.d[j]);                        // as ONE 128-bit tuple (per component
-                                                                                               // hipcc splits the load destinations)
+            for (int j = 0; j < WS_MAXV; ++j) touch128(rg.d[j]);   // as ONE 128-bit tuple (per component hipcc splits the load destinations)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(rg.ssw[j]));
-                    // (unconditionally: at the join behind a conditional use hipcc would wait again)
-                    if (want_w) dma_weights(p, __builtin_amdgcn_readfirstlane(w_cc), __builtin_amdgcn_readfirstlane(w_cy), nxt + 2 * plane, q, taps);
-                }
-                if constexpr (X3)
-                    prod_commit_x3(p, rg, nxt, q, HV, plane, dbg);
-                else
-                    prod_commit(p, rg, nxt, q, HV, plane, dbg);
-                // the DMA was issued before the commit's ~2 000 cycles of work and nothing else of ours is in flight here.
-                // (Waiting at the end of the interval instead, with vmcnt(number of halo loads issued since), measured 6 %
-                // slower.)
-                if (want_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                WS_STAMP(2);
-                if (do_issue) {
-                    prod_issue(p, ptc, items, pc.in_halo, pcc, reuse, q, dbg, rg);
-                    w_cc = pcc;
-                    w_cy = ptc.cy;
-                    if (++pcc == ncc) {
-                        pcc = 0;
-#if WS_EARLY_SETUP
-                        if (g + 3 < my_chunks) {   // the next issue starts another tile
-                            pd = load_desc(drow, ++pk);
-                            reuse = (pd.flags & WS_DF_REUSE) != 0;  // same spatial tile as the previous tile of this run
-                            if (!reuse) prod_setup_desc(p, pd, pc, items);
-                            WS_STAMP(8);
-                        }
-#endif
-                    }
-                }
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(rg.ssw[j]));
+            // (unconditionally: at the join behind a conditional use hipcc would wait again)
+            if (want_w) dma_weights(p, __builtin_amdgcn_readfirstlane(rg.cc), __builtin_amdgcn_readfirstlane(rg.cy), dst + 2 * plane, q, taps);
+            if constexpr (X3)
+                prod_commit_x3(p, rg, dst, q, HV, plane, dbg);
+            else
+                prod_commit(p, rg, dst, q, HV, plane, dbg);
+            // the DMA was issued before the commit's ~2 000 cycles of work.  (Waiting at the end of the interval instead, with
+            // vmcnt(number of halo loads issued since), measured 6 % slower.)
+            if (want_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WS_STAMP(2);
+        };
+        if (live && my_chunks > 0) {
+            pd = load_desc(drow, 0);
+            prod_setup_desc(p, pd, pc, items);
+            issue_next(rgA, 1 < my_chunks);
+        }
+#if WS_PF2
+        auto interval = [&](int g, ChunkRegs& cur, ChunkRegs& nxt) {
+            if (live && g + 1 < my_chunks) {
+                WS_STAMP(1);
+                if (g + 2 < my_chunks) issue_next(nxt, g + 3 < my_chunks);
+                WS_STAMP(3);
+                commit(cur, bufs + ((g + 1) & 1) * buf_bytes);
+            }
+            __syncthreads();
+        };
+        for (int g = -1; g < my_chunks; g += 2) {
+            interval(g, rgA, rgB);
+            if (g + 1 < my_chunks) interval(g + 1, rgB, rgA);
+        }
+#else
+        for (int g = -1; g < my_chunks; ++g) {
+            if (live && g + 1 < my_chunks) {
+                WS_STAMP(1);
+                commit(rgA, bufs + ((g + 1) & 1) * buf_bytes);
+                if (g + 2 < my_chunks) issue_next(rgA, g + 3 < my_chunks);
                 WS_STAMP(3);
             }
             __syncthreads();
         }
+#endif
         return;
     }
 
@@ -491,16 +461,10 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         }
     };
 
-#if WS_DESC
     TileDesc cd;
     cd.flags = cd.vo = cd.ibase = 0;
     TileCoord& tc = cd.tc;
     int done_fl = 0, done_vo = 0;
-#else
-    TileSeq cseq;
-    cseq.n = cseq.left = cseq.j = 0;
-    TileCoord& tc = cseq.tc;
-#endif
     tc.n = tc.cy = tc.ox0 = tc.oy0 = tc.oz0 = tc.sp = 0;
     if (WS_TRACING && blockIdx.x == 0 && tid == 0) {
         p.trace[WS_TRACE_SLOTS - 4] = __builtin_readcyclecounter();
@@ -524,13 +488,8 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             st_cy = tc.cy;
         }
         const int cout0 = tc.cy * 32;
-#if WS_DESC
         const bool full = (dfl & WS_DF_FULL) != 0;
         const size_t ovox = (size_t)(unsigned)dvo;
-#else
-        const bool full = tc.ox0 + p.b0 * p.w0 <= p.Do && tc.oy0 + p.b1 * p.w1 <= p.Ho && tc.oz0 + p.b2 * p.w2 <= p.Wo;
-        const size_t ovox = ((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0;
-#endif
         // wave-uniform base + 32-bit lane offset (scalar-base global_store / global_load forms, see prod_issue)
         // chunk-planar output [N][Cout/16][voxel][16]: this lane writes the 16 couts of plane (cout0 / 16 + kh) of its voxel
         const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + ovox * 16;
@@ -691,36 +650,21 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 #ifdef WS_TRACE_EPILOGUE
         WS_STAMP(13);
 #endif
-#if WS_DESC
         if (more) {
             cd = load_desc(drow, k);
             new_run = (cd.flags & WS_DF_NEWRUN) != 0;
         }
-#else
-        if (k == 0)
-            seq_first(p, cseq);
-        else if (more)
-            new_run = seq_next(p, cseq);
-#endif
 #ifdef WS_TRACE_EPILOGUE
         WS_STAMP(14);
 #endif
 #if WS_DEFER_EPILOGUE
-#if WS_DESC
         if (k > 0 && !(dbg & 8)) epilogue(done_tc, done_fl, done_vo);  // the previous tile's (its statistics belong to the previous run: before the flush)
-#else
-        if (k > 0 && !(dbg & 8)) epilogue(done_tc, 0, 0);  // the previous tile's (its statistics belong to the previous run: before the flush)
-#endif
         if (!more) break;
 #endif
         if (new_run) {  // the partial sums of a virtual workgroup go to its own slot
             flush_stats();
             st_n = -1;
-#if WS_DESC
             slot = (int)((unsigned)cd.flags >> 16) * 4 + cw;
-#else
-            slot = cseq.j * 4 + cw;
-#endif
         }
         if (!X3 && tc.cy != bias_cy) {  // this lane's 16 biases of the cout chunk, D-fragment layout (entry 4 gq + e <-> cout 8 gq + 4 kh + e)
             bias_cy = tc.cy;
@@ -781,11 +725,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.h1, p.h2, acc, biasv);
             WS_STAMP(5);
 #if !WS_DEFER_EPILOGUE
-#if WS_DESC
             if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc, cd.flags, cd.vo);
-#else
-            if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc, 0, 0);
-#endif
 #endif
             WS_STAMP(6);
             __syncthreads();
@@ -797,10 +737,8 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         done_tc.ox0 = __builtin_amdgcn_readfirstlane(tc.ox0);
         done_tc.oy0 = __builtin_amdgcn_readfirstlane(tc.oy0);
         done_tc.oz0 = __builtin_amdgcn_readfirstlane(tc.oz0);
-#if WS_DESC
         done_fl = __builtin_amdgcn_readfirstlane(cd.flags);
         done_vo = __builtin_amdgcn_readfirstlane(cd.vo);
-#endif
     }
     if (WS_TRACING && blockIdx.x == 0 && tid == 0) {
         p.trace[WS_TRACE_SLOTS - 2] = __builtin_readcyclecounter();
@@ -969,10 +907,8 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     BOA_REQUIRE(a.runs != nullptr, "conv_ws: could not allocate the run table");
     const int* desc = nullptr;
     int desc_row = 0;
-#if WS_DESC
     desc = ws_desc_table(ctx, a, total, grid, &desc_row);
     BOA_REQUIRE(desc != nullptr, "conv_ws: could not allocate the tile descriptor table");
-#endif
     // a.partials must be all zero on entry: the callers zero it once (allocation / test seam) and k_norm_finalize
     // clears what it has read, so no per-launch memset is needed
     if (want_trace) {

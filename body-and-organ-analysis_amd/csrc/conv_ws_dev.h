@@ -389,6 +389,7 @@ struct ChunkRegs {
     unsigned live;        // bit j: voxel j belongs to the halo (v < HV)
     int has_ss;
     int skip_halo;        // the LDS buffer already holds this chunk's halo (previous tile = same spatial tile, other couts)
+    int cc, cy;           // k_conv_ws: (chunk, cout chunk) the set was issued for -- the weights follow by DMA at commit time
 };
 
 __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& tc, const ProdItems& it, unsigned live, int cc,
