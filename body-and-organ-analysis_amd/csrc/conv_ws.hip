@@ -562,10 +562,6 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 stats(stB);
             else
                 stats(stA);
-            // the accumulators are dead from here (the next tile's first MFMA / bias load overwrites them), which hipcc cannot see through
-            // the chunk loop's `cc == 0` test: an empty asm "defines" them, so that v IS the accumulator registers and the swaps
-            // below work in place (16 v_mov per M-tile otherwise)
-            asm volatile("" : "=v"(acc[r]));
             if constexpr (X3) {
                 // fp32 octet planes [N][Cout/8][voxel][8]: this lane's entries 4 gq .. 4 gq + 3 are couts 8 gq + 4 kh .. + 3 of its
                 // voxel = 16 contiguous bytes of plane cout0 / 8 + gq; the two k-halves of a voxel fill its 32-byte record
@@ -659,6 +655,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 #endif
 #if WS_DEFER_EPILOGUE
         if (k > 0 && !(dbg & 8)) epilogue(done_tc, done_fl, done_vo);  // the previous tile's (its statistics belong to the previous run: before the flush)
+        // The accumulators are dead from here (the tile's first MFMA / bias load overwrites them), which hipcc cannot see through the
+        // chunk loop's `cc == 0` test: an empty asm "defines" them -- on EVERY path, so that no path has to carry the old values
+        // (inside the conditional epilogue it made hipcc copy all 64 accumulator registers to a second bank and back once per tile)
+        // and the epilogue's v_permlane32_swap transposes them in place (16 v_mov per M-tile otherwise).
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" : "=v"(acc[r]));
         if (!more) break;
 #endif
         if (new_run) {  // the partial sums of a virtual workgroup go to its own slot
