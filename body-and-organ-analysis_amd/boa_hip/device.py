@@ -135,6 +135,41 @@ class DeviceBuffer:
         return C.c_void_p(self.ptr)
 
 
+class FlagRing:
+    """Deferred "inf in the predicted array" flags (predict_from_raw_data.py:623-625 raises after every sliding window): each predict
+    call of a multi-model task takes its own zeroed int32 slot and the host reads the slots ONCE, when the volume's last model has
+    been queued -- a read per model was a stream drain per model (host gaps between the stages)."""
+    SLOTS = 64
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.buf = ctx.alloc(4 * self.SLOTS)
+        self.buf.zero()
+        self.n = 0
+
+    def next(self):
+        if self.n == self.SLOTS:
+            self.check()
+        v = BufferView(self.buf, 4 * self.n, 4)
+        self.n += 1
+        return v
+
+    def check(self):
+        """Raises if any slot handed out since the last check was set; the slots are zero again afterwards."""
+        if self.n == 0:
+            return
+        used, self.n = self.n, 0
+        flags = self.buf.download((self.SLOTS,), np.int32)
+        if flags[:used].any():
+            self.buf.zero()
+            raise RuntimeError("Encountered inf in predicted array. Aborting...")
+
+    def free(self):
+        if self.buf is not None:
+            self.buf.free()
+            self.buf = None
+
+
 class BufferView:
     """Non-owning window [byte_offset, byte_offset + nbytes) of a DeviceBuffer (z-slabs of a (z, y, x) volume are
     contiguous ranges of its buffer)."""

@@ -245,8 +245,12 @@ class HipPredictor:
                 work[name] = b
             return b
 
-        flag = buf("flag", 4)
-        flag.zero()
+        ring = work.get("flag_ring")   # (device.FlagRing of the calling task: the inf flag is read once per volume, not per model)
+        if ring is not None:
+            flag = ring.next()
+        else:
+            flag = buf("flag", 4)
+            flag.zero()
         lut_arr = None
         if lut is not None:
             lut_arr = np.zeros(256, dtype=np.uint8)
@@ -255,7 +259,7 @@ class HipPredictor:
         crop = any(b != 0 for b in below) or list(PV) != list(V)
         direct = resample_to is None
         if direct and self.use_gather_head and self._predict_labels_fused(dvol, V, PV, below, origins, labels_out, lut_p, merge, crop, flag, buf):
-            if int(flag.download((1,), np.int32)[0]):
+            if ring is None and int(flag.download((1,), np.int32)[0]):
                 raise RuntimeError("Encountered inf in predicted array. Aborting...")
             if own:
                 for b in work.values():
@@ -274,7 +278,7 @@ class HipPredictor:
                 nf if (last and fold) else 0, 0 if (direct or fold) else 1, lut_p,
                 1 if merge else 0, labels_out.vp if (last and direct) else None, int3(below) if crop else None,
                 int3(V) if crop else None, flag.vp), "boa_finalize_labels")
-        if int(flag.download((1,), np.int32)[0]):
+        if ring is None and int(flag.download((1,), np.int32)[0]):
             raise RuntimeError("Encountered inf in predicted array. Aborting...")
         if not direct:
             out_dims, slice_axis = resample_to

@@ -135,8 +135,13 @@ class SegmentationTask:
             return self._predict_zyx_model_sharded(d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx)
         if self.shard is not None and self.shard.comm.world > 1 and self.multimodel and len(self.parts) > 1 and self._units_applicable(shape, spacing_zyx):
             return self._predict_zyx_unit_sharded(d_ct, shape, d_labels, in_dtype, n)
+        ring = self._work.get("flag_ring")
+        if ring is None:
+            from .device import FlagRing
+            ring = self._work["flag_ring"] = FlagRing(ctx)
         for k in range(len(self.parts)):
             self._run_model(k, d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx, merge=self.multimodel, shard=self.shard)
+        ring.check()   # the models' inf flags, one read per volume
 
     # ---- (row x model) units: all ranks busy on one multi-model volume ---------------------------------------------------------
     def _units_applicable(self, shape, spacing_zyx) -> bool:
