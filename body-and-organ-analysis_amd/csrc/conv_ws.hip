@@ -476,19 +476,25 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     // issue the HBM-cold loads of the tile after next), the interval of a tile's last chunk their short one, so the roles'
     // long and short intervals now coincide instead of alternating in opposite phase.
     f32x16 acc[R];
-    auto epilogue = [&](const TileCoord& tc, int dfl, int dvo) {
-        (void)dfl;
-        (void)dvo;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;   // (the first iteration's no-op epilogue reads them)
+    // `valid` = there is a previous tile (false in the workgroup's first iteration only): the epilogue runs UNCONDITIONALLY -- as a
+    // conditional block its results (partial sums in fresh registers) met the untouched ones at a join and hipcc copied 32 .. 48 register
+    // pairs per tile -- and is a numerical no-op then: the accumulators start at zero, the tile counts as sticking out with every voxel
+    // masked (no stores, + 0 to the partial sums), the flush logic is skipped.
+    auto epilogue = [&](const TileCoord& tc, int dfl, int dvo, bool valid) {
         // ---- epilogue: + bias, InstanceNorm partial sums (fp32), register transpose (v_permlane32_swap), fp16
         // convert, two 16-byte stores per lane (32 contiguous bytes of the voxel's record)
         const bool two = TWO_SETS && p.cy_fast;
-        if (tc.n != st_n || (!two && tc.cy != st_cy)) {
+        if (valid && (tc.n != st_n || (!two && tc.cy != st_cy))) {
             flush_stats();
             st_n = tc.n;
             st_cy = tc.cy;
         }
         const int cout0 = tc.cy * 32;
-        const bool full = (dfl & WS_DF_FULL) != 0;
+        const bool full = valid && (dfl & WS_DF_FULL) != 0;
         const size_t ovox = (size_t)(unsigned)dvo;
         // wave-uniform base + 32-bit lane offset (scalar-base global_store / global_load forms, see prod_issue)
         // chunk-planar output [N][Cout/16][voxel][16]: this lane writes the 16 couts of plane (cout0 / 16 + kh) of its voxel
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             if (!full) {  // wave-uniform: only tiles that stick out of the tensor mask statistics and stores
                 int x, y, z;
                 vox_rel(l31, x, y, z);
-                ok = tc.ox0 + mx + x < p.Do && tc.oy0 + my + y < p.Ho && tc.oz0 + mz + z < p.Wo;
+                ok = valid && tc.ox0 + mx + x < p.Do && tc.oy0 + my + y < p.Ho && tc.oz0 + mz + z < p.Wo;
             }
             const float dm = ok ? 1.f : 0.f;
             float v[16];  // conv + bias: the accumulators were started at the bias
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         WS_STAMP(14);
 #endif
 #if WS_DEFER_EPILOGUE
-        if (k > 0 && !(dbg & 8)) epilogue(done_tc, done_fl, done_vo);  // the previous tile's (its statistics belong to the previous run: before the flush)
+        if (!(dbg & 8)) epilogue(done_tc, done_fl, done_vo, k > 0);  // the previous tile's (its statistics belong to the previous run: before the flush)
         // The accumulators are dead from here (the tile's first MFMA / bias load overwrites them), which hipcc cannot see through the
         // chunk loop's `cc == 0` test: an empty asm "defines" them -- on EVERY path, so that no path has to carry the old values
         // (inside the conditional epilogue it made hipcc copy all 64 accumulator registers to a second bank and back once per tile)
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.h1, p.h2, acc, biasv);
             WS_STAMP(5);
 #if !WS_DEFER_EPILOGUE
-            if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc, cd.flags, cd.vo);
+            if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc, cd.flags, cd.vo, true);
 #endif
             WS_STAMP(6);
             __syncthreads();
