@@ -12,17 +12,22 @@
 // Workgroups are persistent and walk a contiguous run of output tiles (x fastest; cout chunk fastest for the
 // 2-chunk / 2-cout-chunk case, where the staged halo is reused), so the staging of a tile's first chunk hides under
 // the previous tile's last chunk and the chip-wide working set is a contiguous run of tiles (halo reuse in L2).
-// Per-tile bookkeeping is division free (relative offsets precomputed per kernel, incremental tile walk, wave-uniform
-// fast path for tiles whose halo / output lies inside the tensor).
+// Per-tile bookkeeping is ONE scalar load per role: the tile sequence of every workgroup (conv_ws_dev.h: virtual workgroups, run
+// tables) is walked once per (layer geometry, batch, grid) by k_ws_build_desc below into a table of 32-byte descriptors (tile
+// coordinates, statistics slot, halo class and faces, output offset).  A role is a single wave per SIMD: it issues an instruction
+// every ~4.7 cycles and pays ~25 cycles per SGPR-spill reload and ~22 per taken branch (tools/issue_rate.hip), so what the role
+// loops carry per tile -- not the MFMA pipe -- sets the tile time (profiles/r05_conv_ws_experiments.txt).
 //
 // Same arithmetic as k_conv_mfma (conv.hip).  Statistics: partials[n][cout][2][nslots], one slot per (workgroup,
 // consumer wave), written once per (sample, cout chunk) a wave works on; the table is zero elsewhere (zeroed at
 // allocation, re-zeroed by k_norm_finalize).
-// Debug: `dbg` bits (BOA_WS_DBG) skip stages for ablation -- 2 producers, 4 output stores, 8 epilogue,
-// 16 weight staging, 32 halo commit, 64 transform, 128 halo loads, 256 / 1024 default wave priorities off; results are then
-// wrong by design (except 256 / 1024).
-// BOA_WS_TRACE=1 records s_memtime stamps of block 0 (consumer wave 0: 4 chunk start, 5 MFMA loop done, 6 epilogue done;
-// producer wave 4: 1 barrier passed, 7 loads landed, 2 committed, 8 tile set up, 3 next loads issued).
+// Debug (TRACED build only, -DWS_WITH_TRACE: tools/build_alt.sh trace -DWS_WITH_TRACE; the production build compiles both out of the
+// role loops): `dbg` bits (BOA_WS_DBG) skip stages for ablation -- 2 producers, 4 output stores, 8 epilogue, 16 weight staging,
+// 32 halo commit, 64 transform, 128 halo loads, 256 / 1024 default wave priorities off, 2048 producers first, 4096 consumers without
+// fragment reads and MFMAs; results are then wrong by design (except the priority bits).
+// BOA_WS_TRACE=<block> records s_memtime stamps of that workgroup (consumer wave 0: 4 chunk start, 5 MFMA loop done, 6 before the
+// barrier, with -DWS_TRACE_EPILOGUE 13 / 14 loop top, 9 - 12 epilogue; producer wave 4: 1 barrier passed, 7 loads landed, 2 committed,
+// 8 tile set up, 3 next loads issued).
 #include <stdlib.h>
 
 #include "conv.h"
