@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_ws_build_desc(ConvArgs p, int grid, int 
     int* r = out + (size_t)b * row * 8;
     int my = 0;
     for (int v = b; v < p.N * p.vw; v += grid) my += p.runs[(v % p.vw) * 8];
-    if (my > row - 1) my = row - 1;   // (cannot happen: the host sizes the rows with an upper bound; checked there)
+    if (my > row - 1) __builtin_trap();   // (cannot happen: ws_desc_table sizes the rows with a proven upper bound; fail loudly, never truncate)
     r[0] = my;
     for (int i = 1; i < 8; ++i) r[i] = 0;
     TileSeq s;
@@ -874,7 +874,10 @@ const int* ws_run_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, i
 static const int* ws_desc_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, int grid, int* row_out) {
     std::vector<int> key = {-1,   a.t0, a.t1, a.t2, a.b0, a.b1, a.b2, a.w0, a.w1, a.w2, a.Cout, a.cy_fast, a.vw, a.ncy, a.N,  grid,
                             a.Do, a.Ho, a.Wo, a.Di, a.Hi, a.Wi, a.s0, a.s1, a.s2, a.p0, a.p1,   a.p2,      a.h0, a.h1,  a.h2};
-    // rows: an upper bound of a workgroup's tiles (runs differ by at most one tile within an XCD range and by one more between ranges)
+    // rows: an upper bound of a workgroup's tiles.  A run has at most tiles_per_sample / vw + 2 tiles (ws_run_table: the 8 XCD ranges
+    // differ by one tile, the runs inside a range by one more) and a workgroup executes ceil(N vw / grid) runs.  The tables live as long
+    // as the context (one per layer geometry, batch and grid: the tail batches of a volume add a few; <= ~150 MB for every batch size
+    // 1 .. 25 of one net geometry).
     const int vper = (a.N * a.vw + grid - 1) / grid;
     const int row = vper * (tiles_per_sample / a.vw + 2) + 1;
     *row_out = row;
