@@ -154,6 +154,12 @@ class FlagRing:
         self.n += 1
         return v
 
+    def reset(self):
+        """Drop what an aborted volume left behind."""
+        if self.n:
+            self.buf.zero()
+            self.n = 0
+
     def check(self):
         """Raises if any slot handed out since the last check was set; the slots are zero again afterwards."""
         if self.n == 0:

@@ -139,6 +139,7 @@ class SegmentationTask:
         if ring is None:
             from .device import FlagRing
             ring = self._work["flag_ring"] = FlagRing(ctx)
+        ring.reset()
         for k in range(len(self.parts)):
             self._run_model(k, d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx, merge=self.multimodel, shard=self.shard)
         ring.check()   # the models' inf flags, one read per volume

@@ -164,6 +164,38 @@ def test_total_pipeline_same_labels_both_forms(ctx):
         assert agree >= 0.999
 
 
+def test_task_reads_the_inf_flags_once_per_volume_and_still_raises(ctx):
+    """Inside a multi-model task the predictors' inf flags go to a device.FlagRing that the task reads once per volume (one stream
+    drain instead of one per model): an overflow in the THIRD of five part models must still raise the reference's RuntimeError
+    (predict_from_raw_data.py:622-625) before any label leaves the task, and a clean volume afterwards must run (slots re-zeroed)."""
+    from boa_hip import label_maps, plans, totalseg
+    rng = np.random.default_rng(5)
+    ct = rng.normal(0, 300, size=(44, 40, 52)).astype(np.int16)
+    ct[ct == 0] = 1
+
+    def models(bad):
+        out = []
+        for i, (tid, nc) in enumerate(zip(label_maps.PART_TASK_IDS, (25, 27, 19, 24, 27))):
+            pj, dj = plans.synthetic_plans(patch=(32, 32, 32), features=(32, 64), num_classes=nc)
+            cfg = plans.model_config_from_plans(pj, dj)
+            sd = plans.synthetic_state_dict(cfg.geometry, seed=tid)
+            if bad and i == 2:
+                key = [k for k in sd if "seg_layers" in k and k.endswith("weight")][-1]
+                sd[key] = sd[key] * 2e4
+            out.append((tid, cfg, [plans.weight_blob_from_state_dict(cfg.geometry, sd)]))
+        return out
+
+    ts = totalseg.TotalSegmentatorHip(ctx, models(True), step_size=0.8, max_batch=4)
+    with pytest.raises(RuntimeError, match="inf"):
+        ts.predict(ct)
+    ts.close()
+    ts = totalseg.TotalSegmentatorHip(ctx, models(False), step_size=0.8, max_batch=4)
+    lab = ts.predict(ct)
+    assert lab.shape == ct.shape and lab.any()
+    lab2 = ts.predict(ct)          # second volume through the same task: the ring's slots are reused
+    np.testing.assert_array_equal(lab, lab2)
+    ts.close()
+
 
 @pytest.mark.parametrize("precision", ["fp16", "fp32"])
 @pytest.mark.parametrize("nc", [2, 4, 5, 13])
