@@ -505,6 +505,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
         // chunk-planar output [N][Cout/16][voxel][16]: this lane writes the 16 couts of plane (cout0 / 16 + kh) of its voxel
         const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + ovox * 16;
         const unsigned olane = ((unsigned)kh * (unsigned)out_vox + (unsigned)srel0) * 32u;
+        const unsigned char* const tile_dst = (const unsigned char*)(p.out + obase);   // (the 64-bit part once per tile; an M-tile adds 32 bits)
 #ifdef WS_TRACE_EPILOGUE
         WS_STAMP(9);
 #endif
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                 w[pr * 4 + 3] = cvt_pk_h2(hi4[2], hi4[3]);
             }
             if (ok && !(dbg & 4)) {
-                WS_GLOBAL unsigned char* dst = sgpr_ptr(p.out + (obase + (size_t)mrel * 16));
+                WS_GLOBAL unsigned char* dst = sgpr_ptr(tile_dst + (unsigned)mrel * 32u);
                 unsigned ol = olane;
                 asm volatile("" : "+v"(ol));  // keep the 32 -> 64 bit extension in this block (instruction selection is per block)
 #ifndef WS_TEMPORAL_STORES
