@@ -258,13 +258,17 @@ extern "C" int boa_tissue_projections(boa_ctx* c, const uint8_t* dev_tissues, co
 // global one when it fills up and at the end: one global atomic per DISTINCT key of ~10^5 voxels instead of one per
 // voxel.  A wave whose 1 024 voxels all carry the same key (air around the patient) issues one LDS atomic, or none when
 // the key is "not measured".
-#define HIST_TAB 16384          // entries: 64 KiB keys + 64 KiB counts
-#define HIST_FLUSH 11000        // distinct keys in the table that trigger a flush (load factor 2/3)
+// Table size: 2^LOG2 entries of {key, count}.  LOG2 = 14 (128 KiB) leaves ONE workgroup (4 waves) per CU -- the voxel loads of an
+// iteration are then a chain of exposed HBM round trips; LOG2 = 12 (32 KiB) lets four workgroups share a CU and still holds the
+// distinct (label, HU) keys of a contiguous voxel range of compact organs between flushes.
 #define HIST_EMPTY 0xFFFFFFFFu
 
+template <int LOG2>
 __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
                                                     const unsigned char* __restrict__ mask, size_t n_all, size_t head, int hu_min,
                                                     int nbins, unsigned int* __restrict__ hist, size_t groups_per_block) {
+    constexpr int HIST_TAB = 1 << LOG2;
+    constexpr int HIST_FLUSH = HIST_TAB * 2 / 3;     // distinct keys in the table that trigger a flush (load factor 2/3)
     extern __shared__ __attribute__((aligned(16))) unsigned char hist_smem[];
     unsigned int* keys = (unsigned int*)hist_smem;   // [HIST_TAB]
     unsigned int* cnts = keys + HIST_TAB;            // [HIST_TAB]
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
         return b < 0 ? 0 : (b >= nbins ? nbins - 1 : b);
     };
     auto count = [&](unsigned key, unsigned c) {  // key = label << 16 | bin  (nbins <= 65536)
-        unsigned h = (key * 2654435761u) >> 18;   // 14 bits
+        unsigned h = (key * 2654435761u) >> (32 - LOG2);
 #pragma unroll 1
         for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (HIST_TAB - 1)) {
             unsigned k = keys[h];
@@ -415,15 +419,21 @@ extern "C" int boa_label_hu_histogram(boa_ctx* c, const int16_t* dev_ct, const u
     if (head > n) head = n;
     const bool together = (((uintptr_t)dev_ct + 2 * head) & 15) == 0 && (!dev_mask || (((uintptr_t)dev_mask + head) & 15) == 0);
     // contiguous voxel ranges per workgroup (few labels each): ~4 workgroups per CU, at least one 4 096-voxel iteration
+    static const int hist_log2 = getenv("BOA_HIST_LOG2") ? atoi(getenv("BOA_HIST_LOG2")) : 12;
+    static const int hist_wg = getenv("BOA_HIST_WG") ? atoi(getenv("BOA_HIST_WG")) : (hist_log2 == 14 ? 4 : 16);   // workgroups per CU
     const size_t iters = ((n - head) / 16 + 255) / 256;
-    const size_t gpb = std::max<size_t>(1, (iters + (size_t)c->cu_count * 4 - 1) / ((size_t)c->cu_count * 4));
+    const size_t gpb = std::max<size_t>(1, (iters + (size_t)c->cu_count * hist_wg - 1) / ((size_t)c->cu_count * hist_wg));
     const int grid = (int)std::max<size_t>(1, (iters + gpb - 1) / gpb);
     KernelTimer t(c, BOA_K_AGG, 0, (double)n * (3.0 + (dev_mask ? 1 : 0)));
     if (together) {
-        static bool once = (hipFuncSetAttribute((const void*)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024), true);
+        static bool once = (hipFuncSetAttribute((const void*)k_label_hist<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024), true);
         (void)once;
-        hipLaunchKernelGGL(k_label_hist, dim3(grid), dim3(256), (size_t)HIST_TAB * 8, c->stream, dev_ct, dev_labels, dev_mask, n,
-                           head, hu_min, nbins, dev_hist, gpb);
+        if (hist_log2 == 14)
+            hipLaunchKernelGGL(k_label_hist<14>, dim3(grid), dim3(256), (size_t)8 << 14, c->stream, dev_ct, dev_labels, dev_mask, n,
+                               head, hu_min, nbins, dev_hist, gpb);
+        else
+            hipLaunchKernelGGL(k_label_hist<12>, dim3(grid), dim3(256), (size_t)8 << 12, c->stream, dev_ct, dev_labels, dev_mask, n,
+                               head, hu_min, nbins, dev_hist, gpb);
     } else {
         hipLaunchKernelGGL(k_label_hist_scalar, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 32)), dim3(256), 0,
                            c->stream, dev_ct, dev_labels, dev_mask, n, hu_min, nbins, dev_hist);

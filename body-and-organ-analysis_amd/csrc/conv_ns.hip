@@ -22,6 +22,92 @@
 
 #include "conv_ws_dev.h"
 
+// ---- LDS halo layout of the stride-2 instantiations ("SW") ------------------------------------------------
+// A consumer lane's voxel of M-tile plane x is (y, z) = (2 ly + dy, 2 lz + dz): in the linear [x][y][z] halo the 32 lanes of a k-half
+// sit 32 bytes apart along z and 2 * 17 * 16 = 544 bytes apart along y, i.e. on EVEN 16-byte slots only and on the same slots (mod 256
+// bytes) in three of the four ly rows -- ds_read_b128 is serviced in four fixed 16-lane groups ({0-3, 12-15, 20-27}, ...: hardware
+// guide, LDS table), and every group met 3-way bank conflicts: the fragment reads of the stride-2 layers cost three LDS cycles where
+// one would do, on an LDS that the 0.75 - 0.83 KiB of reads per MFMA already fills (round-5 trace: 2 800 cycles per chunk of 54 MFMAs).
+// The stride-2 halo is therefore stored DE-INTERLEAVED by the parity of y and z:
+//   slot(x, y, z) = (x * 9 + yp(y)) * 24 + zp(z),   yp(y) = (y & 1) * 5 + (y >> 1),   zp(z) = (z & 1) * 10 + (z >> 1)
+// (9 x 9 x 17 halo: 5 even + 4 odd rows, 9 even + 8 odd columns).  A tap's 32 voxels are then (ly, lz) -> const + ly * 24 + lz:
+// 8 contiguous slots per row, rows 24 slots = 384 bytes apart (= 128 mod 256), so each of the four lane groups covers the 16 slots
+// of a 256-byte bank row exactly once; the tap offsets stay compile-time immediates.  The producers' stores (8-lane groups = 4
+// consecutive voxels x 2 k-half planes, 128-byte bank rows) stay conflict-free with the odd columns at slot 10 (= 2 mod 8) and the
+// planes' 64-byte skew.  Lanes past the halo store into one dummy slot behind the plane.
+#define NS_SW_ROW 24
+#define NS_SW_YODD 5
+#define NS_SW_ZODD 10
+__host__ __device__ constexpr int ns_sw_yp(int y) { return (y & 1) * NS_SW_YODD + (y >> 1); }
+__host__ __device__ constexpr int ns_sw_zp(int z) { return (z & 1) * NS_SW_ZODD + (z >> 1); }
+__host__ __device__ constexpr int ns_sw_slots() { return 9 * 9 * NS_SW_ROW; }            // slots of one k-half plane (+ 8 of padding: the dummy slot)
+__host__ __device__ constexpr int ns_sw_plane_bytes() { return (ns_sw_slots() + 8) * 16 + 64; }   // = 64 mod 128: the k-half planes' stores interleave
+
+#ifndef NS_PF2
+#define NS_PF2 1   // two producer register sets: halo loads a whole chunk interval ahead (see the producer loop); 0 = never
+#endif
+
+// prod_commit / prod_commit_x3 (conv_ws_dev.h) with a per-item LDS offset instead of the linear voxel index
+template <bool X3, bool SS, bool EDGE>
+__device__ __forceinline__ void ns_commit_items_sw(const ConvArgs& p, const ChunkRegs& rg, unsigned char* d0, const int (&off)[WS_MAXV], int plane,
+                                                   int nv, unsigned slope2) {
+    if (EDGE)
+        asm volatile("; commit sw: edge tile");
+    else
+        asm volatile("; commit sw: interior tile");
+#pragma unroll
+    for (int j = 0; j < WS_MAXV; ++j) {
+        if (j < nv) {
+            if constexpr (X3) {
+                float y[4] = {__uint_as_float(rg.d[j].x), __uint_as_float(rg.d[j].y), __uint_as_float(rg.d[j].z), __uint_as_float(rg.d[j].w)};
+                if (SS) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float f = __builtin_fmaf(y[i], __uint_as_float(rg.ssw[2 * i]), __uint_as_float(rg.ssw[2 * i + 1]));
+                        y[i] = f > 0.f ? f : f * p.slope;
+                    }
+                }
+                uint2 hi, lo;
+                x3_split4(y, hi, lo);
+                if (EDGE && !((rg.ok >> j) & 1u)) hi = lo = make_uint2(0, 0);
+                *(uint2*)(d0 + off[j]) = hi;
+                *(uint2*)(d0 + plane + off[j]) = lo;
+            } else {
+                uint4 o = rg.d[j];
+                if (SS) o = norm_act8_pk(o, rg.ssw, slope2);
+                if (EDGE && !((rg.ok >> j) & 1u)) o = make_uint4(0, 0, 0, 0);
+                *(uint4*)(d0 + off[j]) = o;
+            }
+        }
+    }
+}
+
+template <bool X3>
+__device__ __forceinline__ void ns_commit_sw(const ConvArgs& p, ChunkRegs& rg, unsigned char* dst_in, const int (&off)[WS_MAXV], int q, int HV,
+                                             int plane, int dbg) {
+    const int nv = (dbg & 32) ? 0 : (HV + WS_PROD / 2 - 1) / (WS_PROD / 2);
+    if (rg.skip_halo) return;
+    union {
+        unsigned u;
+        h2_t v;
+    } sl2;
+    sl2.v = h2_t{(_Float16)p.slope, (_Float16)p.slope};
+    // fp16: lane q & 1 owns k-half plane q & 1 of its voxels; split precision: hi -> plane 0, lo -> plane 1, lane q & 1 the 8-byte half
+    unsigned char* d0 = X3 ? dst_in + (q & 1) * 8 : dst_in + (q & 1) * plane;
+    const bool edge = __builtin_amdgcn_ballot_w64(rg.ok != rg.live) != 0;
+    if (rg.has_ss) {
+        if (edge)
+            ns_commit_items_sw<X3, true, true>(p, rg, d0, off, plane, nv, sl2.u);
+        else
+            ns_commit_items_sw<X3, true, false>(p, rg, d0, off, plane, nv, sl2.u);
+    } else {
+        if (edge)
+            ns_commit_items_sw<X3, false, true>(p, rg, d0, off, plane, nv, sl2.u);
+        else
+            ns_commit_items_sw<X3, false, false>(p, rg, d0, off, plane, nv, sl2.u);
+    }
+}
+
 // One 16-channel chunk: acc[r] += sum over the 27 taps.  b0p: LDS address of this lane's voxel in plane 0 of the wave's
 // M-tiles, this lane's k-half plane (halo extents are compile-time: every fragment read has an immediate offset); wb: the
 // packed weights (wave-uniform base); vcur / vnext: this lane's byte offset of (chunk, tap 0) of this and of the following
@@ -32,7 +118,7 @@
 // NR: slots of the weight ring (3 or 9: a divisor of the 9 groups, so the slot of a group does not depend on the chunk); group g + NR - 1 is
 // fetched while group g is consumed.  NR = 9 for the S = 2, RM = 2 instantiation: its groups are 6 MFMAs (192 cycles) long, two groups ahead
 // was less than an L2 round trip (BOA_WS_TRACE: 3 900 / 2 850 cycles per chunk of 54 MFMAs).
-template <int S, int RM, bool X3, int NR>
+template <int S, int RM, bool X3, int NR, bool NOFETCH = false>
 __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16 (&acc)[RM], f16x8 (&a)[NR][3], f16x8 (&al)[X3 ? NR : 1][3],
                                                 const WS_GLOBAL unsigned char* wb, unsigned vcur, unsigned vnext, unsigned gs, unsigned lo_off) {
     constexpr int NB = S * (RM - 1) + 3;
@@ -53,12 +139,13 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
         }
     };
 #pragma unroll
-    for (int jj = 0; jj < NB; ++jj) b[jj] = *(const f16x8*)(b0p + (jj * H1 * H2) * 16);
+    for (int jj = 0; jj < NB; ++jj) b[jj] = *(const f16x8*)(b0p + (S == 2 ? jj * 9 * NS_SW_ROW : jj * H1 * H2) * 16);
     __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
 #pragma unroll
     for (int g = 0; g < 9; ++g) {
         const int slot = g % NR;
-        if (g + NR - 1 < 9)
+        if constexpr (NOFETCH) {   // (ablation, traced build: the weight ring is never refilled)
+        } else if (g + NR - 1 < 9)
             fetch_a(vcur, g + NR - 1, (g + NR - 1) % NR);
         else
             fetch_a(vnext, g + NR - 1 - 9, (g + NR - 1) % NR);
@@ -83,7 +170,7 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * MM, 0);
             if (g + 1 < 9) {
                 const int gn = g + 1, dy = gn / 3, dz = gn % 3;
-                b[jj] = *(const f16x8*)(b0p + ((jj * H1 + dy) * H2 + dz) * 16);
+                b[jj] = *(const f16x8*)(b0p + (S == 2 ? (jj * 9 + ns_sw_yp(dy)) * NS_SW_ROW + ns_sw_zp(dz) : (jj * H1 + dy) * H2 + dz) * 16);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
@@ -93,7 +180,7 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
 // S: conv stride (all axes); WN: consumer waves along the cout axis (cout group = WN chunks), 4 / WN wave rows along x;
 // RM: M-tiles (x-planes of 4 x 8 output voxels) per wave.  Block tile = (4 / WN) * RM planes.
 template <int S, int WN, int RM, bool X3>
-__global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg) {
+__global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg, const int* __restrict__ desc, int desc_row) {
 #ifdef WS_WITH_TRACE
     const int dbg = dbg_arg;
 #else
@@ -108,81 +195,132 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg)
     const int l31 = lane & 31;
     const int kh = lane >> 5;
     const int HV = p.h0 * p.h1 * p.h2;
-    const int plane = ws_plane_bytes(HV);
+    const int plane = S == 2 ? ns_sw_plane_bytes() : ws_plane_bytes(HV);
     const int ncc = (p.C0 + p.C1) / 16;
     const int buf_bytes = 2 * plane;  // LDS: [halo buf 0][halo buf 1], each two k-octet planes
     unsigned char* bufs = smem;
 
-    int my_tiles = 0;
-    for (int v = (int)blockIdx.x; v < p.N * p.vw; v += (int)gridDim.x) my_tiles += p.runs[(v % p.vw) * 8];
+    // this workgroup's row of the launch's descriptor table (k_ws_build_desc, conv_ws.hip): entry 0 = its tile count, entry 1 + k =
+    // its k-th tile; each role reads one 32-byte descriptor per tile with scalar loads instead of walking the run tables
+    const int* __restrict__ drow = desc + (size_t)blockIdx.x * desc_row * 8;
+    const int my_tiles = drow[0];
     const int my_chunks = my_tiles * ncc;
     for (int i = tid; i < p.Cout; i += WS_THREADS) ((float*)(smem + 2 * buf_bytes))[i] = p.bias[i];  // (ordered by the first barrier)
+    const int tr_blk = WS_TRACING ? (int)p.trace[WS_TRACE_SLOTS - 5] : -1;   // (debug) the traced block: BOA_WS_TRACE=<block>
 
     if (producer) {
         // ---- producer waves: as in k_conv_ws without the weight staging (chunk g + 1 committed while the consumers work on
         // chunk g, its global loads issued one barrier interval earlier)
         const int q = tid - 256;
         const ProdConst pc = prod_const(p, q, HV);
-        TileSeq pseq;
-        pseq.n = pseq.left = pseq.j = 0;
-        TileCoord& ptc = pseq.tc;
+        // SW layout: this lane's LDS byte offset of its halo voxels (kernel constants, like pc.rel)
+        int ldso[WS_MAXV];
+#pragma unroll
+        for (int j = 0; j < WS_MAXV; ++j) {
+            const int v = (q >> 1) + (WS_PROD / 2) * j;
+            const int hz = v % 17, t = v / 17;
+            const int hy = t % 9, hx = t / 9;
+            ldso[j] = (v < HV ? (hx * 9 + ns_sw_yp(hy)) * NS_SW_ROW + ns_sw_zp(hz) : ns_sw_slots()) * 16;
+        }
+        TileDesc pd;   // the tile whose chunks are being issued
+        pd.flags = pd.vo = pd.ibase = 0;
+        TileCoord& ptc = pd.tc;
+        int pk = 0;
         ptc.n = ptc.cy = ptc.ox0 = ptc.oy0 = ptc.oz0 = ptc.sp = 0;
         ProdItems items;
 #pragma unroll
         for (int j = 0; j < WS_MAXV; ++j) items.gi[j] = 0;
         items.ok = 0;
-        ChunkRegs rg;
+        // Two register sets (PF2): the loads of chunk g + 2 are issued at the HEAD of the interval, before chunk g + 1 is committed, so
+        // they have a whole barrier interval to land.  The stride-2 layers stage 8 input voxels per output voxel and are bound by
+        // the producers' HBM / L2 round trips (trace of an interior workgroup, 32 -> 64 @128^3: 330 + 1 220 cycles per tile waiting for
+        // loads that were issued behind the previous commit); k_conv_ns has no weight DMA whose vmcnt(0) would also wait for
+        // them (what made the same change a loss in k_conv_ws).  The interval loop is unrolled by two so that the sets alternate
+        // without copies.  A/B on one box (tools/ab_layers.sh, batch 8): 64 -> 128 @64^3 -5 %, 128 -> 256 @32^3 -8 %, 256 -> 320 @16^3
+        // -8 %; the 32 -> 64 layer at 128^3 (RM = 2: HBM-cold input, 3.6 TB/s of halo traffic) +16 % -- twice the loads in flight per
+        // CU there only deepen the queue in front of the memory side -- so that instantiation keeps one set.
+        constexpr bool PF2 = NS_PF2 && RM == 4;
+        ChunkRegs rgA, rgB;
+        auto clear_regs = [&](ChunkRegs& rg) {
 #pragma unroll
-        for (int j = 0; j < WS_MAXV; ++j) rg.d[j] = make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < WS_MAXV; ++j) rg.d[j] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rg.ssw[j] = 0;
-        rg.ok = rg.live = 0;
-        rg.has_ss = 0;
-        rg.skip_halo = 0;
+            for (int j = 0; j < 8; ++j) rg.ssw[j] = 0;
+            rg.ok = rg.live = 0;
+            rg.has_ss = 0;
+            rg.skip_halo = 0;
+            rg.cc = rg.cy = 0;
+        };
+        clear_regs(rgA);
+        clear_regs(rgB);
         int pcc = 0;
         int ptr_n = 0;
-        // debug timeline of producer wave 4 of block 0 (second half of the trace buffer): 1 barrier passed, 8 next tile set up,
-        // 2 chunk committed, 3 next loads issued
+        // debug timeline of producer wave 4 of the traced block (second half of the trace buffer): 1 barrier passed, 8 next tile set up,
+        // 7 loads landed, 2 chunk committed, 3 next loads issued
 #define NS_PSTAMP(code)                                                                                                          \
     do {                                                                                                                         \
-        if (WS_TRACING && blockIdx.x == 0 && wave == 4 && lane == 0 && ptr_n < WS_TRACE_SLOTS / 2) {                                  \
+        if (WS_TRACING && (int)blockIdx.x == tr_blk && wave == 4 && lane == 0 && ptr_n < WS_TRACE_SLOTS / 2 - 8) {                                  \
             p.trace[WS_TRACE_SLOTS / 2 + ptr_n] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
             ++ptr_n;                                                                                                             \
         }                                                                                                                        \
     } while (0)
         const bool live = !(dbg & 2);
+        auto setup_next = [&]() {   // descriptor + halo addresses of the next tile (before its first chunk is issued)
+            pd = load_desc(drow, ++pk);
+            prod_setup_desc(p, pd, pc, items);
+            NS_PSTAMP(8);
+        };
+        auto issue = [&](ChunkRegs& rg) {
+            prod_issue(p, ptc, items, pc.in_halo, pcc, false, q, dbg, rg);
+            if (++pcc == ncc) pcc = 0;
+            NS_PSTAMP(3);
+        };
+        auto commit = [&](ChunkRegs& rg, unsigned char* dst) {
+            if (WS_TRACING) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                NS_PSTAMP(7);
+            }
+            if constexpr (S == 2)
+                ns_commit_sw<X3>(p, rg, dst, ldso, q, HV, plane, dbg);
+            else if constexpr (X3)
+                prod_commit_x3(p, rg, dst, q, HV, plane, dbg);
+            else
+                prod_commit(p, rg, dst, q, HV, plane, dbg);
+            NS_PSTAMP(2);
+        };
         if (live && my_chunks > 0) {
-            seq_first(p, pseq);
-            prod_setup(p, ptc, pc, items);
-            prod_issue(p, ptc, items, pc.in_halo, 0, false, q, dbg, rg);
+            pd = load_desc(drow, 0);
+            prod_setup_desc(p, pd, pc, items);
+            prod_issue(p, ptc, items, pc.in_halo, 0, false, q, dbg, rgA);
             if (++pcc == ncc) pcc = 0;
         }
-        for (int g = -1; g < my_chunks; ++g) {
-            if (live && g + 1 < my_chunks) {
-                unsigned char* nxt = bufs + ((g + 1) & 1) * buf_bytes;
-                const bool do_issue = g + 2 < my_chunks;
-                NS_PSTAMP(1);
-                if (do_issue && pcc == 0) {  // (before the commit: see k_conv_ws)
-                    seq_next(p, pseq);
-                    prod_setup(p, ptc, pc, items);
-                    NS_PSTAMP(8);
+        if constexpr (PF2) {
+            auto interval = [&](int g, ChunkRegs& cur, ChunkRegs& nxt) {
+                if (live && g + 1 < my_chunks) {
+                    NS_PSTAMP(1);
+                    if (g + 2 < my_chunks) {
+                        if (pcc == 0) setup_next();
+                        issue(nxt);
+                    }
+                    commit(cur, bufs + ((g + 1) & 1) * buf_bytes);
                 }
-                if (WS_TRACING) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    NS_PSTAMP(7);
-                }
-                if constexpr (X3)
-                    prod_commit_x3(p, rg, nxt, q, HV, plane, dbg);
-                else
-                    prod_commit(p, rg, nxt, q, HV, plane, dbg);
-                NS_PSTAMP(2);
-                if (do_issue) {
-                    prod_issue(p, ptc, items, pc.in_halo, pcc, false, q, dbg, rg);
-                    if (++pcc == ncc) pcc = 0;
-                }
-                NS_PSTAMP(3);
+                __syncthreads();
+            };
+            for (int g = -1; g < my_chunks; g += 2) {
+                interval(g, rgA, rgB);
+                if (g + 1 < my_chunks) interval(g + 1, rgB, rgA);
             }
-            __syncthreads();
+        } else {
+            for (int g = -1; g < my_chunks; ++g) {
+                if (live && g + 1 < my_chunks) {
+                    NS_PSTAMP(1);
+                    const bool do_issue = g + 2 < my_chunks;
+                    if (do_issue && pcc == 0) setup_next();   // (before the commit: the loads go out right behind it, see k_conv_ws)
+                    commit(rgA, bufs + ((g + 1) & 1) * buf_bytes);
+                    if (do_issue) issue(rgA);
+                }
+                __syncthreads();
+            }
         }
         return;
     }
@@ -193,19 +331,18 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg)
     // debug timeline (BOA_WS_TRACE): consumer wave 0 of block 0; codes 1 tile start, 2 before the first chunk, 3 chunk done, 4 barrier passed
 #define NS_STAMP(code)                                                                                                   \
     do {                                                                                                                 \
-        if (WS_TRACING && blockIdx.x == 0 && wave == 0 && lane == 0 && tr_n < WS_TRACE_SLOTS) {                              \
+        if (WS_TRACING && (int)blockIdx.x == tr_blk && wave == 0 && lane == 0 && tr_n < WS_TRACE_SLOTS / 2) {                              \
             p.trace[tr_n] = ((unsigned long long)(code) << 56) | (__builtin_readcyclecounter() & 0x00ffffffffffffffull); \
             ++tr_n;                                                                                                      \
         }                                                                                                                \
     } while (0)
-    constexpr int WM = 4 / WN;
     const int cw = wave & 3;
     const int wn = cw % WN, wm = cw / WN;
     const int ly = l31 >> 3, lz = l31 & 7;
     const int nchunks_out = p.Cout / 32;
     // this lane's voxel in plane 0 of the wave's M-tiles, its k-half plane
     constexpr int H1 = 3 * S + 3, H2 = 7 * S + 3;  // halo extents along y, z (host: conv_ns_tile)
-    const int hoff = (((S * (wm * RM)) * H1 + S * ly) * H2 + S * lz) * 16 + kh * plane;
+    const int hoff = (S == 2 ? ((2 * (wm * RM)) * 9 + ly) * NS_SW_ROW + lz : ((S * (wm * RM)) * H1 + S * ly) * H2 + S * lz) * 16 + kh * plane;
     const int srel0 = ly * p.Wo + lz;
     const size_t out_vox = (size_t)p.Do * p.Ho * p.Wo;
     const int nslots = p.nslots;
@@ -246,12 +383,13 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg)
     };
 
     f32x16 acc[RM];
-    auto epilogue = [&](const TileCoord& tc, int ch) {
+    auto epilogue = [&](const TileCoord& tc, int ch, int dfl, int dvo) {
         st_n = tc.n;  // (the caller flushed when the sample / cout chunk / run changed)
         st_ch = ch;
         const int cout0 = ch * 32;
-        const bool full = tc.ox0 + WM * RM <= p.Do && tc.oy0 + 4 <= p.Ho && tc.oz0 + 8 <= p.Wo;
-        const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + (((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) * 16;
+        const bool full = (dfl & WS_DF_FULL) != 0;   // (block tile = 4 x 4 x 8 = b x w of conv_ns_tile: make_desc's test)
+        const size_t ovox = (size_t)(unsigned)dvo;
+        const size_t obase = ((size_t)tc.n * p.Cout + cout0) * out_vox + ovox * 16;
         const unsigned olane = ((unsigned)kh * (unsigned)out_vox + (unsigned)srel0) * 32u;
 #pragma unroll
         for (int r = 0; r < RM; ++r) {
@@ -276,7 +414,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg)
             }
             if constexpr (X3) {   // fp32 octet planes (k_conv_ws<X3>'s store)
                 if (ok && !(dbg & 4)) {
-                    const size_t doff = ((size_t)tc.n * p.Cout + cout0) * out_vox * 4 + ((((size_t)tc.ox0 * p.Ho + tc.oy0) * p.Wo + tc.oz0) + (size_t)mrel) * 32;
+                    const size_t doff = ((size_t)tc.n * p.Cout + cout0) * out_vox * 4 + (ovox + (size_t)mrel) * 32;
                     const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)doff), dhi = __builtin_amdgcn_readfirstlane((unsigned)(doff >> 32));
                     WS_GLOBAL unsigned char* dst = sgpr_ptr((const unsigned char*)p.out + (((size_t)dhi << 32) | dlo));
 #pragma unroll
@@ -361,35 +499,26 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg)
             }
     };
 
-    TileSeq cseq;
-    cseq.n = cseq.left = cseq.j = 0;
-    cseq.tc.n = cseq.tc.cy = cseq.tc.ox0 = cseq.tc.oy0 = cseq.tc.oz0 = cseq.tc.sp = 0;
-    // cout group of the tile after the current one (the weight ring is prefetched across tile boundaries): within a run the
-    // group advances when the spatial index wraps (spatial tiles are the fastest index), a new run reads its table entry
-    const int nsp = p.t0 * p.t1 * p.t2;
-    auto peek_next_cy = [&]() -> int {
-        if (cseq.left > 1) return cseq.tc.sp == nsp - 1 ? (cseq.tc.cy + 1 == p.ncy ? 0 : cseq.tc.cy + 1) : cseq.tc.cy;
-        int j = cseq.j + p.vstep_j;
-        if (j >= p.vw) j -= p.vw;
-        return p.runs[j * 8 + 1];
-    };
+    TileDesc cd;
+    cd.flags = cd.vo = cd.ibase = 0;
+    cd.tc.n = cd.tc.cy = cd.tc.ox0 = cd.tc.oy0 = cd.tc.oz0 = cd.tc.sp = 0;
     bool ring_valid = false;
-    TileCoord done_tc = cseq.tc;
-    int done_ch = 0;
+    TileCoord done_tc = cd.tc;
+    int done_ch = 0, done_fl = 0, done_vo = 0;
     bool done_active = false;
     __syncthreads();  // chunk 0 and the bias table staged
     for (int k = 0; k < my_tiles + 1; ++k) {
         const bool more = k < my_tiles;
         bool new_run = true;
         NS_STAMP(1);
-        if (k == 0) {
-            if (more) seq_first(p, cseq);
-        } else if (more)
-            new_run = seq_next(p, cseq);
+        if (more) {
+            cd = load_desc(drow, k);
+            new_run = (cd.flags & WS_DF_NEWRUN) != 0;
+        }
         const bool have_next = k + 1 < my_tiles;
-        const TileCoord& tc = cseq.tc;
+        const TileCoord& tc = cd.tc;
         const int ch = tc.cy * WN + wn;
-        if (k > 0 && done_active && !(dbg & 8)) epilogue(done_tc, done_ch);  // deferred: the previous tile's
+        if (k > 0 && done_active && !(dbg & 8)) epilogue(done_tc, done_ch, done_fl, done_vo);  // deferred: the previous tile's
         // ONE flush site: the accumulated partial sums go to their slot when the next tile belongs to another virtual
         // workgroup, sample or cout chunk, and at the end
         if (k > 0 && (!more || new_run || tc.n != st_n || ch != st_ch)) {
@@ -397,10 +526,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg)
             st_n = -1;
         }
         if (!more) break;
-        if (new_run) slot = cseq.j * 4 + cw;
+        if (new_run) slot = (int)((unsigned)cd.flags >> 16) * 4 + cw;
         const bool active = ch < nchunks_out;
         // the chunk the ring is prefetched for after this tile: the next tile's (clamped to a valid chunk when this wave idles there)
-        int ch_next = have_next ? peek_next_cy() * WN + wn : ch;
+        // (the cout group of the tile after this one: the weight ring is prefetched across tile boundaries)
+        int ch_next = have_next ? drow[(size_t)(k + 2) * 8 + 1] * WN + wn : ch;
         const bool next_active = have_next && ch_next < nchunks_out;
         if (ch_next >= nchunks_out) ch_next = nchunks_out - 1;
         if (active) {
@@ -428,7 +558,13 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg)
                 const WS_GLOBAL unsigned char* wb = sgpr_ptr(p.wpk);
                 const unsigned vcur = woff(cc, ch);
                 const unsigned vnext = cc + 1 < ncc ? woff(cc + 1, ch) : woff(0, ch_next);
-                consume_chunk_x<S, RM, X3, NR>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
+                if (dbg & 8192)   // (ablation: every second tile without weight fetches -- what the consumers' L2 -> register weight traffic costs)
+                    if (k & 1)
+                        consume_chunk_x<S, RM, X3, NR, true>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
+                    else
+                        consume_chunk_x<S, RM, X3, NR>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
+                else
+                    consume_chunk_x<S, RM, X3, NR>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
             }
             NS_STAMP(3);
             __syncthreads();
@@ -442,12 +578,15 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg)
         done_tc.oy0 = __builtin_amdgcn_readfirstlane(tc.oy0);
         done_tc.oz0 = __builtin_amdgcn_readfirstlane(tc.oz0);
         done_ch = __builtin_amdgcn_readfirstlane(ch);
+        done_fl = __builtin_amdgcn_readfirstlane(cd.flags);
+        done_vo = __builtin_amdgcn_readfirstlane(cd.vo);
         done_active = active;
     }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
 const int* ws_run_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, int vw);
+const int* ws_desc_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, int grid, int* row_out);
 int conv_ws_vw(int tiles_per_sample, int cu_count);
 
 static size_t ns_plane_host(int HV) { return ((size_t)(HV + WS_PROD / 2 - 1) / (WS_PROD / 2)) * (WS_PROD / 2) * 16 + 64; }
@@ -484,17 +623,18 @@ void conv_ns_tile(const ConvGeom& g, ConvTile* t) {
         t->tiles[d] = (dims[d] + ext[d] - 1) / ext[d];
         HV *= (size_t)t->h[d];
     }
-    t->lds_bytes = 4 * ns_plane_host((int)HV) + (size_t)g.Cout * sizeof(float);  // two halo buffers + the bias table
+    // two halo buffers (stride 2: the de-interleaved layout, see NS_SW_ROW) + the bias table
+    t->lds_bytes = 4 * (g.s[0] == 2 ? (size_t)ns_sw_plane_bytes() : ns_plane_host((int)HV)) + (size_t)g.Cout * sizeof(float);
 }
 
 int conv_ns_ncy(int Cout) { return (Cout / 32 + ns_wn(Cout) - 1) / ns_wn(Cout); }
 
 template <int S, int WN, int RM, bool X3 = false>
-static void launch_ns(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int grid) {
+static void launch_ns(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int grid, const int* desc, int desc_row) {
     static bool once = (hipFuncSetAttribute((const void*)k_conv_ns<S, WN, RM, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
     hipLaunchKernelGGL((k_conv_ns<S, WN, RM, X3>), dim3(grid), dim3(WS_THREADS), t.lds_bytes, ctx->stream, a,
-                       getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0);
+                       getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0, desc, desc_row);
 }
 
 int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double flops, double bytes, bool x3) {
@@ -516,6 +656,8 @@ int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     if (want_trace) {
         hipMalloc(&a.trace, WS_TRACE_SLOTS * 8);
         hipMemsetAsync(a.trace, 0, WS_TRACE_SLOTS * 8, ctx->stream);
+        const unsigned long long blk = (unsigned long long)std::min(std::max(atoi(getenv("BOA_WS_TRACE")), 0), grid - 1);
+        hipMemcpyAsync(a.trace + WS_TRACE_SLOTS - 5, &blk, 8, hipMemcpyHostToDevice, ctx->stream);
     }
     a.nslots = 4 * vw;
     a.vw = vw;
@@ -524,21 +666,24 @@ int launch_conv_ns(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     a.cy_fast = 0;
     a.runs = ws_run_table(ctx, a, total, vw);
     BOA_REQUIRE(a.runs != nullptr, "conv_ns: could not allocate the run table");
+    int desc_row = 0;
+    const int* desc = ws_desc_table(ctx, a, total, grid, &desc_row);
+    BOA_REQUIRE(desc != nullptr, "conv_ns: could not allocate the tile descriptor table");
     KernelTimer tm(ctx, BOA_K_CONV_MFMA, flops, bytes);
     ctx->counters[x3 ? BOA_CNT_CONV_X3 : BOA_CNT_CONV_WS]++;
     if (x3) {
         BOA_REQUIRE(a.s0 == 2, "conv_ns: the split-precision instantiations are stride 2 only");
         if (ns_wn(a.Cout) == 2)
-            launch_ns<2, 2, 2, true>(ctx, a, t, grid);
+            launch_ns<2, 2, 2, true>(ctx, a, t, grid, desc, desc_row);
         else
-            launch_ns<2, 4, 4, true>(ctx, a, t, grid);
+            launch_ns<2, 4, 4, true>(ctx, a, t, grid, desc, desc_row);
     } else if (ns_wn(a.Cout) == 2) {
         BOA_REQUIRE(a.s0 == 2, "conv_ns: the two-chunk cout group is instantiated for stride 2 only");
-        launch_ns<2, 2, 2>(ctx, a, t, grid);
+        launch_ns<2, 2, 2>(ctx, a, t, grid, desc, desc_row);
     } else if (a.s0 == 1)
-        launch_ns<1, 4, 4>(ctx, a, t, grid);
+        launch_ns<1, 4, 4>(ctx, a, t, grid, desc, desc_row);
     else
-        launch_ns<2, 4, 4>(ctx, a, t, grid);
+        launch_ns<2, 4, 4>(ctx, a, t, grid, desc, desc_row);
     tm.stop();
     if (want_trace && a.trace) {
         static unsigned long long host[WS_TRACE_SLOTS];

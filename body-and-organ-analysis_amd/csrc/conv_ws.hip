@@ -872,7 +872,7 @@ const int* ws_run_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, i
 
 // Descriptor table of a launch (WS_DESC): a function of the layer geometry, the batch and the grid; built once per key on the
 // device by k_ws_build_desc and kept for the context's lifetime (8 samples of the 128^3 layers: 32 768 tiles = 1 MiB).
-static const int* ws_desc_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, int grid, int* row_out) {
+const int* ws_desc_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, int grid, int* row_out) {
     std::vector<int> key = {-1,   a.t0, a.t1, a.t2, a.b0, a.b1, a.b2, a.w0, a.w1, a.w2, a.Cout, a.cy_fast, a.vw, a.ncy, a.N,  grid,
                             a.Do, a.Ho, a.Wo, a.Di, a.Hi, a.Wi, a.s0, a.s1, a.s2, a.p0, a.p1,   a.p2,      a.h0, a.h1,  a.h2};
     // rows: an upper bound of a workgroup's tiles.  A run has at most tiles_per_sample / vw + 2 tiles (ws_run_table: the 8 XCD ranges

@@ -39,6 +39,10 @@ def timed(name, fn, nbytes):
 
 timed("tissue_aggregate", lambda: bca.tissue_aggregate(ctx, d_ct, d["regions"], d["parts"], shape)[0], 5.0 * n)
 timed("label_hu_histogram", lambda: M.label_hu_histogram(ctx, d_ct, d["total"], n) is None, 3.0 * n)
+# the same pass on salt-and-pepper labels (what the random-weight nets of bench.py produce): every voxel another (label, HU) key
+d_noise = ctx.from_numpy(np.random.default_rng(5).integers(0, 118, size=n, dtype=np.uint8))
+timed("label_hu_histogram noise", lambda: M.label_hu_histogram(ctx, d_ct, d_noise, n) is None, 3.0 * n)
+d_noise.free()
 d_m, d_o, d_t = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
 M.label_hu_mask(ctx, d_ct, d["total"], range(1, 30), 0, n, d_m)
 timed("binary_erode_6", lambda: M.binary_erode(ctx, d_m, d_o, d_t, shape, 6), 2.0 * n)
