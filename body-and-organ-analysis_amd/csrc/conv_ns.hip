@@ -35,6 +35,10 @@
 // of a 256-byte bank row exactly once; the tap offsets stay compile-time immediates.  The producers' stores (8-lane groups = 4
 // consecutive voxels x 2 k-half planes, 128-byte bank rows) stay conflict-free with the odd columns at slot 10 (= 2 mod 8) and the
 // planes' 64-byte skew.  Lanes past the halo store into one dummy slot behind the plane.
+#ifndef NS_SW
+#define NS_SW 1   // 0: the linear layout for every stride (A/B builds)
+#endif
+#define NS_SWZ(S) (NS_SW && (S) == 2)
 #define NS_SW_ROW 24
 #define NS_SW_YODD 5
 #define NS_SW_ZODD 10
@@ -118,7 +122,7 @@ __device__ __forceinline__ void ns_commit_sw(const ConvArgs& p, ChunkRegs& rg, u
 // NR: slots of the weight ring (3 or 9: a divisor of the 9 groups, so the slot of a group does not depend on the chunk); group g + NR - 1 is
 // fetched while group g is consumed.  NR = 9 for the S = 2, RM = 2 instantiation: its groups are 6 MFMAs (192 cycles) long, two groups ahead
 // was less than an L2 round trip (BOA_WS_TRACE: 3 900 / 2 850 cycles per chunk of 54 MFMAs).
-template <int S, int RM, bool X3, int NR, bool NOFETCH = false>
+template <int S, int RM, bool X3, int NR>
 __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16 (&acc)[RM], f16x8 (&a)[NR][3], f16x8 (&al)[X3 ? NR : 1][3],
                                                 const WS_GLOBAL unsigned char* wb, unsigned vcur, unsigned vnext, unsigned gs, unsigned lo_off) {
     constexpr int NB = S * (RM - 1) + 3;
@@ -139,13 +143,12 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
         }
     };
 #pragma unroll
-    for (int jj = 0; jj < NB; ++jj) b[jj] = *(const f16x8*)(b0p + (S == 2 ? jj * 9 * NS_SW_ROW : jj * H1 * H2) * 16);
+    for (int jj = 0; jj < NB; ++jj) b[jj] = *(const f16x8*)(b0p + (NS_SWZ(S) ? jj * 9 * NS_SW_ROW : jj * H1 * H2) * 16);
     __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
 #pragma unroll
     for (int g = 0; g < 9; ++g) {
         const int slot = g % NR;
-        if constexpr (NOFETCH) {   // (ablation, traced build: the weight ring is never refilled)
-        } else if (g + NR - 1 < 9)
+        if (g + NR - 1 < 9)
             fetch_a(vcur, g + NR - 1, (g + NR - 1) % NR);
         else
             fetch_a(vnext, g + NR - 1 - 9, (g + NR - 1) % NR);
@@ -170,7 +173,7 @@ __device__ __forceinline__ void consume_chunk_x(const unsigned char* b0p, f32x16
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * MM, 0);
             if (g + 1 < 9) {
                 const int gn = g + 1, dy = gn / 3, dz = gn % 3;
-                b[jj] = *(const f16x8*)(b0p + (S == 2 ? (jj * 9 + ns_sw_yp(dy)) * NS_SW_ROW + ns_sw_zp(dz) : (jj * H1 + dy) * H2 + dz) * 16);
+                b[jj] = *(const f16x8*)(b0p + (NS_SWZ(S) ? (jj * 9 + ns_sw_yp(dy)) * NS_SW_ROW + ns_sw_zp(dz) : (jj * H1 + dy) * H2 + dz) * 16);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg,
     const int l31 = lane & 31;
     const int kh = lane >> 5;
     const int HV = p.h0 * p.h1 * p.h2;
-    const int plane = S == 2 ? ns_sw_plane_bytes() : ws_plane_bytes(HV);
+    const int plane = NS_SWZ(S) ? ns_sw_plane_bytes() : ws_plane_bytes(HV);
     const int ncc = (p.C0 + p.C1) / 16;
     const int buf_bytes = 2 * plane;  // LDS: [halo buf 0][halo buf 1], each two k-octet planes
     unsigned char* bufs = smem;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg,
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 NS_PSTAMP(7);
             }
-            if constexpr (S == 2)
+            if constexpr (NS_SWZ(S))
                 ns_commit_sw<X3>(p, rg, dst, ldso, q, HV, plane, dbg);
             else if constexpr (X3)
                 prod_commit_x3(p, rg, dst, q, HV, plane, dbg);
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg,
     const int nchunks_out = p.Cout / 32;
     // this lane's voxel in plane 0 of the wave's M-tiles, its k-half plane
     constexpr int H1 = 3 * S + 3, H2 = 7 * S + 3;  // halo extents along y, z (host: conv_ns_tile)
-    const int hoff = (S == 2 ? ((2 * (wm * RM)) * 9 + ly) * NS_SW_ROW + lz : ((S * (wm * RM)) * H1 + S * ly) * H2 + S * lz) * 16 + kh * plane;
+    const int hoff = (NS_SWZ(S) ? ((2 * (wm * RM)) * 9 + ly) * NS_SW_ROW + lz : ((S * (wm * RM)) * H1 + S * ly) * H2 + S * lz) * 16 + kh * plane;
     const int srel0 = ly * p.Wo + lz;
     const size_t out_vox = (size_t)p.Do * p.Ho * p.Wo;
     const int nslots = p.nslots;
@@ -558,13 +561,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg,
                 const WS_GLOBAL unsigned char* wb = sgpr_ptr(p.wpk);
                 const unsigned vcur = woff(cc, ch);
                 const unsigned vnext = cc + 1 < ncc ? woff(cc + 1, ch) : woff(0, ch_next);
-                if (dbg & 8192)   // (ablation: every second tile without weight fetches -- what the consumers' L2 -> register weight traffic costs)
-                    if (k & 1)
-                        consume_chunk_x<S, RM, X3, NR, true>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
-                    else
-                        consume_chunk_x<S, RM, X3, NR>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
-                else
-                    consume_chunk_x<S, RM, X3, NR>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
+                consume_chunk_x<S, RM, X3, NR>(cur + ho, acc, a, al, wb, vcur, vnext, gs, lo_off);
             }
             NS_STAMP(3);
             __syncthreads();
@@ -624,7 +621,7 @@ void conv_ns_tile(const ConvGeom& g, ConvTile* t) {
         HV *= (size_t)t->h[d];
     }
     // two halo buffers (stride 2: the de-interleaved layout, see NS_SW_ROW) + the bias table
-    t->lds_bytes = 4 * (g.s[0] == 2 ? (size_t)ns_sw_plane_bytes() : ns_plane_host((int)HV)) + (size_t)g.Cout * sizeof(float);
+    t->lds_bytes = 4 * (NS_SWZ(g.s[0]) ? (size_t)ns_sw_plane_bytes() : ns_plane_host((int)HV)) + (size_t)g.Cout * sizeof(float);
 }
 
 int conv_ns_ncy(int Cout) { return (Cout / 32 + ns_wn(Cout) - 1) / ns_wn(Cout); }
