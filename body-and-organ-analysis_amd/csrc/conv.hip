@@ -1236,6 +1236,37 @@ int launch_norm_finalize(boa_ctx* ctx, float* partials, int nblk, int N, int C, 
 
 // ======================================================================================================
 // transposed conv, kernel == stride: out[o] = sum_ci y[o / s][ci] * W[ci][co][o % s] + b
+// ---- the transposed convs' per-wave LDS slab (D fragments -> 16-byte pieces of the output voxels' records) -------------------------
+// Logical layout [plane][output voxel ov = l31 * TZ + t][16 couts]: lane (l31, kh) writes the 8-byte piece q = 2 (gq & 1) + kh of its
+// voxel's 32-byte record, the wave then reads 16-byte pieces `lane + 64 k` and stores 1 KiB runs.  With TZ = 2 the writing lanes sit
+// 64 bytes apart: every 16-lane group of the ds_write_b64 fell on two banks' worth of one 128-byte row -- 8-way conflicts, 72 - 76 % of
+// the kernels' LDS cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r05_pmc_lds.txt).  Physical layout for TZ = 2: record
+// (t, l31) at t * 32 + (l31 ^ 4 t) (lanes 32 bytes apart; the xor keeps the two taps of a voxel pair off the same bank row for the
+// reads), piece q at q ^ ((l31 >> 2) & 3) (the four lanes of a group that share a 32-byte window take its four pieces): writes and
+// reads are conflict-free; a reader whose record has an odd swizzle finds the two 8-byte pieces of its half swapped and swaps them back.
+template <int TZ>
+__device__ __forceinline__ int convt_slab_waddr(int gq, int l31, int t, int kh) {
+    if constexpr (TZ == 2) {
+        const int rec = t * 32 + (l31 ^ (4 * t));
+        const int q = ((gq & 1) * 2 + kh) ^ ((l31 >> 2) & 3);
+        return ((gq >> 1) * 64 + rec) * 32 + q * 8;
+    } else {
+        return ((gq >> 1) * 32 * TZ + l31 * TZ + t) * 32 + (8 * (gq & 1) + 4 * kh) * 2;
+    }
+}
+template <int TZ>
+__device__ __forceinline__ uint4 convt_slab_read(const unsigned char* slab, int pl, int piece) {
+    if constexpr (TZ == 2) {
+        const int ov = piece >> 1, h = piece & 1;
+        const int j = ov >> 1, tz = ov & 1;
+        const int sw = (j >> 2) & 3;
+        const uint4 d = *(const uint4*)(slab + (pl * 64 + tz * 32 + (j ^ (4 * tz))) * 32 + (h ^ (sw >> 1)) * 16);
+        return (sw & 1) ? make_uint4(d.z, d.w, d.x, d.y) : d;
+    } else {
+        return *(const uint4*)(slab + pl * 32 * TZ * 32 + piece * 16);
+    }
+}
+
 struct ConvTArgs {
     const __half* src;
     const float* ss;
@@ -1429,7 +1460,7 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
                 pk.h[1] = __float2half_rn(acc[t][gq * 4 + 1] + biasv[gq * 4 + 1]);
                 pk.h[2] = __float2half_rn(acc[t][gq * 4 + 2] + biasv[gq * 4 + 2]);
                 pk.h[3] = __float2half_rn(acc[t][gq * 4 + 3] + biasv[gq * 4 + 3]);
-                *(uint2*)(slab + ((gq >> 1) * 32 * TZ + l31 * TZ + t) * 32 + (8 * (gq & 1) + 4 * kh) * 2) = pk.u;
+                *(uint2*)(slab + convt_slab_waddr<TZ>(gq, l31, t, kh)) = pk.u;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1439,7 +1470,7 @@ __global__ __launch_bounds__(256) void k_convt_mfma(ConvTArgs p) {
 #pragma unroll
             for (int k = 0; k < TZ; ++k) {
                 const int piece = lane + 64 * k;
-                const uint4 d = *(const uint4*)(slab + pl * 32 * TZ * 32 + piece * 16);
+                const uint4 d = convt_slab_read<TZ>(slab, pl, piece);
                 if (ovalid[k]) *(uint4*)(optr[k] + poff + (size_t)pl * ovox * 32) = d;
             }
         __builtin_amdgcn_wave_barrier();
@@ -1560,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_convt_mfma_rw(ConvTArgs p) {
                     pk.h[1] = __float2half_rn(acc[t][gq * 4 + 1] + bq[gq].y);
                     pk.h[2] = __float2half_rn(acc[t][gq * 4 + 2] + bq[gq].z);
                     pk.h[3] = __float2half_rn(acc[t][gq * 4 + 3] + bq[gq].w);
-                    *(uint2*)(slab + ((gq >> 1) * 32 * TZ + l31 * TZ + t) * 32 + (8 * (gq & 1) + 4 * kh) * 2) = pk.u;
+                    *(uint2*)(slab + convt_slab_waddr<TZ>(gq, l31, t, kh)) = pk.u;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1569,7 +1600,7 @@ __global__ __launch_bounds__(256) void k_convt_mfma_rw(ConvTArgs p) {
 #pragma unroll
                 for (int k = 0; k < TZ; ++k) {
                     const int piece = lane + 64 * k;
-                    const uint4 d = *(const uint4*)(slab + pl * 32 * TZ * 32 + piece * 16);
+                    const uint4 d = convt_slab_read<TZ>(slab, pl, piece);
                     if ((ovalid >> (g * TZ + k)) & 1u) *(uint4*)(optr[g][k] + poff + (size_t)pl * ovox * 32) = d;
                 }
             __builtin_amdgcn_wave_barrier();
@@ -1708,7 +1739,7 @@ __global__ __launch_bounds__(256) void k_convt_deep(ConvTArgs p) {
                     pk.h[1] = __float2half_rn(acc[t][m][gq * 4 + 1] + bq[gq].y);
                     pk.h[2] = __float2half_rn(acc[t][m][gq * 4 + 2] + bq[gq].z);
                     pk.h[3] = __float2half_rn(acc[t][m][gq * 4 + 3] + bq[gq].w);
-                    *(uint2*)(slab + ((gq >> 1) * 32 * TZ + l31 * TZ + t) * 32 + (8 * (gq & 1) + 4 * kh) * 2) = pk.u;
+                    *(uint2*)(slab + convt_slab_waddr<TZ>(gq, l31, t, kh)) = pk.u;
                 }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1716,7 +1747,7 @@ __global__ __launch_bounds__(256) void k_convt_deep(ConvTArgs p) {
 #pragma unroll
                 for (int k = 0; k < TZ; ++k) {
                     const int piece = lane + 64 * k;
-                    const uint4 d = *(const uint4*)(slab + pl * 32 * TZ * 32 + piece * 16);
+                    const uint4 d = convt_slab_read<TZ>(slab, pl, piece);
                     if ((ovalid >> (m * TZ + k)) & 1u) *(uint4*)(optr[m][k] + poff + (size_t)pl * ovox * 32) = d;
                 }
             __builtin_amdgcn_wave_barrier();
