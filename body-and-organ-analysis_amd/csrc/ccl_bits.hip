@@ -201,12 +201,18 @@ __global__ __launch_bounds__(256) void k_bits_assign(const unsigned* __restrict_
     }
 }
 
+__host__ __device__ inline int cb_fill_stride(int W) { return W | 1; }   // LDS row stride of the slice floods (odd: see k_bits_fill2d)
+
 // ---- slice-wise contour fill on bit masks (the flood of k_fill_holes_bits, morph.hip, without the byte <-> bit conversions) -------
 __global__ __launch_bounds__(256) void k_bits_fill2d(const unsigned* __restrict__ in, CbGeom g, unsigned* __restrict__ out) {
     extern __shared__ unsigned int fsm2[];
     const int Y = g.Y, W = g.W, X = g.X;
-    unsigned int* bg = fsm2;                   // [Y][W]
-    unsigned int* rc = fsm2 + (size_t)Y * W;   // [Y][W]
+    // LDS rows are WP = W | 1 words apart: in the horizontal sweeps lane y walks row y word by word, and with an even stride (a 512-wide
+    // slice: 16 words = 64 bytes) the 32 lanes of a ds_read_b32 group fell on two banks -- 16-way conflicts, 87 % of the kernel's LDS
+    // cycles (SQ_LDS_BANK_CONFLICT 3.3 G of 3.8 G per launch, profiles/r05_pmc_lds_bench.txt); an odd stride spreads them over all 32
+    const int WP = cb_fill_stride(W);
+    unsigned int* bg = fsm2;                    // [Y][WP]
+    unsigned int* rc = fsm2 + (size_t)Y * WP;   // [Y][WP]
     __shared__ int changed;
     const int tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.y * g.words + (size_t)blockIdx.x * Y * W;
@@ -218,8 +224,8 @@ __global__ __launch_bounds__(256) void k_bits_fill2d(const unsigned* __restrict_
         if (y == 0 || y == Y - 1) r = b;
         if (w == 0) r |= b & 1u;
         if (w == W - 1) r |= b & (1u << ((X - 1) & 31));
-        bg[idx] = b;
-        rc[idx] = r;
+        bg[y * WP + w] = b;
+        rc[y * WP + w] = r;
     }
     __syncthreads();
     for (;;) {
@@ -227,8 +233,8 @@ __global__ __launch_bounds__(256) void k_bits_fill2d(const unsigned* __restrict_
         __syncthreads();
         int ch = 0;
         for (int y = tid; y < Y; y += 256) {
-            unsigned int* rr = rc + y * W;
-            const unsigned int* bb = bg + y * W;
+            unsigned int* rr = rc + y * WP;
+            const unsigned int* bb = bg + y * WP;
             unsigned int carry = 0;
             for (int w = 0; w < W; ++w) {          // towards higher x (the carry ripples through every run that holds a seed)
                 const unsigned int b = bb[w];
@@ -250,11 +256,11 @@ __global__ __launch_bounds__(256) void k_bits_fill2d(const unsigned* __restrict_
         }
         __syncthreads();
         for (int idx = tid; idx < nw; idx += 256) {   // vertical step (each word has one writer; neighbours are only read)
-            const int y = idx / W;
-            const unsigned int r = rc[idx];
-            const unsigned int up = y > 0 ? rc[idx - W] : 0u, dn = y < Y - 1 ? rc[idx + W] : 0u;
-            const unsigned int nr = r | ((up | dn) & bg[idx]);
-            if (nr != r) { rc[idx] = nr; ch = 1; }
+            const int y = idx / W, li = idx + y * (WP - W);
+            const unsigned int r = rc[li];
+            const unsigned int up = y > 0 ? rc[li - WP] : 0u, dn = y < Y - 1 ? rc[li + WP] : 0u;
+            const unsigned int nr = r | ((up | dn) & bg[li]);
+            if (nr != r) { rc[li] = nr; ch = 1; }
         }
         if (ch) changed = 1;
         __syncthreads();
@@ -262,8 +268,8 @@ __global__ __launch_bounds__(256) void k_bits_fill2d(const unsigned* __restrict_
         __syncthreads();
     }
     for (int idx = tid; idx < nw; idx += 256) {
-        const int w = idx % W;
-        out[base + idx] = (~bg[idx] | (bg[idx] & ~rc[idx])) & cb_valid_word(X, w);   // foreground | holes
+        const int y = idx / W, w = idx - y * W, li = y * WP + w;
+        out[base + idx] = (~bg[li] | (bg[li] & ~rc[li])) & cb_valid_word(X, w);   // foreground | holes
     }
 }
 
@@ -850,7 +856,7 @@ extern "C" int boa_bits_erode_u8(boa_ctx* c, const uint8_t* dev_mask, uint8_t* d
 }
 
 // 1 when the slice fits the LDS flood (Y * W words twice), else 0 (the caller keeps the byte-mask path of boa_fill_holes_2d)
-extern "C" int boa_bits_fill_supported(int Y, int X) { return (size_t)Y * ((X + 31) / 32) * 8 <= 150 * 1024 ? 1 : 0; }
+extern "C" int boa_bits_fill_supported(int Y, int X) { return (size_t)Y * cb_fill_stride((X + 31) / 32) * 8 <= 150 * 1024 ? 1 : 0; }
 
 extern "C" int boa_bits_fill_holes_2d(boa_ctx* c, const uint32_t* dev_in, int Z, int Y, int X, int n_masks, uint32_t* dev_out) {
     BOA_REQUIRE(c && dev_in && dev_out && Z > 0 && Y > 0 && X > 0 && n_masks >= 1, "boa_bits_fill_holes_2d: bad argument");
@@ -859,7 +865,7 @@ extern "C" int boa_bits_fill_holes_2d(boa_ctx* c, const uint32_t* dev_in, int Z,
     static bool once = (hipFuncSetAttribute((const void*)k_bits_fill2d, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256), true);
     (void)once;
     KernelTimer t(c, BOA_K_MORPH, 0, 8.0 * (double)g.words * n_masks);
-    hipLaunchKernelGGL(k_bits_fill2d, dim3((unsigned)Z, (unsigned)n_masks), dim3(256), (size_t)Y * g.W * 8, c->stream, dev_in, g, dev_out);
+    hipLaunchKernelGGL(k_bits_fill2d, dim3((unsigned)Z, (unsigned)n_masks), dim3(256), (size_t)Y * cb_fill_stride(g.W) * 8, c->stream, dev_in, g, dev_out);
     t.stop();
     BOA_HIP_TRY(hipGetLastError());
     return BOA_OK;
