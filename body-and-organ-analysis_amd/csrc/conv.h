@@ -29,6 +29,7 @@ struct ConvTile {
     int w[3];        // wave M-tile shape, product 32
     int b[3];        // M-tiles per block along each axis, product 4R
     int h[3];        // input halo extents
+    int xs;          // LDS stride between the halo's x-planes in voxels (>= h[1] * h[2]; see choose_conv_tile)
     int tiles[3];    // block tiles per axis
     size_t lds_bytes;
 };
@@ -97,6 +98,7 @@ struct ConvArgs {
     int N, Di, Hi, Wi, Do, Ho, Wo, Cout;
     int k0, k1, k2, s0, s1, s2, p0, p1, p2;
     int w0, w1, w2, b0, b1, b2, h0, h1, h2, t0, t1, t2;
+    int xs;  // k_conv_ws / k_conv_ns: voxels between the halo's x-planes in LDS (h1 * h2, or padded: ConvTile::xs)
     int lw1, lw2, lb1, lb2;  // log2 of the (power-of-two) wave-tile / block-tile extents
     const __half* wpk;
     const float* bias;

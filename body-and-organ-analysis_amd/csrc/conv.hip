@@ -165,6 +165,15 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out, bool x3) {
                                 covered *= (long long)tl[d] * ext;
                                 tiles *= tl[d];
                             }
+                            // k_conv_ws, M-tiles that span several x-planes (w0 > 1, rows of w2 = 8 / 16 lanes: the 16^3 ... 4^3 layers):
+                            // lane row lx sits xs voxels = xs * 16 bytes behind row lx - 1, and with xs = h1 * h2 (180 / 100 at the 16^3 / 8^3
+                            // layers: = 64 bytes mod 256) the rows of a ds_read_b128 lane group overlapped on the banks -- 35 - 44 % of these
+                            // launches' LDS cycles were conflicts (profiles/r05_pmc_lds.txt).  The planes are padded to xs = w2 (mod 16): the
+                            // rows of every lane group then tile a 256-byte bank row.  HV below counts the padded planes.
+                            int xs = h[1] * h[2];
+                            if (variant == 1 && w0 > 1 && w1 == 1 && w2 >= 8 && w2 <= 16 && g.s[0] == 1 && g.s[2] == 1 && !getenv("BOA_WS_NO_XPAD"))
+                                while (xs % 16 != w2 % 16) ++xs;
+                            if (variant == 1) HV = (long long)h[0] * xs;
                             if (variant == 1 && !conv_ws_supported(g.k, (int)HV)) continue;
                             const size_t lds = variant == 1 ? conv_ws_lds_bytes((int)HV, taps, ncc, g.Cout)
                                                             : conv_lds_bytes((int)HV, taps);
@@ -190,7 +199,7 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out, bool x3) {
                                 const bool res = conv_ws_resident((int)HV, taps, ncc, g.Cout);
                                 // measured (s_memtime stamps, 32->32 @128^3): a 1360-voxel chunk costs the producers ~6500
                                 // cycles next to the consumers' MFMA stream -> ~4.3 cycles per halo voxel + fixed part
-                                const double t_prod = (double)HV * 4.3 + (res ? 0.0 : taps * 64.0 / 256.0 * 60.0) + 800.0;
+                                const double t_prod = (double)h[0] * h[1] * h[2] * 4.3 + (res ? 0.0 : taps * 64.0 / 256.0 * 60.0) + 800.0;   // (the halo's voxels, not the padded planes)
                                 t_chunk = std::max(t_mfma * 1.15, t_prod * (g.s[2] > 1 ? 1.0 : lds_pen)) + 500.0;
                             } else {
                                 const double items = (2.0 * HV + taps * 64.0) / 256.0;
@@ -213,6 +222,7 @@ bool choose_conv_tile(const ConvGeom& g, int cu_count, ConvTile* out, bool x3) {
                                     out->tiles[d] = tl[d];
                                 }
                                 out->lds_bytes = lds;
+                                out->xs = xs;
                             }
                         }
                 }
@@ -441,6 +451,7 @@ int launch_conv_mfma(boa_ctx* ctx, const ActSrc& s0, const ActSrc& s1, const Con
     a.p0 = (g.k[0] - 1) / 2; a.p1 = (g.k[1] - 1) / 2; a.p2 = (g.k[2] - 1) / 2;
     a.w0 = t.w[0]; a.w1 = t.w[1]; a.w2 = t.w[2]; a.b0 = t.b[0]; a.b1 = t.b[1]; a.b2 = t.b[2];
     a.h0 = t.h[0]; a.h1 = t.h[1]; a.h2 = t.h[2]; a.t0 = t.tiles[0]; a.t1 = t.tiles[1]; a.t2 = t.tiles[2];
+    a.xs = t.xs > 0 ? t.xs : t.h[1] * t.h[2];
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     a.lw1 = ilog2(t.w[1]); a.lw2 = ilog2(t.w[2]); a.lb1 = ilog2(t.b[1]); a.lb2 = ilog2(t.b[2]);
     a.wpk = wpk; a.bias = bias; a.out = out; a.partials = partials; a.slope = slope;
@@ -497,6 +508,7 @@ int launch_conv_x3(boa_ctx* ctx, const float* src0, const float* ss0, int C0, co
     a.p0 = (g.k[0] - 1) / 2; a.p1 = (g.k[1] - 1) / 2; a.p2 = (g.k[2] - 1) / 2;
     a.w0 = t.w[0]; a.w1 = t.w[1]; a.w2 = t.w[2]; a.b0 = t.b[0]; a.b1 = t.b[1]; a.b2 = t.b[2];
     a.h0 = t.h[0]; a.h1 = t.h[1]; a.h2 = t.h[2]; a.t0 = t.tiles[0]; a.t1 = t.tiles[1]; a.t2 = t.tiles[2];
+    a.xs = t.xs > 0 ? t.xs : t.h[1] * t.h[2];
     auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     a.lw1 = ilog2(t.w[1]); a.lw2 = ilog2(t.w[2]); a.lb1 = ilog2(t.b[1]); a.lb2 = ilog2(t.b[2]);
     a.wpk = wpk; a.bias = bias; a.out = (__half*)out; a.partials = partials; a.slope = slope;

@@ -242,7 +242,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ns(ConvArgs p, int dbg_arg,
         // without copies.  A/B on one box (tools/ab_layers.sh, batch 8): 64 -> 128 @64^3 -5 %, 128 -> 256 @32^3 -8 %, 256 -> 320 @16^3
         // -8 %; the 32 -> 64 layer at 128^3 (RM = 2: HBM-cold input, 3.6 TB/s of halo traffic) +16 % -- twice the loads in flight per
         // CU there only deepen the queue in front of the memory side -- so that instantiation keeps one set.
+#ifdef NS_PF2_ALL
+        constexpr bool PF2 = NS_PF2 != 0;   // (A/B builds)
+#else
         constexpr bool PF2 = NS_PF2 && RM == 4;
+#endif
         ChunkRegs rgA, rgB;
         auto clear_regs = [&](ChunkRegs& rg) {
 #pragma unroll
@@ -609,6 +613,7 @@ static int ns_wn(int Cout) { return Cout >= 128 ? 4 : 2; }
 
 void conv_ns_tile(const ConvGeom& g, ConvTile* t) {
     t->variant = 2;
+    t->xs = 0;   // (its own LDS layouts; ConvArgs::xs = h1 * h2 for the shared producer constants)
     t->R = 4;
     t->w[0] = 1; t->w[1] = 4; t->w[2] = 8;
     t->b[0] = 4; t->b[1] = 1; t->b[2] = 1;

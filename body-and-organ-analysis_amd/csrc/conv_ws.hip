@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void k_ws_build_desc(ConvArgs p, int grid, int 
 // [Wl | Wl] x [Xh ; Xl] -- all four cross terms of (Wh + Wl)(Xh + Xl) in fp32 accumulators.  Both k-halves of a lane pair read the
 // same weight fragment (hi at ap + tap KiB, lo 512 B behind it).
 template <int R, int K0, int K1, int K2, bool FIRST, bool X3>
-__device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R], const unsigned char* ap, int h1, int h2,
+__device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R], const unsigned char* ap, int xs, int h2,
                                               f32x16 (&acc)[R], const f32x16& c0) {
     // Software pipeline over the (compile-time) taps: the A/B fragments of tap t + WS_PF are read while the MFMAs of
     // tap t issue.  The sched_group_barrier sequence pins that order: [PF x (R+1) reads] then per tap
@@ -89,7 +89,7 @@ __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R
     constexpr int NRD = R + (X3 ? 2 : 1);   // LDS reads per tap
     auto fetch = [&](int tn, int slot) {
         const int dzn = tn % K2, dyn = (tn / K2) % K1, dxn = tn / (K2 * K1);
-        const int off = ((dxn * h1 + dyn) * h2 + dzn) * 16;
+        const int off = (dxn * xs + dyn * h2 + dzn) * 16;   // (xs: voxels between x-planes, ConvTile::xs)
         a[slot] = *(const f16x8*)(ap + tn * 1024);
         if constexpr (X3) al[slot] = *(const f16x8*)(ap + tn * 1024 + 512);
 #pragma unroll
@@ -128,7 +128,7 @@ __device__ __forceinline__ void consume_chunk(const unsigned char* const (&bp)[R
 // The per-tap form asks the LDS for 160 B/clk per CU at the full MFMA rate with R = 4 (4 waves x 5 KiB per 4 MFMAs of
 // 32 clk), more than the 128 B/clk it has; this form needs 96 B/clk.
 template <int R, int K0, int K2, bool FIRST, bool X3>
-__device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const unsigned char* ap, int h1, int h2,
+__device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const unsigned char* ap, int xs, int h2,
                                                 f32x16 (&acc)[R], const f32x16& c0) {
     // MFMAs run in input-row order (row j feeds the pairs r + dy = j), so row j's registers are dead after its last
     // MFMA and take the same row of the next (dx, dz) group straight away: one set of R + 2 row fragments streams
@@ -150,7 +150,7 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
     };
     auto fetch_b = [&](int g, int jj) {
         const int dz = g % K2, dx = g / K2;
-        b[jj] = *(const f16x8*)(b0p + ((dx * h1 + jj) * h2 + dz) * 16);
+        b[jj] = *(const f16x8*)(b0p + (dx * xs + jj * h2 + dz) * 16);
     };
     fetch_a(0, 0);
 #pragma unroll
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
     const int l31 = lane & 31;
     const int kh = lane >> 5;
     constexpr int taps = K0 * K1 * K2;
-    const int HV = p.h0 * p.h1 * p.h2;
+    const int HV = p.h0 * p.xs;   // LDS slots of one k-half plane (x-planes xs voxels apart, xs >= h1 * h2)
     const int plane = ws_plane_bytes(HV);
     const int ncc = (p.C0 + p.C1) / 16;
     // LDS map.  resident: [all weights: ncc * taps KiB][halo buf 0][halo buf 1]
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
             const int my = (m >> p.lb2) & (p.b1 - 1);
             const int mx = m >> (p.lb2 + p.lb1);
             const int tx = mx * p.w0 + lx, ty = my * p.w1 + ly, tz = mz * p.w2 + lz;
-            hoff[r] = (((tx * p.s0) * p.h1 + ty * p.s1) * p.h2 + tz * p.s2) * 16 + kh * plane;
+            hoff[r] = ((tx * p.s0) * p.xs + (ty * p.s1) * p.h2 + tz * p.s2) * 16 + kh * plane;
         }
     }
     // epilogue constants: output voxel index relative to the tile origin = srel0 (this lane's voxel l31 within an
@@ -725,18 +725,18 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                     }
                 }
                 if constexpr (YR)
-                    consume_chunk_y<R, K0, K2, false, X3>(bp[0], ap, p.h1, p.h2, acc, biasv);
+                    consume_chunk_y<R, K0, K2, false, X3>(bp[0], ap, p.xs, p.h2, acc, biasv);
                 else
-                    consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.h1, p.h2, acc, biasv);
+                    consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.xs, p.h2, acc, biasv);
             } else if constexpr (YR) {
                 if (cc == 0)
-                    consume_chunk_y<R, K0, K2, true, X3>(bp[0], ap, p.h1, p.h2, acc, biasv);
+                    consume_chunk_y<R, K0, K2, true, X3>(bp[0], ap, p.xs, p.h2, acc, biasv);
                 else
-                    consume_chunk_y<R, K0, K2, false, X3>(bp[0], ap, p.h1, p.h2, acc, biasv);
+                    consume_chunk_y<R, K0, K2, false, X3>(bp[0], ap, p.xs, p.h2, acc, biasv);
             } else if (cc == 0)
-                consume_chunk<R, K0, K1, K2, true, X3>(bp, ap, p.h1, p.h2, acc, biasv);
+                consume_chunk<R, K0, K1, K2, true, X3>(bp, ap, p.xs, p.h2, acc, biasv);
             else
-                consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.h1, p.h2, acc, biasv);
+                consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.xs, p.h2, acc, biasv);
             WS_STAMP(5);
 #if !WS_DEFER_EPILOGUE
             if (cc == ncc - 1 && !(dbg & 8)) epilogue(tc, cd.flags, cd.vo, true);
@@ -874,7 +874,7 @@ const int* ws_run_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, i
 // device by k_ws_build_desc and kept for the context's lifetime (8 samples of the 128^3 layers: 32 768 tiles = 1 MiB).
 const int* ws_desc_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, int grid, int* row_out) {
     std::vector<int> key = {-1,   a.t0, a.t1, a.t2, a.b0, a.b1, a.b2, a.w0, a.w1, a.w2, a.Cout, a.cy_fast, a.vw, a.ncy, a.N,  grid,
-                            a.Do, a.Ho, a.Wo, a.Di, a.Hi, a.Wi, a.s0, a.s1, a.s2, a.p0, a.p1,   a.p2,      a.h0, a.h1,  a.h2};
+                            a.Do, a.Ho, a.Wo, a.Di, a.Hi, a.Wi, a.s0, a.s1, a.s2, a.p0, a.p1,   a.p2,      a.h0, a.h1,  a.h2, a.xs};
     // rows: an upper bound of a workgroup's tiles.  A run has at most tiles_per_sample / vw + 2 tiles (ws_run_table: the 8 XCD ranges
     // differ by one tile, the runs inside a range by one more) and a workgroup executes ceil(N vw / grid) runs.  The tables live as long
     // as the context (one per layer geometry, batch and grid: the tail batches of a volume add a few; <= ~150 MB for every batch size
@@ -898,7 +898,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     const int vw = conv_ws_vw(total, ctx->cu_count);
     const int grid = (int)std::min<long long>((long long)vw * a0.N, ctx->cu_count);
     const int taps = a0.k0 * a0.k1 * a0.k2;
-    const int HV = t.h[0] * t.h[1] * t.h[2];
+    const int HV = t.h[0] * (t.xs > 0 ? t.xs : t.h[1] * t.h[2]);
     const int resident = conv_ws_resident(HV, taps, (a0.C0 + a0.C1) / 16, a0.Cout) ? 1 : 0;
     BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi <= 16777216.0 && std::max(a0.C0, a0.C1) * 2 < 16777216,
                 "conv_ws: more than 2^24 input voxels per sample (24-bit offset multiply)");

@@ -227,10 +227,11 @@ __device__ __forceinline__ ProdConst prod_const(const ConvArgs& p, int q, int HV
     for (int f = 0; f < 6; ++f) k.face[f] = 0;
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
+        // (LDS index v = hx * xs + hy * h2 + hz; xs >= h1 * h2: the slots of a padded plane's tail belong to no halo voxel)
         const int v = (q >> 1) + (WS_PROD / 2) * j;
-        const int hz = v % p.h2, t = v / p.h2;
-        const int hy = t % p.h1, hx = t / p.h1;
-        const bool in = v < HV;
+        const int hx = v / p.xs, rem = v - hx * p.xs;
+        const int hz = rem % p.h2, hy = rem / p.h2;
+        const bool in = v < HV && hy < p.h1;
         k.rel[j] = in ? (hx * p.Hi + hy) * p.Wi + hz : 0;
         k.hc[j] = in ? (hx | (hy << 10) | (hz << 20)) : 0;
         const unsigned bit = in ? (1u << j) : 0u;
@@ -423,7 +424,7 @@ __device__ __forceinline__ void prod_issue(const ConvArgs& p, const TileCoord& t
     // instead of 64 cycles per load instruction), the scalar-base form is not.
     const unsigned char* sbase = (const unsigned char*)base;
     const unsigned lane_off = (unsigned)(q & 1) * 16u;
-    const int nrounds = (p.h0 * p.h1 * p.h2 + WS_PROD / 2 - 1) / (WS_PROD / 2);  // rounds that carry halo voxels (wave-uniform)
+    const int nrounds = (p.h0 * p.xs + WS_PROD / 2 - 1) / (WS_PROD / 2);  // rounds that carry halo voxels (wave-uniform)
 #pragma unroll
     for (int j = 0; j < WS_MAXV; ++j) {
         // no per-lane test: voxels beyond the halo / outside the tensor have gi == 0 (a valid address, data discarded)
