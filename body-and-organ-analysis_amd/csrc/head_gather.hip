@@ -51,6 +51,22 @@ struct GatherArgs {
     unsigned char lut[256];
 };
 
+// fp16 += fp32 on a packed pair, as ONE pair: two conversions up (the second an SDWA form), one v_pk_add_f32, one v_cvt_pk_f16_f32 (RTNE) --
+// the same fp32 additions and roundings as f2us(us2f(lo) + x) | f2us(us2f(hi) + y) << 16.  Written with shifts and masks hipcc paired the
+// LOW halves of two neighbouring accumulator words (and the high halves) for its packed adds and paid three v_mov, a v_and, a v_lshl and two
+// v_or_sdwa per four values to get the products and the results back into place: 19 instead of 12 instructions per four classes.
+__device__ __forceinline__ unsigned gh_acc_add(unsigned acc, float x, float y) {
+    typedef float ghp2_t __attribute__((ext_vector_type(2)));
+    union {
+        unsigned u;
+        gh2_t v;
+    } a, r;
+    a.u = acc;
+    const ghp2_t s = ghp2_t{(float)a.v[0], (float)a.v[1]} + ghp2_t{x, y};
+    r.v = __builtin_convertvector(s, gh2_t);
+    return r.u;
+}
+
 // fp32 (scale, shift) [tile][32][2] -> the packed layout the head reads: [tile][kh][step 0: sc x4, sh x4 | step 1: sc x4, sh x4]
 __global__ void k_pack_head_ss(const float* __restrict__ ss, unsigned* __restrict__ out, int n_tiles) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,8 +297,7 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
                     for (int i = 0; i < 8; ++i) {
                         const gf2_t sum = gf2_t{d[2 * i], d[2 * i + 1]} + gf2_t{s_bz[kh][2 * i], s_bz[kh][2 * i + 1]};
                         const gf2_t pr = GAUSS ? sum * gf2_t{g, g} : sum;
-                        const float a0_ = us2f((unsigned short)(acch[i] & 0xFFFFu)), a1_ = us2f((unsigned short)(acch[i] >> 16));
-                        acch[i] = (unsigned)f2us(a0_ + pr.x) | ((unsigned)f2us(a1_ + pr.y) << 16);
+                        acch[i] = gh_acc_add(acch[i], pr.x, pr.y);
                     }
                     nacc = us2f(f2us(nacc + g));
                 }
@@ -404,8 +419,7 @@ __device__ __forceinline__ void gather_head_body(const GatherArgs& p) {
                             // kernel is latency-bound and wants waves, not fewer instructions).  v_fma_mix{lo,hi}_f16 with a multiplier of
                             // 1.0 would do add + conversion in one instruction but is NOT the same arithmetic in rare cases (8 of 134 M
                             // voxels of a 512^3 part model came out with another label than the scatter form: tests/test_gpu_fullsize.py)
-                            const float a0 = us2f((unsigned short)(acch[i] & 0xFFFFu)), a1 = us2f((unsigned short)(acch[i] >> 16));
-                            acch[i] = (unsigned)f2us(a0 + pr.x) | ((unsigned)f2us(a1 + pr.y) << 16);
+                            acch[i] = gh_acc_add(acch[i], pr.x, pr.y);
                         }
                         nacc = us2f(f2us(nacc + g));
                     }
