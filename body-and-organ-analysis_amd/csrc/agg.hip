@@ -260,7 +260,7 @@ extern "C" int boa_tissue_projections(boa_ctx* c, const uint8_t* dev_tissues, co
 // the key is "not measured".
 // Table size: 2^LOG2 entries of {key, count}.  LOG2 = 14 (128 KiB) leaves ONE workgroup (4 waves) per CU -- the voxel loads of an
 // iteration are then a chain of exposed HBM round trips; LOG2 = 12 (32 KiB) lets four workgroups share a CU and still holds the
-// distinct (label, HU) keys of a contiguous voxel range of compact organs between flushes.
+// distinct (label, HU) keys of a contiguous voxel range of compact organs between flushes; LOG2 = 13 (two workgroups) is the default.
 #define HIST_EMPTY 0xFFFFFFFFu
 
 template <int LOG2>
@@ -419,8 +419,11 @@ extern "C" int boa_label_hu_histogram(boa_ctx* c, const int16_t* dev_ct, const u
     if (head > n) head = n;
     const bool together = (((uintptr_t)dev_ct + 2 * head) & 15) == 0 && (!dev_mask || (((uintptr_t)dev_mask + head) & 15) == 0);
     // contiguous voxel ranges per workgroup (few labels each): ~4 workgroups per CU, at least one 4 096-voxel iteration
-    static const int hist_log2 = getenv("BOA_HIST_LOG2") ? atoi(getenv("BOA_HIST_LOG2")) : 12;
-    static const int hist_wg = getenv("BOA_HIST_WG") ? atoi(getenv("BOA_HIST_WG")) : (hist_log2 == 14 ? 4 : 16);   // workgroups per CU
+    // table size / workgroups per CU, kernel time in us (tools/hist_sweep.sh, tools/hist_bench.sh; 512^3):   structured phantom | bench labels (noise-like)
+    //   2^14, 4:  845 | 947      2^13, 8:  679 | 1 124      2^12, 8:  571 | 1 905      2^12, 16:  650 | 2 056
+    // compact organs want occupancy, salt-and-pepper labels a table that merges more duplicates before it spills: 2^13 is the default
+    static const int hist_log2 = getenv("BOA_HIST_LOG2") ? atoi(getenv("BOA_HIST_LOG2")) : 13;
+    static const int hist_wg = getenv("BOA_HIST_WG") ? atoi(getenv("BOA_HIST_WG")) : (hist_log2 == 14 ? 4 : 8);   // workgroups per CU
     const size_t iters = ((n - head) / 16 + 255) / 256;
     const size_t gpb = std::max<size_t>(1, (iters + (size_t)c->cu_count * hist_wg - 1) / ((size_t)c->cu_count * hist_wg));
     const int grid = (int)std::max<size_t>(1, (iters + gpb - 1) / gpb);
@@ -430,6 +433,9 @@ extern "C" int boa_label_hu_histogram(boa_ctx* c, const int16_t* dev_ct, const u
         (void)once;
         if (hist_log2 == 14)
             hipLaunchKernelGGL(k_label_hist<14>, dim3(grid), dim3(256), (size_t)8 << 14, c->stream, dev_ct, dev_labels, dev_mask, n,
+                               head, hu_min, nbins, dev_hist, gpb);
+        else if (hist_log2 == 13)
+            hipLaunchKernelGGL(k_label_hist<13>, dim3(grid), dim3(256), (size_t)8 << 13, c->stream, dev_ct, dev_labels, dev_mask, n,
                                head, hu_min, nbins, dev_hist, gpb);
         else
             hipLaunchKernelGGL(k_label_hist<12>, dim3(grid), dim3(256), (size_t)8 << 12, c->stream, dev_ct, dev_labels, dev_mask, n,
