@@ -10,7 +10,8 @@ OBJ=/tmp/boa_alt_$NAME; mkdir -p $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I$PKG/../include -I$PKG/csrc -Wno-unused-result -Wno-unused-value -Wno-pass-failed $*"
 for f in $PKG/csrc/*.hip; do
   o=$OBJ/$(basename ${f%.hip}).o
-  if [ ! -f $o ] || [ $f -nt $o ] || [ "$(cat $OBJ/.flags 2>/dev/null)" != "$*" ]; then /opt/rocm/bin/hipcc $FLAGS -c $f -o $o & fi
+  hdr_new=0; for h in $PKG/csrc/*.h $PKG/../include/*.h; do [ -f $o ] && [ $h -nt $o ] && hdr_new=1; done   # (a changed header rebuilds everything: a stale object with an old struct layout links fine and runs wrong)
+  if [ ! -f $o ] || [ $f -nt $o ] || [ $hdr_new = 1 ] || [ "$(cat $OBJ/.flags 2>/dev/null)" != "$*" ]; then /opt/rocm/bin/hipcc $FLAGS -c $f -o $o & fi
 done
 wait
 echo "$*" > $OBJ/.flags
