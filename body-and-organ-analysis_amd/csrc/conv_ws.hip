@@ -201,6 +201,110 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
     }
 }
 
+// Split-precision form of the row-reuse loop with TAP PAIRS (round 6): 3 MFMAs per two taps instead of 4.
+// A product (Wh + Wl)(Xh + Xl) needs Wh Xh + Wh Xl + Wl Xh (Wl Xl is 2^-22 of the product: below the fp32 rounding of the sum) = three
+// K-halves of 8 channels per tap.  The two (dx, dz) groups g0, g1 of a pair share their three MFMAs per (row, dy):
+//   [Wh(g0) | Wh(g1)] x [Xh(g0) ; Xh(g1)]  +  [Wh(g0) | Wh(g1)] x [Xl(g0) ; Xl(g1)]  +  [Wl(g0) | Wl(g1)] x [Xh(g0) ; Xh(g1)]
+// Every operand is ONE ds_read_b128 whose address depends on the lane's k-half: the kh = 1 lanes read the same plane at group g1's tap
+// offset (B: the (dx, dz) shift of the halo voxel; A: the tap's KiB of the weight buffer) -- no register shuffles, no second resident
+// chunk.  Per two groups: 12 row fragments + 6 weight fragments (18 KiB of LDS reads, 24 before) feed 9 R MFMAs (12 R before).  An odd
+// last group runs in the old form ([Wh | Wh], [Wl | Wl] x [Xh ; Xl], which also carries its Wl Xl).
+template <int R, int K0, int K2>
+__device__ __forceinline__ void consume_chunk_y_x3(const unsigned char* b0p, const unsigned char* ap, int xs, int h2, int plane, int kh,
+                                                   f32x16 (&acc)[R]) {
+    constexpr int G = K0 * K2;
+    constexpr int NP = G / 2;          // pairs of groups
+    constexpr int NU = NP + (G & 1);   // units: NP pairs + the single last group
+    constexpr int NB = R + 2;
+    f16x8 ah[2][3], al[2][3];
+    f16x8 fh[NB], fl[NB];
+    const unsigned char* bhi = b0p - kh * plane;   // the hi plane for both k-halves (b0p points at this lane's own plane)
+    auto gtap = [](int g, int dy) { return (((g / K2) * 3 + dy) * K2 + (g % K2)) * 1024; };
+    auto fetch_a = [&](int u, int slot) {
+        if (u < NP) {
+            const int g0 = 2 * u, g1 = g0 + 1;
+            const unsigned char* a0 = ap + kh * (gtap(g1, 0) - gtap(g0, 0));   // (the difference does not depend on dy)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                ah[slot][dy] = *(const f16x8*)(a0 + gtap(g0, dy));
+                al[slot][dy] = *(const f16x8*)(a0 + gtap(g0, dy) + 512);
+            }
+        } else {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                ah[slot][dy] = *(const f16x8*)(ap + gtap(G - 1, dy));
+                al[slot][dy] = *(const f16x8*)(ap + gtap(G - 1, dy) + 512);
+            }
+        }
+    };
+    auto fetch_b = [&](int u, int jj) {
+        if (u < NP) {
+            const int g0 = 2 * u, g1 = g0 + 1;
+            const int o0 = ((g0 / K2) * xs + (g0 % K2)) * 16, o1 = ((g1 / K2) * xs + (g1 % K2)) * 16;
+            const unsigned char* q = bhi + (kh ? o1 : o0) + jj * h2 * 16;
+            fh[jj] = *(const f16x8*)q;
+            fl[jj] = *(const f16x8*)(q + plane);
+        } else {
+            fh[jj] = *(const f16x8*)(b0p + (((G - 1) / K2) * xs + jj * h2 + ((G - 1) % K2)) * 16);
+        }
+    };
+    constexpr int NA = 6;
+    fetch_a(0, 0);
+#pragma unroll
+    for (int jj = 0; jj < NB; ++jj) fetch_b(0, jj);
+    __builtin_amdgcn_sched_group_barrier(0x100, NA + (NP > 0 ? 2 : 1) * NB, 0);
+#define X3_MFMA_GROUP(n) do { if (pair) __builtin_amdgcn_sched_group_barrier(0x008, 3 * (n), 0); else __builtin_amdgcn_sched_group_barrier(0x008, 2 * (n), 0); } while (0)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int cb = u & 1;
+        const bool pair = u < NP;
+        if (u + 1 < NU) {
+            fetch_a(u + 1, cb ^ 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj) {
+            int cnt = 0;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = jj - dy;
+                if (r < 0 || r >= R) continue;
+                ++cnt;
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][dy], fh[jj], acc[r], 0, 0, 0);
+            }
+            if (pair) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int r = jj - dy;
+                    if (r < 0 || r >= R) continue;
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][dy], fl[jj], acc[r], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = jj - dy;
+                if (r < 0 || r >= R) continue;
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][dy], fh[jj], acc[r], 0, 0, 0);
+            }
+            if (jj == 0 || jj == NB - 1)
+                X3_MFMA_GROUP(1);
+            else if (jj == 1 || jj == NB - 2)
+                X3_MFMA_GROUP(R >= 2 ? 2 : 1);
+            else
+                X3_MFMA_GROUP(3);
+            (void)cnt;
+            if (u + 1 < NU) {
+                fetch_b(u + 1, jj);
+                if (u + 1 < NP)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    }
+#undef X3_MFMA_GROUP
+}
+
 // X3 = split-precision mode (boa_net precision 2, the label-contract mode): activations are fp32 in OCTET planes
 // [N][C/8][voxel][8 floats] -- byte for byte the geometry of the fp16 chunk planes, so p.C0 / p.C1 count 2-byte units (2 x the real
 // channels), p.src* / p.ss16_* point at fp32 data and everything that only moves bytes (tile walk, halo addressing, weight DMA) is
@@ -724,9 +828,13 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
                         }
                     }
                 }
-                if constexpr (YR)
+                if constexpr (YR) {
+#ifdef WS_X3_UNPAIRED   // (A/B: the round-4 form, 4 MFMAs per two taps)
                     consume_chunk_y<R, K0, K2, false, X3>(bp[0], ap, p.xs, p.h2, acc, biasv);
-                else
+#else
+                    consume_chunk_y_x3<R, K0, K2>(bp[0], ap, p.xs, p.h2, plane, kh, acc);
+#endif
+                } else
                     consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.xs, p.h2, acc, biasv);
             } else if constexpr (YR) {
                 if (cc == 0)
