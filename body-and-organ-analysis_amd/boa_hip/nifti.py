@@ -266,11 +266,43 @@ def write_gzip_members(f, payload, compresslevel: int = 1, threads: int = 1, blo
             f.write(part)
 
 
+def quatern_from_affine(affine: np.ndarray) -> Tuple[Tuple[float, float, float], Tuple[float, float, float], float]:
+    """(quatern b c d, qoffset, qfac) of an affine whose 3 x 3 part is rotation x positive zooms (x an optional flip of the third
+    axis): the NIfTI-1.1 standard's matrix -> quaternion recipe (`nifti_mat44_to_quatern`), the inverse of `_qform`."""
+    A = np.asarray(affine, dtype=np.float64)
+    R = A[:3, :3] / np.sqrt(np.sum(A[:3, :3] ** 2, axis=0))[None, :]
+    qfac = 1.0
+    if np.linalg.det(R) < 0:
+        R = R.copy()
+        R[:, 2] = -R[:, 2]
+        qfac = -1.0
+    r11, r12, r13, r21, r22, r23, r31, r32, r33 = R.reshape(-1)
+    a = r11 + r22 + r33 + 1.0
+    if a > 0.5:
+        a = 0.5 * np.sqrt(a)
+        b, c, d = 0.25 * (r32 - r23) / a, 0.25 * (r13 - r31) / a, 0.25 * (r21 - r12) / a
+    else:
+        xd, yd, zd = 1.0 + r11 - (r22 + r33), 1.0 + r22 - (r11 + r33), 1.0 + r33 - (r11 + r22)
+        if xd > 1.0:
+            b = 0.5 * np.sqrt(xd)
+            c, d, a = 0.25 * (r12 + r21) / b, 0.25 * (r13 + r31) / b, 0.25 * (r32 - r23) / b
+        elif yd > 1.0:
+            c = 0.5 * np.sqrt(yd)
+            b, d, a = 0.25 * (r12 + r21) / c, 0.25 * (r23 + r32) / c, 0.25 * (r13 - r31) / c
+        else:
+            d = 0.5 * np.sqrt(zd)
+            b, c, a = 0.25 * (r13 + r31) / d, 0.25 * (r23 + r32) / d, 0.25 * (r21 - r12) / d
+        if a < 0.0:
+            b, c, d = -b, -c, -d
+    return (float(b), float(c), float(d)), tuple(float(x) for x in A[:3, 3]), qfac
+
+
 def save(path, data: np.ndarray, affine: np.ndarray, like: Optional[NiftiHeader] = None,
-         extensions: Optional[List[Tuple[int, bytes]]] = None, compresslevel: int = 1, threads: Optional[int] = None):
+         extensions: Optional[List[Tuple[int, bytes]]] = None, compresslevel: int = 1, threads: Optional[int] = None,
+         form_codes: Optional[Tuple[int, int]] = None):
     """Write `data` (file axis order); `.gz` paths are deflated on `threads` cores (default SAVE_THREADS).  `like`: header to copy (pixdim units, descrip, q/s-form codes ... as
     `img_in_orig.header.copy()` keeps them); datatype/bitpix/dim/vox_offset and the affine fields are set from the
-    arguments; scl_slope/inter are reset (label volumes are stored unscaled)."""
+    arguments; scl_slope/inter are reset (label volumes are stored unscaled).  `form_codes`: also store the affine as a qform."""
     data = np.asarray(data)
     if data.dtype not in _DT_INV:
         raise TypeError(f"unsupported dtype {data.dtype}")
@@ -290,6 +322,12 @@ def save(path, data: np.ndarray, affine: np.ndarray, like: Optional[NiftiHeader]
     v[52:64] = [float(x) for x in affine[:3, :].reshape(-1)]
     if like is not None and like.sform_code == 0:
         v[45] = 2
+    if form_codes is not None:                 # (qform_code, sform_code) with the quaternion of `affine` (what ITK's NIfTI writer stores)
+        quat, qoff, qfac = quatern_from_affine(affine)
+        v[44], v[45] = int(form_codes[0]), int(form_codes[1])
+        v[46:49] = list(quat)
+        v[49:52] = list(qoff)
+        v[22] = qfac
     exts = list(extensions or [])
     ext_blob = b""
     for ecode, content in exts:
