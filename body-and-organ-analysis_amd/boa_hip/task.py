@@ -131,18 +131,22 @@ class SegmentationTask:
                 vol.free()
             vol = self._work["vol"] = ctx.alloc(n * 4)
         d_labels.zero()
-        if self.model_shard is not None and self.model_shard.world > 1 and self.multimodel:
-            return self._predict_zyx_model_sharded(d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx)
-        if self.shard is not None and self.shard.comm.world > 1 and self.multimodel and len(self.parts) > 1 and self._units_applicable(shape, spacing_zyx):
-            return self._predict_zyx_unit_sharded(d_ct, shape, d_labels, in_dtype, n)
+        # The predictors of this task take their inf-flag slots from the ring in `self._work` (predictor.py discovers it there), so EVERY
+        # path below owns it: reset before the first model, one read after the last (a path that skipped the check would drop the
+        # reference's "Encountered inf in predicted array" error and let unchecked slots pile up -- ADVICE r5).
         ring = self._work.get("flag_ring")
         if ring is None:
             from .device import FlagRing
             ring = self._work["flag_ring"] = FlagRing(ctx)
         ring.reset()
-        for k in range(len(self.parts)):
-            self._run_model(k, d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx, merge=self.multimodel, shard=self.shard)
-        ring.check()   # the models' inf flags, one read per volume
+        if self.model_shard is not None and self.model_shard.world > 1 and self.multimodel:
+            self._predict_zyx_model_sharded(d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx)
+        elif self.shard is not None and self.shard.comm.world > 1 and self.multimodel and len(self.parts) > 1 and self._units_applicable(shape, spacing_zyx):
+            self._predict_zyx_unit_sharded(d_ct, shape, d_labels, in_dtype, n)
+        else:
+            for k in range(len(self.parts)):
+                self._run_model(k, d_ct, shape, d_labels, in_dtype, vol, n, spacing_zyx, merge=self.multimodel, shard=self.shard)
+        ring.check()   # the models' inf flags of this rank, one read per volume
 
     # ---- (row x model) units: all ranks busy on one multi-model volume ---------------------------------------------------------
     def _units_applicable(self, shape, spacing_zyx) -> bool:

@@ -207,19 +207,22 @@ __device__ __forceinline__ void consume_chunk_y(const unsigned char* b0p, const 
 //   [Wh(g0) | Wh(g1)] x [Xh(g0) ; Xh(g1)]  +  [Wh(g0) | Wh(g1)] x [Xl(g0) ; Xl(g1)]  +  [Wl(g0) | Wl(g1)] x [Xh(g0) ; Xh(g1)]
 // Every operand is ONE ds_read_b128 whose address depends on the lane's k-half: the kh = 1 lanes read the same plane at group g1's tap
 // offset (B: the (dx, dz) shift of the halo voxel; A: the tap's KiB of the weight buffer) -- no register shuffles, no second resident
-// chunk.  Per two groups: 12 row fragments + 6 weight fragments (18 KiB of LDS reads, 24 before) feed 9 R MFMAs (12 R before).  An odd
-// last group runs in the old form ([Wh | Wh], [Wl | Wl] x [Xh ; Xl], which also carries its Wl Xl).
+// chunk.  Per two groups: 12 row fragments + 6 weight fragments (18 KiB of LDS reads, 24 before) feed 9 R MFMAs (12 R before).
+// The odd last group pairs its dy = 0 / 1 taps the same way (the kh = 1 lanes read the NEXT input row: R fragment pairs
+// [Xh_r ; Xh_r+1], [Xl_r ; Xl_r+1]) and runs dy = 2 in the old form ([Wh | Wh], [Wl | Wl] x [Xh ; Xl], which also carries its Wl Xl):
+// 5 R MFMAs instead of 6 R.  Per chunk of 27 taps: 41 R MFMAs (54 R in the round-4 form; 40.5 R is the floor of a 3-term product).
 template <int R, int K0, int K2>
 __device__ __forceinline__ void consume_chunk_y_x3(const unsigned char* b0p, const unsigned char* ap, int xs, int h2, int plane, int kh,
                                                    f32x16 (&acc)[R]) {
     constexpr int G = K0 * K2;
     constexpr int NP = G / 2;          // pairs of groups
-    constexpr int NU = NP + (G & 1);   // units: NP pairs + the single last group
     constexpr int NB = R + 2;
+    static_assert((G & 1) == 1 && NP >= 1 && R >= 2 && R <= 4, "consume_chunk_y_x3: 3 or 9 groups, 2 .. 4 rows per wave");
     f16x8 ah[2][3], al[2][3];
     f16x8 fh[NB], fl[NB];
     const unsigned char* bhi = b0p - kh * plane;   // the hi plane for both k-halves (b0p points at this lane's own plane)
     auto gtap = [](int g, int dy) { return (((g / K2) * 3 + dy) * K2 + (g % K2)) * 1024; };
+    constexpr int GL = G - 1;                      // the single last group
     auto fetch_a = [&](int u, int slot) {
         if (u < NP) {
             const int g0 = 2 * u, g1 = g0 + 1;
@@ -229,56 +232,63 @@ __device__ __forceinline__ void consume_chunk_y_x3(const unsigned char* b0p, con
                 ah[slot][dy] = *(const f16x8*)(a0 + gtap(g0, dy));
                 al[slot][dy] = *(const f16x8*)(a0 + gtap(g0, dy) + 512);
             }
-        } else {
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                ah[slot][dy] = *(const f16x8*)(ap + gtap(G - 1, dy));
-                al[slot][dy] = *(const f16x8*)(ap + gtap(G - 1, dy) + 512);
-            }
+        } else {   // slot entries 0: the (dy 0 | dy 1) pair, 2: dy 2 for both k-halves
+            const unsigned char* a0 = ap + kh * (gtap(GL, 1) - gtap(GL, 0));
+            ah[slot][0] = *(const f16x8*)(a0 + gtap(GL, 0));
+            al[slot][0] = *(const f16x8*)(a0 + gtap(GL, 0) + 512);
+            ah[slot][2] = *(const f16x8*)(ap + gtap(GL, 2));
+            al[slot][2] = *(const f16x8*)(ap + gtap(GL, 2) + 512);
         }
     };
+    // row fragments of pair u: fh[jj] / fl[jj] = hi / lo plane of input row jj at (g0 | g1)
     auto fetch_b = [&](int u, int jj) {
-        if (u < NP) {
-            const int g0 = 2 * u, g1 = g0 + 1;
-            const int o0 = ((g0 / K2) * xs + (g0 % K2)) * 16, o1 = ((g1 / K2) * xs + (g1 % K2)) * 16;
-            const unsigned char* q = bhi + (kh ? o1 : o0) + jj * h2 * 16;
+        const int g0 = 2 * u, g1 = g0 + 1;
+        const int o0 = ((g0 / K2) * xs + (g0 % K2)) * 16, o1 = ((g1 / K2) * xs + (g1 % K2)) * 16;
+        const unsigned char* q = bhi + (kh ? o1 : o0) + jj * h2 * 16;
+        fh[jj] = *(const f16x8*)q;
+        fl[jj] = *(const f16x8*)(q + plane);
+    };
+    // row fragments of the last group, two per call (jj = the pair row whose registers have just been freed):
+    //   jj < R: fh[jj] / fl[jj] = [X_jj ; X_jj+1] of the hi / lo plane (the dy 0 | dy 1 pair of output row jj)
+    //   jj >= R: input rows 2 + 2 (jj - R), + 1 in the [Xh ; Xl] form -> fh[jj], fl[jj] (dy 2 of output rows 2 (jj - R), + 1)
+    auto single_rows = [](int jj) { return jj < R ? 2 : (2 * (jj - R) + 1 < R ? 2 : (2 * (jj - R) < R ? 1 : 0)); };
+    auto fetch_s = [&](int jj) {
+        const int o = ((GL / K2) * xs + (GL % K2)) * 16;
+        if (jj < R) {
+            const unsigned char* q = bhi + o + (jj + kh) * h2 * 16;
             fh[jj] = *(const f16x8*)q;
             fl[jj] = *(const f16x8*)(q + plane);
         } else {
-            fh[jj] = *(const f16x8*)(b0p + (((G - 1) / K2) * xs + jj * h2 + ((G - 1) % K2)) * 16);
+            const int i = 2 * (jj - R);
+            if (i < R) fh[jj] = *(const f16x8*)(b0p + o + (i + 2) * h2 * 16);
+            if (i + 1 < R) fl[jj] = *(const f16x8*)(b0p + o + (i + 3) * h2 * 16);
         }
     };
-    constexpr int NA = 6;
     fetch_a(0, 0);
 #pragma unroll
     for (int jj = 0; jj < NB; ++jj) fetch_b(0, jj);
-    __builtin_amdgcn_sched_group_barrier(0x100, NA + (NP > 0 ? 2 : 1) * NB, 0);
-#define X3_MFMA_GROUP(n) do { if (pair) __builtin_amdgcn_sched_group_barrier(0x008, 3 * (n), 0); else __builtin_amdgcn_sched_group_barrier(0x008, 2 * (n), 0); } while (0)
+    __builtin_amdgcn_sched_group_barrier(0x100, 6 + 2 * NB, 0);
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int u = 0; u < NP; ++u) {
         const int cb = u & 1;
-        const bool pair = u < NP;
-        if (u + 1 < NU) {
-            fetch_a(u + 1, cb ^ 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
-        }
+        fetch_a(u + 1, cb ^ 1);
+        if (u + 1 < NP)
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        else
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
         for (int jj = 0; jj < NB; ++jj) {
-            int cnt = 0;
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int r = jj - dy;
                 if (r < 0 || r >= R) continue;
-                ++cnt;
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][dy], fh[jj], acc[r], 0, 0, 0);
             }
-            if (pair) {
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int r = jj - dy;
-                    if (r < 0 || r >= R) continue;
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][dy], fl[jj], acc[r], 0, 0, 0);
-                }
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = jj - dy;
+                if (r < 0 || r >= R) continue;
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][dy], fl[jj], acc[r], 0, 0, 0);
             }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -287,22 +297,43 @@ __device__ __forceinline__ void consume_chunk_y_x3(const unsigned char* b0p, con
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][dy], fh[jj], acc[r], 0, 0, 0);
             }
             if (jj == 0 || jj == NB - 1)
-                X3_MFMA_GROUP(1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             else if (jj == 1 || jj == NB - 2)
-                X3_MFMA_GROUP(R >= 2 ? 2 : 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             else
-                X3_MFMA_GROUP(3);
-            (void)cnt;
-            if (u + 1 < NU) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+            if (u + 1 < NP) {
                 fetch_b(u + 1, jj);
-                if (u + 1 < NP)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            } else {
+                fetch_s(jj);
+                if (single_rows(jj) == 2)
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                else
+                else if (single_rows(jj) == 1)
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         }
     }
-#undef X3_MFMA_GROUP
+    // the last group
+    {
+        constexpr int cb = NP & 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][0], fh[r], acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][0], fl[r], acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][0], fh[r], acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const f16x8& s2 = (r & 1) ? fl[R + r / 2] : fh[R + r / 2];
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][2], s2, acc[r], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const f16x8& s2 = (r & 1) ? fl[R + r / 2] : fh[R + r / 2];
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb][2], s2, acc[r], 0, 0, 0);
+        }
+    }
 }
 
 // X3 = split-precision mode (boa_net precision 2, the label-contract mode): activations are fp32 in OCTET planes
