@@ -504,10 +504,27 @@ def postprocess_part_segmentation_device(ctx: Context, d_seg: DeviceBuffer, shap
     if _morph_bytes() or not ctx.lib.boa_bits_fill_supported(Y, X):
         return _postprocess_part_segmentation_device_bytes(ctx, d_seg, shape, threshold)
     n = Z * Y * X
-    if labels is None:
+    # An ABSENT label's inverted pass sees the whole volume as one hole: harmless while the volume has >= `threshold` voxels (the hole
+    # stays), but a smaller volume would be filled with a label that does not occur -- the reference only visits np.unique(mask).
+    if labels is None or n < threshold:
         labels = np.flatnonzero(slice_label_presence(ctx, d_seg, shape).any(axis=0))
     labels = sorted(int(v) for v in labels if int(v) > 0)
     words = int(ctx.lib.boa_bits_words(Z, Y, X))
+    try:
+        return _postprocess_part_bits(ctx, d_seg, shape, threshold, labels, words)
+    except (MemoryError, ValueError) as e:
+        # the bit path holds ~2 B / voxel + 12 KiB / tile per mask for 8 masks at once and indexes voxels / tiles with 31 bits: when it
+        # cannot run (BOA_ENOMEM after the allocator's own trim + retry, BOA_EINVAL from a size limit) the byte path does the same
+        # filters label by label in 13 B / voxel
+        import logging
+        logging.getLogger(__name__).warning("bit-mask post-processing unavailable (%s): falling back to the byte-mask path", e)
+        ctx.lib.boa_trim(ctx.h)
+        return _postprocess_part_segmentation_device_bytes(ctx, d_seg, shape, threshold)
+
+
+def _postprocess_part_bits(ctx: Context, d_seg: DeviceBuffer, shape, threshold: int, labels, words: int) -> DeviceBuffer:
+    Z, Y, X = shape
+    n = Z * Y * X
     d_out = ctx.zeros(n)
     try:
         for b0 in range(0, len(labels), 8):          # batches of 8 masks (one byte of membership bits per label value), ascending

@@ -175,8 +175,17 @@ static int trim_locked(boa_ctx* c) {
     // the other lane's context, torch / RCCL buffers, a post-processing volume whose hipMalloc failed -- and the next volume's
     // tile loop re-allocates it (or falls back to the scatter form if it no longer fits)
     const bool drop_stash = c->stash && !c->stash_busy;
-    if (c->pool_free.empty() && !drop_stash) return BOA_OK;
+    if (c->pool_free.empty() && !drop_stash && c->ws_desc_bytes == 0) return BOA_OK;
     BOA_HIP_TRY(hipStreamSynchronize(c->stream));
+    // the conv kernels' tile descriptor tables (one per layer geometry, batch and grid: the tail batches of differently sized volumes keep
+    // adding some) are rebuilt on their next use -- one small kernel each; the run tables (per layer geometry only) stay
+    for (size_t i = c->ws_runs.size(); i-- > 0;)
+        if (!c->ws_runs[i].first.empty() && c->ws_runs[i].first[0] == -1) {
+            hipFree(c->ws_runs[i].second);
+            c->ws_runs.erase(c->ws_runs.begin() + i);
+            c->ws_runs_host.erase(c->ws_runs_host.begin() + i);
+        }
+    c->ws_desc_bytes = 0;
     for (auto& b : c->pool_free) hipFree(b.second);
     c->pool_free.clear();
     c->pool_bytes = 0;

@@ -856,7 +856,19 @@ extern "C" int boa_bits_erode_u8(boa_ctx* c, const uint8_t* dev_mask, uint8_t* d
 }
 
 // 1 when the slice fits the LDS flood (Y * W words twice), else 0 (the caller keeps the byte-mask path of boa_fill_holes_2d)
-extern "C" int boa_bits_fill_supported(int Y, int X) { return (size_t)Y * cb_fill_stride((X + 31) / 32) * 8 <= 150 * 1024 ? 1 : 0; }
+// (the limit is the current device's opt-in LDS per workgroup minus 10 KiB of headroom -- 150 KiB on gfx950's 160 KiB; without a device the
+//  gfx950 figure is assumed: the answer is only acted on by a launch)
+static size_t cb_lds_limit() {
+    static const size_t lim = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && v > 0)
+            return (size_t)std::min(v, 160 * 1024) - 10 * 1024;
+        (void)hipGetLastError();
+        return (size_t)150 * 1024;
+    }();
+    return lim;
+}
+extern "C" int boa_bits_fill_supported(int Y, int X) { return (size_t)Y * cb_fill_stride((X + 31) / 32) * 8 <= cb_lds_limit() ? 1 : 0; }
 
 extern "C" int boa_bits_fill_holes_2d(boa_ctx* c, const uint32_t* dev_in, int Z, int Y, int X, int n_masks, uint32_t* dev_out) {
     BOA_REQUIRE(c && dev_in && dev_out && Z > 0 && Y > 0 && X > 0 && n_masks >= 1, "boa_bits_fill_holes_2d: bad argument");

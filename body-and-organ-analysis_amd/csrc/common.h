@@ -64,6 +64,8 @@ struct boa_ctx {
     // k_conv_ws run tables (first tile + length of every virtual workgroup's run), one per distinct layer geometry,
     // built on first use and kept for the life of the context: (key, device pointer)
     std::vector<std::pair<std::vector<int>, void*>> ws_runs;
+    std::vector<std::vector<int>> ws_runs_host;   // parallel to ws_runs: the host copy of a run table (empty for descriptor tables)
+    size_t ws_desc_bytes = 0;                     // bytes of the per-launch descriptor tables (key[0] == -1); boa_trim releases them
     // boa_malloc / boa_free: stream-ordered caching allocator for the transient volume-sized buffers of the host code
     // (a freed block goes back to `pool_free` without a device synchronisation and is handed out again for a request of
     // about its size; every use of a block is enqueued on `stream`, so reuse is ordered).  Network activations and weight

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void k_ws_build_desc(ConvArgs p, int grid, int 
     int* r = out + (size_t)b * row * 8;
     int my = 0;
     for (int v = b; v < p.N * p.vw; v += grid) my += p.runs[(v % p.vw) * 8];
-    if (my > row - 1) __builtin_trap();   // (cannot happen: ws_desc_table sizes the rows with a proven upper bound; fail loudly, never truncate)
+    if (my > row - 1) my = row - 1;   // (unreachable: ws_desc_table checks every workgroup's tile count against the row length on the host before the launch)
     r[0] = my;
     for (int i = 1; i < 8; ++i) r[i] = 0;
     TileSeq s;
@@ -1006,6 +1006,7 @@ const int* ws_run_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, i
         return nullptr;
     }
     ctx->ws_runs.emplace_back(std::move(key), dev);
+    ctx->ws_runs_host.emplace_back(std::move(tab));
     return (const int*)dev;
 }
 
@@ -1023,10 +1024,29 @@ const int* ws_desc_table(boa_ctx* ctx, const ConvArgs& a, int tiles_per_sample, 
     *row_out = row;
     for (auto& e : ctx->ws_runs)
         if (e.first == key) return (const int*)e.second;
+    // the row length is an upper bound of every workgroup's tile count: checked here against the host copy of the run table, so the
+    // builder kernel can neither truncate a row nor write past it (an error return instead of a device trap)
+    {
+        const std::vector<int>* runs_host = nullptr;
+        for (size_t i = 0; i < ctx->ws_runs.size(); ++i)
+            if (ctx->ws_runs[i].second == (const void*)a.runs) runs_host = &ctx->ws_runs_host[i];
+        if (!runs_host || runs_host->size() < (size_t)a.vw * 8) return nullptr;
+        for (int b = 0; b < grid; ++b) {
+            long long my = 0;
+            for (long long v = b; v < (long long)a.N * a.vw; v += grid) my += (*runs_host)[(size_t)(v % a.vw) * 8];
+            if (my > row - 1) {
+                boa_set_error("conv_ws: workgroup %d walks %lld tiles, descriptor rows hold %d", b, my, row - 1);
+                return nullptr;
+            }
+        }
+    }
     void* dev = nullptr;
-    if (hipMalloc(&dev, (size_t)grid * row * 8 * sizeof(int)) != hipSuccess) return nullptr;
+    const size_t bytes = (size_t)grid * row * 8 * sizeof(int);
+    if (hipMalloc(&dev, bytes) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(k_ws_build_desc, dim3((grid + 63) / 64), dim3(64), 0, ctx->stream, a, grid, row, (int*)dev);
     ctx->ws_runs.emplace_back(std::move(key), dev);
+    ctx->ws_runs_host.emplace_back();
+    ctx->ws_desc_bytes += bytes;
     return (const int*)dev;
 }
 
@@ -1039,6 +1059,7 @@ int launch_conv_ws(boa_ctx* ctx, const ConvArgs& a_in, const ConvTile& t, double
     const int taps = a0.k0 * a0.k1 * a0.k2;
     const int HV = t.h[0] * (t.xs > 0 ? t.xs : t.h[1] * t.h[2]);
     const int resident = conv_ws_resident(HV, taps, (a0.C0 + a0.C1) / 16, a0.Cout) ? 1 : 0;
+    BOA_REQUIRE(!x3 || a0.Cout * 4 <= 2048, "conv_ws (split precision): Cout %d exceeds the 512-entry bias table kept in LDS behind the halo buffers", a0.Cout);
     BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi <= 16777216.0 && std::max(a0.C0, a0.C1) * 2 < 16777216,
                 "conv_ws: more than 2^24 input voxels per sample (24-bit offset multiply)");
     BOA_REQUIRE((double)a0.Di * a0.Hi * a0.Wi * std::max(a0.C0, a0.C1) * 2.0 < 4294967296.0,

@@ -13,7 +13,8 @@ import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+LLVM = os.environ.get("BOA_LLVM_BIN", "/opt/rocm/lib/llvm/bin").rstrip("/")
+ARCH = os.environ.get("BOA_ARCH", "gfx950")
 
 
 def code_object(path, tmp):
@@ -22,7 +23,7 @@ def code_object(path, tmp):
     if subprocess.call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", path, os.path.join(tmp, "discard.o")],
                        stderr=subprocess.DEVNULL) != 0:
         return None        # host-only object
-    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}",
                            f"--input={fat}", f"--output={co}"])
     return co
 
