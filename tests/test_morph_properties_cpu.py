@@ -57,3 +57,32 @@ def test_binary_fill_holes_cross_equals_border_flood():
         want = fill_external_contours(m)
         np.testing.assert_array_equal(ndimage.binary_fill_holes(m), want)
         assert want[5, 6]
+
+
+def test_even_footprint_erosion_side_is_pinned():
+    """erode_region (BOA/compute/measurements.py:61-71; pyproject.toml:46 "different results for kernel 6"): the reference pads its 6^3
+    footprint AT THE END to 7^3 before skimage sees it, i.e. ones at offsets -3 .. +2 around the centre (7 // 2 = 3) on every axis -- the
+    old skimage behaviour it says it preserves (newer skimage pads an even footprint at the START: -2 .. +3).  skimage is absent (parity
+    unpinned); this writes the side down: a voxel survives iff the 6 voxels p - 3 .. p + 2 are set on every axis (outside the volume
+    counts as set), checked on an asymmetric blob against a brute-force window."""
+    from oracle import measurements as om
+    m = np.zeros((20, 22, 24), bool)
+    m[4:12, 5:13, 6:20] = True            # 8 x 8 x 14 box
+    m[4:12, 5:13, 6:9] &= True
+    m[8:12, 13:20, 6:20] = True           # an L: second arm 4 thick along axis 0 -> it cannot survive a 6-wide window
+    got = om.erode_region(m)
+    pad = np.ones(tuple(s + 6 for s in m.shape), bool)     # border_value True: the outside does not erode
+    pad[3:-3, 3:-3, 3:-3] = m
+    want = np.zeros_like(m)
+    for p in np.argwhere(m):
+        z, y, x = p + 3
+        want[tuple(p)] = pad[z - 3:z + 3, y - 3:y + 3, x - 3:x + 3].all()
+    assert (got == want).all()
+    # the 8-wide box leaves 3 survivors per short axis, at box start + 3 .. + 5: shifted half a voxel towards HIGHER indices
+    zs, ys, xs = np.nonzero(got)
+    assert (zs.min(), zs.max()) == (7, 9) and (ys.min(), ys.max()) == (8, 10) and (xs.min(), xs.max()) == (9, 17)
+    # the mirrored convention (-2 .. +3) would give 6..8 / 7..9 / 8..16: it must NOT be what the oracle computes
+    k = np.zeros((7, 7, 7), bool)
+    k[1:, 1:, 1:] = True
+    other = ndimage.binary_erosion(m, structure=k, border_value=1)
+    assert not (other == got).all() and np.nonzero(other)[0].min() == 6
