@@ -65,8 +65,10 @@ def parse_args():
     ap.add_argument("--exact-batch", type=int, default=25,
                     help="tile batch of the fp32-mode volume (2 GB of fp32 activations per tile: one 50 GB arena shared by the context's networks)")
     ap.add_argument("--cpu-tiles", type=int, default=8)
-    ap.add_argument("--cpu-all-cores", action="store_true",
-                    help="cpu_baseline: also time one tile forward on every host core (oversubscribed hosts: ~30 s; off by default)")
+    ap.add_argument("--cpu-all-cores", dest="cpu_all_cores", action="store_true", default=True,
+                    help="cpu_baseline: also time ONE tile forward on every host core (BASELINE.md 4.3's second setting; ~30 s on an "
+                         "oversubscribed host) -> cpu_baseline.all_cores; on by default since round 6")
+    ap.add_argument("--no-cpu-all-cores", dest="cpu_all_cores", action="store_false", help="skip the all-cores leg of cpu_baseline")
     ap.add_argument("--lanes", type=int, default=2, choices=[2, 3],
                     help="streams of the overlap extra: 2 = `total` | both BCA nets, 3 = `total` | body_parts | body_regions")
     ap.add_argument("--no-c3", action="store_true", help="skip the configs[2] extra (one 512x512x768 volume, total+bca)")
@@ -728,6 +730,18 @@ def main():
                            for k in ("head_accum", "finalize_argmax", "convT_mfma", "conv_first") if prof[k]["launches"]},
             # (head_accum: since round 3 the gather form of the tile loop -- stash read + labels, no accumulator planes, no separate
             #  finalize pass; its algorithmic bytes are 66 B per voxel and covering tile, a third of the scatter form's)
+            # ONE number for BASELINE.json's "% HBM roofline": the time-weighted fraction over every event-timed class that is not the MFMA
+            # conv class (sum of their algorithmic bytes / sum of their event times / 8 TB/s); the launch-latency classes (norm_finalize) and
+            # the LDS-bound scan stages (morphology) are in it on purpose -- they are part of the step
+            "hbm_roofline": (lambda ks: {
+                "frac": sum(prof[k]["bytes"] for k in ks) / max(sum(prof[k]["ms"] for k in ks), 1e-9) / 1e6 / HBM_PEAK_GBPS,
+                "achieved_GBps": sum(prof[k]["bytes"] for k in ks) / max(sum(prof[k]["ms"] for k in ks), 1e-9) / 1e6,
+                "peak_GBps": HBM_PEAK_GBPS, "ms_per_step": sum(prof[k]["ms"] for k in ks) / args.steps,
+                "share_of_kernel_time": sum(prof[k]["ms"] for k in ks) / max(total_ms, 1e-9),
+                "classes": {k: {"ms_per_step": prof[k]["ms"] / args.steps,
+                                "frac": prof[k]["bytes"] / max(prof[k]["ms"], 1e-9) / 1e6 / HBM_PEAK_GBPS} for k in ks},
+                "note": "algorithmic bytes (what a stage must read and write once) over HIP-event time, all non-MFMA kernel classes of the timed region"})(
+                    [k for k, v in prof.items() if k != "conv_mfma" and v["launches"] and v["bytes"] > 0]),
             "kernel_variants": counters,
             "median_ms_per_step": float(np.median(step_s)) * 1e3,
             # the PCIe-inclusive rate of the same workload, stated at top level next to `value` (host CT in, label volumes + tables out;
@@ -756,6 +770,9 @@ def main():
                                                  "git": pj_.get("git")}
         except Exception as e:  # noqa: BLE001
             res["roofline"]["traffic_source"] = f"unavailable ({type(e).__name__})"
+        if comm is not None and hasattr(comm, "stats"):
+            res["comm"] = dict(comm.stats(), note="rank 0's boa_comm_stats over the whole process (warm-up + timed steps): RCCL calls and bytes "
+                                                  "sent or reduced; DESIGN.md section 6 tabulates the expected bytes per boundary")
         dev_tiles, close_parity = None, None
         if not args.no_parity and args.gpus == 1:
             try:
@@ -812,14 +829,18 @@ def main():
                     "tile_batch": args.exact_batch, "tile_forwards_per_volume": tile_forwards,
                     "ms_per_tile_forward": float(np.mean(tx)) * 1e3 / tile_forwards,
                     "conv_TFLOPs_fp32_equivalent": xc["flops"] / max(xc["ms"], 1e-9) / 1e9,
-                    "conv_mfma_issue_TFLOPs": 4.0 * xc["flops"] / max(xc["ms"], 1e-9) / 1e9,
-                    "conv_frac_of_f16_peak_at_4_mfma_flops_per_flop": 4.0 * xc["flops"] / max(xc["ms"], 1e-9) / 1e9 / MFMA_F16_DENSE_PEAK_TFLOPS,
+                    # MFMA flops per fp32 flop: 41 / 13.5 = 3.04 on the tap-paired row-reuse layers (all stride-1 layers 128^3 .. 16^3, round 6),
+                    # 4 on the stride-2 (k_conv_ns) and per-tap layers; the issue rate below assumes 3.04 everywhere (a lower bound)
+                    "mfma_flops_per_fp32_flop": {"row_reuse_layers": 41.0 / 13.5, "stride2_and_per_tap_layers": 4.0},
+                    "conv_mfma_issue_TFLOPs_lower_bound": (41.0 / 13.5) * xc["flops"] / max(xc["ms"], 1e-9) / 1e9,
+                    "conv_frac_of_f16_peak_lower_bound": (41.0 / 13.5) * xc["flops"] / max(xc["ms"], 1e-9) / 1e9 / MFMA_F16_DENSE_PEAK_TFLOPS,
                     "kernel_ms_per_volume": {k: v["ms"] / len(tx) for k, v in xprof.items() if v["launches"]},
                     "kernel_variants": xcnt, "setup_and_warmup_s": t_setup,
                     "total_labels_present": int(sum(1 for v in x_meas["segmentations"]["total"].values() if v.get("present"))) if x_meas else None,
                     "note": "the same total+bca volume with every network in the fp32 mode: fp32 weights / activations / accumulation as the "
                             "reference's CPU path (predict_from_raw_data.py:648), every operand split into two fp16 parts on the matrix cores "
-                            "(2 MFMAs per 8 input channels and tap = 4 MFMA flops per fp32 flop); whole volumes timed, nothing extrapolated"}
+                            "(3 MFMAs per 8 input channels and TWO taps in the row-reuse convs: Wh Xh + Wh Xl + Wl Xh with the k-halves holding "
+                            "the same part of two taps; 2 MFMAs per tap elsewhere); whole volumes timed, nothing extrapolated"}
                 log(f"exact (fp32 split-precision) mode: {tx} s per volume -> {1.0 / float(np.mean(tx)):.4f} volumes/s; conv "
                     f"{xc['flops'] / max(xc['ms'], 1e-9) / 1e9:.0f} TFLOP/s fp32-equivalent; variants {xcnt}")
                 x_total.close()

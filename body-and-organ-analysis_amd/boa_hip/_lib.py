@@ -122,6 +122,7 @@ _PROTOS = {
     "boa_comm_exchange": (i32, [vp, i32, C.POINTER(vp), C.POINTER(u64), i32, i32, C.POINTER(vp), C.POINTER(u64), i32]),
     "boa_comm_shift_slab": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, ip, vp]),
     "boa_comm_all_reduce": (i32, [vp, vp, u64, i32]),
+    "boa_comm_planes_to_owner": (i32, [vp, vp, i32, ip, i32, ip, ip, ip, i32, ip, ip, ip]),
     "boa_comm_stats": (i32, [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "boa_add_f16_planes": (i32, [vp, vp, vp, vp, i32, ip, i32, i32]),
 }

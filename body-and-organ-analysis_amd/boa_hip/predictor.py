@@ -413,8 +413,18 @@ class _ShardedJob:
             self.flogits.append((F, lo, hi))
             if f == 0 and after_first_start is not None:
                 after_first_start()
-        for F, lo, hi in self.flogits:      # every rank, every fold, in fold order (non-members contribute zeros)
-            ts.all_reduce_logit_planes(self.ctx, comm, F, self.C_, self.PV, lo, hi)
+        # every rank, every fold, in fold order.  The folds are only ever read on this rank's finalize share (_finish_fold_units), so the
+        # plane-disjoint normalised logits go to the rank that finalises them (reduce-scatter as a plane exchange to the owner: half the
+        # per-link bytes of the all-reduce; $BOA_FOLD_ALLREDUCE=1 restores the sum that leaves every rank with complete logits)
+        import os as _os
+        if _os.environ.get("BOA_FOLD_ALLREDUCE"):
+            for F, lo, hi in self.flogits:
+                ts.all_reduce_logit_planes(self.ctx, comm, F, self.C_, self.PV, lo, hi)
+        else:
+            shares = ts.plane_shares(self.PV[0], comm.world)
+            for (F, _, _), plan_f in zip(self.flogits, self.fold_plans):
+                owned = [plan_f.owned_planes(q) for q in range(comm.world)]
+                ts.reduce_scatter_logit_planes(self.ctx, comm, F, self.C_, self.PV, owned, shares)
 
     def _finish_fold_units(self):
         comm = self.shard.comm

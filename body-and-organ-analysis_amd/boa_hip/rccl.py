@@ -110,6 +110,24 @@ class RcclComm:
                                            int(r_lo), int(r_hi), acc.vp, nacc.vp, int(n_classes), int3(PV), stage.vp if stage is not None else None),
               "boa_comm_shift_slab")
 
+    def planes_to_owner(self, buf, n_classes: int, PV, sends, recvs, wait: bool = True):
+        """Plane ranges of the fp16 logits `buf` [C][PV0][PV1][PV2] to / from several peers, in place: sends / recvs = lists of
+        (peer, lo, hi).  See tile_shard.reduce_scatter_logit_planes."""
+        from ._lib import int3
+        import numpy as np
+
+        def cols(items):
+            a = np.asarray(items, dtype=np.int32).reshape(-1, 3)
+            return [np.ascontiguousarray(a[:, k]) for k in range(3)]
+
+        sp, sl, sh = cols(sends)
+        rp, rl, rh = cols(recvs)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))   # noqa: E731
+        check(self.lib.boa_comm_planes_to_owner(self.h, buf.vp, int(n_classes), int3(PV), len(sp), ip(sp), ip(sl), ip(sh), len(rp), ip(rp), ip(rl),
+                                                ip(rh)), "boa_comm_planes_to_owner")
+        if wait:
+            self.wait()
+
     def stats(self):
         calls, nbytes = C.c_longlong(), C.c_longlong()
         check(self.lib.boa_comm_stats(self.h, C.byref(calls), C.byref(nbytes)), "boa_comm_stats")

@@ -478,6 +478,91 @@ def all_reduce_logit_planes(ctx, comm: ShardComm, buf, C_: int, PV, lo: int, hi:
         buf.upload(t.numpy().view(np.uint16))
 
 
+def plane_shares(pv0: int, world: int) -> List[Tuple[int, int]]:
+    """The balanced, contiguous plane ranges [P0, P1) of axis 0 on which the ranks finalise (normalise / fold-sum / argmax)."""
+    return [((int(pv0) * q) // world, (int(pv0) * (q + 1)) // world) for q in range(world)]
+
+
+def owner_exchange_lists(owned: List[Tuple[int, int]], shares: List[Tuple[int, int]], rank: int):
+    """`owned[p]` = planes rank p holds complete (a partition of [0, pv0), empty ranges allowed), `shares[q]` = planes rank q needs.
+    -> (sends, recvs) of `rank` as lists of (peer, lo, hi): what it owns of every other rank's share, what others own of its share."""
+    sends, recvs = [], []
+    for q, (s0, s1) in enumerate(shares):
+        if q != rank:
+            lo, hi = max(owned[rank][0], s0), min(owned[rank][1], s1)
+            if hi > lo:
+                sends.append((q, lo, hi))
+    s0, s1 = shares[rank]
+    for p, (o0, o1) in enumerate(owned):
+        if p != rank:
+            lo, hi = max(o0, s0), min(o1, s1)
+            if hi > lo:
+                recvs.append((p, lo, hi))
+    return sends, recvs
+
+
+def reduce_scatter_logit_planes(ctx, comm, buf, C_: int, PV, owned: List[Tuple[int, int]], shares: Optional[List[Tuple[int, int]]] = None):
+    """The reduce-scatter form of all_reduce_logit_planes for consumers that only finalise their own plane share (the fold units of the
+    BCA nets, predictor._ShardedJob): `buf` = fp16 logits [C][PV0][PV1][PV2]; rank p holds the planes `owned[p]` complete (every rank
+    knows every rank's range: RowPlan.owned_planes is a function of the plan).  Afterwards the planes `shares[rank]` of `buf` are
+    complete on this rank; the other planes are unspecified.  Because the supports are disjoint the "sum" is a plane exchange to the
+    owner -- every plane crosses one link once, against 2 (N - 1) / N of the whole buffer per link for the ring all-reduce -- and the
+    bits arrive untouched (x + 0 would turn -0 into +0)."""
+    world = comm.world
+    if world == 1:
+        return
+    shares = shares if shares is not None else plane_shares(int(PV[0]), world)
+    sends, recvs = owner_exchange_lists(owned, shares, comm.rank)
+    plane = int(PV[1]) * int(PV[2])
+    vox = int(PV[0]) * plane
+    if hasattr(comm, "planes_to_owner"):          # RcclComm: in place, on the communication stream
+        comm.planes_to_owner(buf, C_, PV, sends, recvs)
+        return
+    import torch
+    # gloo / validation transport: one message per (peer, class), posted in the same (class, peer) order on every rank
+    dist = comm.dist
+    staged = []
+    ops = []
+    host = None if comm.on_device else buf.download((C_ * vox,), np.uint16).copy()
+    for c in range(C_):
+        for q, lo, hi in sends:
+            n = (hi - lo) * plane
+            if comm.on_device:
+                t = comm.empty((n,), torch.float16)
+                f = _Foreign(t)
+                one, st = (C.c_int * 3)(1, 1, n), (C.c_longlong * 3)(0, 0, 1)
+                check(ctx.lib.boa_copy3(ctx.h, buf.vp, 1, c * vox + lo * plane, st, one, f.vp, 1, 0, st), "boa_copy3")
+            else:
+                t = torch.from_numpy(host[c * vox + lo * plane:c * vox + hi * plane].view(np.float16).copy())
+            ops.append(dist.P2POp(dist.isend, t, int(q)))
+            staged.append(None)
+        for p, lo, hi in recvs:
+            n = (hi - lo) * plane
+            t = comm.empty((n,), torch.float16)
+            ops.append(dist.P2POp(dist.irecv, t, int(p)))
+            staged.append((c, lo, hi, t))
+    if comm.on_device:
+        ctx.sync()
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for item in staged:
+        if item is None:
+            continue
+        c, lo, hi, t = item
+        n = (hi - lo) * plane
+        if comm.on_device:
+            f = _Foreign(t)
+            one, st = (C.c_int * 3)(1, 1, n), (C.c_longlong * 3)(0, 0, 1)
+            check(ctx.lib.boa_copy3(ctx.h, f.vp, 1, 0, st, one, buf.vp, 1, c * vox + lo * plane, st), "boa_copy3")
+        else:
+            host[c * vox + lo * plane:c * vox + hi * plane] = t.numpy().view(np.uint16)
+    if comm.on_device:
+        ctx.sync()
+    else:
+        buf.upload(host)
+
+
 @dataclass
 class TileShard:
     """What `HipPredictor.predict_segmentation_device(..., shard=...)` needs: the transport (ShardComm over torch.distributed, or

@@ -230,6 +230,44 @@ extern "C" int boa_comm_exchange(boa_comm* c, int dst, const void* const* send_p
     return fence_out(c);
 }
 
+// Plane ranges of fp16 logits [C][PV0][PV1][PV2] to / from several peers, in place (the reduce-scatter of plane-disjoint fold logits:
+// every plane travels once, to the rank that finalises it).  Sub-groups of whole classes; their size is a function of $BOA_COMM_GROUP
+// and the world size only, so every rank opens and closes the same groups in the same order whatever its own message lists hold.
+extern "C" int boa_comm_planes_to_owner(boa_comm* c, uint16_t* logits, int C, const int PV[3], int n_send, const int* send_peer,
+                                        const int* send_lo, const int* send_hi, int n_recv, const int* recv_peer, const int* recv_lo,
+                                        const int* recv_hi) {
+    BOA_REQUIRE(c && logits && PV && C >= 1 && n_send >= 0 && n_recv >= 0, "boa_comm_planes_to_owner: bad argument");
+    BOA_REQUIRE(n_send == 0 || (send_peer && send_lo && send_hi), "boa_comm_planes_to_owner: NULL send arrays");
+    BOA_REQUIRE(n_recv == 0 || (recv_peer && recv_lo && recv_hi), "boa_comm_planes_to_owner: NULL receive arrays");
+    for (int i = 0; i < n_send; ++i)
+        BOA_REQUIRE(send_peer[i] >= 0 && send_peer[i] < c->world && send_peer[i] != c->rank && send_lo[i] >= 0 && send_lo[i] < send_hi[i] && send_hi[i] <= PV[0],
+                    "boa_comm_planes_to_owner: send %d: planes [%d, %d) to rank %d", i, send_lo[i], send_hi[i], send_peer[i]);
+    for (int i = 0; i < n_recv; ++i)
+        BOA_REQUIRE(recv_peer[i] >= 0 && recv_peer[i] < c->world && recv_peer[i] != c->rank && recv_lo[i] >= 0 && recv_lo[i] < recv_hi[i] && recv_hi[i] <= PV[0],
+                    "boa_comm_planes_to_owner: receive %d: planes [%d, %d) from rank %d", i, recv_lo[i], recv_hi[i], recv_peer[i]);
+    Rccl* R = rccl();
+    const size_t plane = (size_t)PV[1] * PV[2], vv = (size_t)PV[0] * plane;
+    BOA_TRY(fence_in(c));
+    const int per = std::max(1, comm_group_msgs() / std::max(1, c->world));   // classes per RCCL group
+    for (int k0 = 0; k0 < C; k0 += per) {
+        const int k1 = std::min(C, k0 + per);
+        BOA_NCCL_TRY(R->GroupStart());
+        for (int k = k0; k < k1; ++k) {
+            for (int i = 0; i < n_send; ++i) {
+                const size_t n = (size_t)(send_hi[i] - send_lo[i]) * plane;
+                BOA_NCCL_GROUP_TRY(R->Send(logits + (size_t)k * vv + (size_t)send_lo[i] * plane, n, ncclFloat16, send_peer[i], c->comm, c->stream));
+                c->bytes += (long long)(n * 2);
+            }
+            for (int i = 0; i < n_recv; ++i)
+                BOA_NCCL_GROUP_TRY(R->Recv(logits + (size_t)k * vv + (size_t)recv_lo[i] * plane, (size_t)(recv_hi[i] - recv_lo[i]) * plane, ncclFloat16,
+                                           recv_peer[i], c->comm, c->stream));
+        }
+        BOA_NCCL_TRY(R->GroupEnd());
+    }
+    c->calls++;
+    return fence_out(c);
+}
+
 // The overlap slab of a tile-row boundary: planes [lo, hi) of the C class planes of `acc` and of `nacc` (fp16, planar
 // [.][PV0][PV1][PV2]).  send: this rank's finished partial sums -> rank dst; recv: the lower rank's -> straight into this rank's
 // planes (exact mode: nothing of this rank's has been added there yet) or into `recv_stage` ((C + 1) x planes x PV1 PV2 halves,

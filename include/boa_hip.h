@@ -477,6 +477,12 @@ int boa_resize_logits_argmax(boa_ctx* ctx, const uint16_t* dev_logits, int C, co
  *                        place (recv_stage NULL: the exact hand-over, the receiver has not added anything there yet) or into
  *                        recv_stage [(C + 1)][planes][PV1 PV2] for boa_add_f16_planes (the pairwise fp16 sum).  dst / src < 0: none
  *   boa_comm_exchange  : generic grouped send / recv of byte ranges (pieces matched in order)
+ *   boa_comm_planes_to_owner: plane ranges of the C class planes of fp16 logits [C][PV0][PV1][PV2] to / from SEVERAL peers, in place:
+ *                        message i of the send list = planes [send_lo[i], send_hi[i]) of every class -> rank send_peer[i], likewise the
+ *                        receive list (disjoint from what this rank keeps).  The reduce-scatter of plane-disjoint fold logits
+ *                        (predict_from_raw_data.py:494-500 adds the folds; every rank only finalises its own plane share): each plane
+ *                        travels once, to the rank that finalises it -- half the per-link bytes of the all-reduce.  Classes go out in
+ *                        sub-groups whose size depends on $BOA_COMM_GROUP and the world size only, so all ranks walk the same groups
  *   boa_comm_all_reduce: in-place sum over all ranks; dtype 0 uint8, 1 fp16, 2 int32, 3 fp32 (label volumes with disjoint
  *                        supports: TS/nnunet.py:553-556 merges the parts afterwards; inf flags; plane-disjoint logits) */
 typedef struct boa_comm boa_comm;
@@ -491,6 +497,9 @@ int boa_comm_exchange(boa_comm* comm, int dst, const void* const* send_ptrs, con
 int boa_comm_shift_slab(boa_comm* comm, int dst, int send_lo, int send_hi, int src, int recv_lo, int recv_hi, uint16_t* dev_acc,
                         uint16_t* dev_n, int C, const int PV[3], uint16_t* recv_stage);
 int boa_comm_all_reduce(boa_comm* comm, void* dev, size_t count, int dtype);
+int boa_comm_planes_to_owner(boa_comm* comm, uint16_t* dev_logits, int C, const int PV[3], int n_send, const int* send_peer,
+                             const int* send_lo, const int* send_hi, int n_recv, const int* recv_peer, const int* recv_lo,
+                             const int* recv_hi);
 int boa_comm_stats(boa_comm* comm, long long* calls, long long* bytes);
 /* acc[k][lo:hi] = half(float(acc[k][lo:hi]) + float(stage[k])), k = 0 .. C (C = the n plane): the owner's side of the pairwise
  * fp16 sum of a slab ("allreduce" exchange mode) */

@@ -474,3 +474,99 @@ def test_fold_units_keep_eight_ranks_busy_on_the_bca_nets():
         lo_hi = [plan.owned_planes(r) for r, _ in blocks]
         assert lo_hi[0][0] == 0 and lo_hi[-1][1] == PV[0] and all(a[1] == b[0] for a, b in zip(lo_hi, lo_hi[1:]))
     assert max(load.values()) <= 2 * 49 and min(load.values()) >= 49     # 490 tile forwards over 8 ranks: 49 .. 98 each (2 ranks alone: 245)
+
+
+# ---- reduce-scatter of the plane-disjoint fold logits (round 6) ------------------------------------------------------------------
+class _HostBuf:
+    """numpy stand-in for a DeviceBuffer on the CPU transport (download / upload of uint16 words)."""
+
+    def __init__(self, words):
+        self.a = np.ascontiguousarray(words, dtype=np.uint16)
+
+    def download(self, shape, dtype):
+        return self.a.reshape(shape).view(dtype)
+
+    def upload(self, arr):
+        self.a[...] = np.asarray(arr).view(np.uint16).reshape(self.a.shape)
+
+
+def _rs_worker(rank, world, port, C_, PV, owned, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from boa_hip import distributed as D
+    from boa_hip import tile_shard as ts
+    dist = D.init("gloo", rank, world)
+    plane = PV[1] * PV[2]
+    full = np.random.default_rng(11).integers(0, 0x7BFF, size=(C_, PV[0], plane), dtype=np.uint16)     # finite fp16 bit patterns
+    full[0, :, 0] = 0x8000                                   # -0.0: a sum with +0 would lose the sign, the exchange must not
+    mine = np.random.default_rng(100 + rank).integers(0, 0xFFFF, size=full.shape, dtype=np.uint16)      # junk wherever this rank owns nothing
+    lo, hi = owned[rank]
+    mine[:, lo:hi] = full[:, lo:hi]
+    buf = _HostBuf(mine.reshape(-1))
+    comm = ts.ShardComm(dist, rank, world, "cpu")
+    shares = ts.plane_shares(PV[0], world)
+    ts.reduce_scatter_logit_planes(None, comm, buf, C_, PV, owned, shares)
+    got = buf.a.reshape(full.shape)
+    s0, s1 = shares[rank]
+    q.put((rank, bool((got[:, s0:s1] == full[:, s0:s1]).all()), s1 - s0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,owned", [
+    (4, [(0, 9), (9, 20), (0, 0), (0, 0)]),                  # a fold on two of four ranks (fold units: the other ranks own nothing)
+    (4, [(0, 0), (0, 13), (13, 20), (0, 0)]),
+    (3, [(0, 7), (7, 14), (14, 20)]),                        # owners == finalisers up to the balanced cut
+    (2, [(0, 20), (0, 0)]),                                  # one owner feeds everybody
+])
+def test_reduce_scatter_of_fold_logits_is_a_bit_exact_plane_exchange(world, owned):
+    """predictor._ShardedJob._begin_fold_units: a fold's normalised logits are complete on the planes its member ranks own; every rank
+    finalises the balanced share plane_shares()[rank].  After reduce_scatter_logit_planes every rank holds its share bit for bit
+    (incl. -0.0, which the all-reduce's x + 0 would flip) and the bytes that moved are each plane once."""
+    from boa_hip import tile_shard as ts
+    C_, PV = 3, (20, 5, 4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rs_worker, args=(r, world, port, C_, PV, owned, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in got) and sum(n for _, _, n in got) == PV[0]
+    # traffic: every plane that is not already at its finaliser travels once
+    shares = ts.plane_shares(PV[0], world)
+    moved = 0
+    for r in range(world):
+        s, rcv = ts.owner_exchange_lists(owned, shares, r)
+        moved += sum(hi - lo for _, lo, hi in s)
+        assert sum(hi - lo for _, lo, hi in rcv) + max(0, min(owned[r][1], shares[r][1]) - max(owned[r][0], shares[r][0])) == shares[r][1] - shares[r][0]
+    stay = sum(max(0, min(owned[r][1], shares[r][1]) - max(owned[r][0], shares[r][0])) for r in range(world))
+    assert moved == PV[0] - stay
+
+
+def test_reduce_scatter_lists_match_across_ranks_at_the_bca_geometry():
+    """Send list of p to q == receive list of q from p for the (fold, row) units of the 512^3 BCA nets on 8 ranks, and the per-link bytes
+    are at most half of the ring all-reduce's 2 (N - 1) / N of the whole buffer."""
+    from boa_hip import sliding_window as sw
+    from boa_hip import tile_shard as ts
+    world, folds = 8, 5
+    PV, _ = sw.pad_amounts([154, 512, 512], [128, 128, 128])
+    origins = np.array(sw.get_sliding_window_origins(PV, [128] * 3, 0.5))
+    rows = sorted(set(int(o[0]) for o in origins))
+    units = ts.plan_units([len(rows)] * folds, world)
+    shares = ts.plane_shares(PV[0], world)
+    for blocks in units:
+        plan = ts.plan_rows(origins, 128, PV[0], world, assignment=blocks)
+        owned = [plan.owned_planes(r) for r in range(world)]
+        lists = [ts.owner_exchange_lists(owned, shares, r) for r in range(world)]
+        for p in range(world):
+            for q_, lo, hi in lists[p][0]:
+                assert (p, lo, hi) in lists[q_][1]
+        assert sum(len(s) for s, _ in lists) == sum(len(r) for _, r in lists)
+        out_planes = max(sum(hi - lo for _, lo, hi in s) for s, _ in lists)
+        assert out_planes <= PV[0]                                   # a rank sends at most the whole buffer once ...
+        ring = 2 * (world - 1) / world * PV[0]
+        in_planes = max(sum(hi - lo for _, lo, hi in r) for _, r in lists)
+        assert in_planes <= ring / 2 / (world - 1) * world           # ... and receives no more than its own share: 1 / N of it
