@@ -326,23 +326,37 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
         __syncthreads();
     };
     const size_t g_begin = (size_t)blockIdx.x * groups_per_block * 256;   // groups of 16 voxels, 256 per iteration
+    // the next iteration's 64 bytes per lane are fetched BEFORE this iteration's table work (round 6): with 32 - 128 KiB of LDS per
+    // workgroup only 1 - 4 workgroups fit a CU, and a loop of load -> wait -> LDS work -> barrier left HBM idle most of the time
+    union LabV {
+        uint4 u;
+        unsigned char b[16];
+    };
+    union HuV {
+        uint4 u[2];
+        short h[16];
+    };
+    LabV nlb, nmb;
+    HuV nhb;
+    nlb.u = nmb.u = nhb.u[0] = nhb.u[1] = make_uint4(0, 0, 0, 0);
+    auto fetch = [&](size_t it) {
+        const size_t g = g_begin + it * 256 + tid;
+        if (it < groups_per_block && g < n16) {
+            nlb.u = *(const uint4*)(labels + g * 16);
+            nhb.u[0] = *(const uint4*)(ct + g * 16);
+            nhb.u[1] = *(const uint4*)(ct + g * 16 + 8);
+            if (mask) nmb.u = *(const uint4*)(mask + g * 16);
+        }
+    };
+    fetch(0);
     for (size_t it = 0; it < groups_per_block; ++it) {
         const size_t g = g_begin + it * 256 + tid;
         const bool live = g < n16;
         unsigned key[16];   // 0 = not measured (label 0 / masked out)
+        const LabV lb = nlb, mb = nmb;
+        const HuV hb = nhb;
+        fetch(it + 1);
         if (live) {
-            union {
-                uint4 u;
-                unsigned char b[16];
-            } lb, mb;
-            union {
-                uint4 u[2];
-                short h[16];
-            } hb;
-            lb.u = *(const uint4*)(labels + g * 16);
-            hb.u[0] = *(const uint4*)(ct + g * 16);
-            hb.u[1] = *(const uint4*)(ct + g * 16 + 8);
-            if (mask) mb.u = *(const uint4*)(mask + g * 16);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const unsigned l = (mask && !mb.b[i]) ? 0u : lb.b[i];
@@ -362,6 +376,7 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
             const unsigned c = 16u * (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
             if (k0 != 0u && (tid & 63) == 0 && c) count(k0, c);
         } else if (live) {
+#ifdef BOA_HIST_SERIAL   // (A/B: the round-5 form, one dependent probe chain per run of equal keys)
             unsigned rk = key[0], run = 1;
 #pragma unroll
             for (int i = 1; i < 16; ++i) {
@@ -374,6 +389,36 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
                 }
             }
             if (rk) count(rk, run);
+#else
+            // Round 6: the 16 voxels of a lane are looked up TOGETHER.  In the steady state a key already sits in its home slot (a slot
+            // keeps its key until the next flush, and flushes are behind the workgroup barrier): 16 independent ds_read_b32 of the home
+            // slots, then one return-less ds_add_u32 per hit -- throughput instead of 16 dependent LDS round trips with a probe loop
+            // each.  Misses (first occurrence of a key, displaced keys) take the probing insert.  Runs of equal keys are merged first
+            // (CT noise makes them rare inside an organ, but label 0 / masked voxels form long runs of key 0, which cost nothing).
+            unsigned hh[16], kk[16], cc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                hh[i] = (key[i] * 2654435761u) >> (32 - LOG2);
+                cc[i] = 1u;
+            }
+#pragma unroll
+            for (int i = 15; i > 0; --i) {   // fold a voxel into its left neighbour when the keys agree (counts flow to the run's first voxel)
+                const bool eq = key[i] == key[i - 1];
+                cc[i - 1] += eq ? cc[i] : 0u;
+                cc[i] = eq ? 0u : cc[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kk[i] = keys[hh[i]];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (key[i] != 0u && cc[i] != 0u) {
+                    if (kk[i] == key[i])
+                        atomicAdd(&cnts[hh[i]], cc[i]);
+                    else
+                        count(key[i], cc[i]);
+                }
+            }
+#endif
         }
         __syncthreads();
         if (nkeys > HIST_FLUSH) flush();   // (uniform: nkeys is read after the barrier by everyone)

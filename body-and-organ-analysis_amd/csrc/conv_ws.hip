@@ -342,7 +342,11 @@ __device__ __forceinline__ void consume_chunk_y_x3(const unsigned char* b0p, con
 // shared; the producers normalise in fp32 and split into hi / lo fp16 LDS planes, the consumers issue two MFMAs per tap
 // (consume_chunk), the epilogue un-scales the accumulators and stores fp32.  Measured against an fp32 FMA chain the product of
 // split operands is the more accurate of the two (tools/x3_probe.hip: rms error 3.2e-7 vs 5.3e-7 of the output rms at K = 864).
-template <int R, int K0, int K1, int K2, bool YR, bool X3>
+// FX (experiment, -DWS_FIXED_SHAPE): the halo strides of the dominant tile shape (w = 1 x 1 x 32, b = 2 x 8 x 1: xs = 340, h2 = 34) as
+// compile-time constants in the consumers' fragment addresses (immediate offsets instead of 18 v_add + ~20 SGPRs per chunk)
+#define WS_FX_XS 340
+#define WS_FX_H2 34
+template <int R, int K0, int K1, int K2, bool YR, bool X3, bool FX = false>
 __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_tiles, int resident_w, int dbg_arg, const int* __restrict__ desc,
                                                         int desc_row) {
     // (round 5, measured and not kept: hipcc re-loads kernel arguments from the kernarg segment in the per-tile paths instead of keeping
@@ -867,6 +871,11 @@ __global__ __launch_bounds__(WS_THREADS) void k_conv_ws(ConvArgs p, int total_ti
 #endif
                 } else
                     consume_chunk<R, K0, K1, K2, false, X3>(bp, ap, p.xs, p.h2, acc, biasv);
+            } else if constexpr (YR && FX) {
+                if (cc == 0)
+                    consume_chunk_y<R, K0, K2, true, X3>(bp[0], ap, WS_FX_XS, WS_FX_H2, acc, biasv);
+                else
+                    consume_chunk_y<R, K0, K2, false, X3>(bp[0], ap, WS_FX_XS, WS_FX_H2, acc, biasv);
             } else if constexpr (YR) {
                 if (cc == 0)
                     consume_chunk_y<R, K0, K2, true, X3>(bp[0], ap, p.xs, p.h2, acc, biasv);
@@ -930,6 +939,17 @@ bool conv_ws_supported(const int k[3], int HV) {
 
 template <int R, int K0, int K1, int K2, bool YR, bool X3>
 static void launch_ws_y(boa_ctx* ctx, const ConvArgs& a, const ConvTile& t, int total, int grid, int resident, const int* desc, int desc_row) {
+#ifdef WS_FIXED_SHAPE
+    if constexpr (YR && R == 4 && !X3) {
+        if (a.xs == WS_FX_XS && a.h2 == WS_FX_H2) {
+            static bool once_fx = (hipFuncSetAttribute((const void*)k_conv_ws<R, K0, K1, K2, YR, X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+            (void)once_fx;
+            hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR, X3, true>), dim3(grid), dim3(WS_THREADS), t.lds_bytes + 2048, ctx->stream, a, total, resident,
+                               getenv("BOA_WS_DBG") ? atoi(getenv("BOA_WS_DBG")) : 0, desc, desc_row);
+            return;
+        }
+    }
+#endif
     static bool once = (hipFuncSetAttribute((const void*)k_conv_ws<R, K0, K1, K2, YR, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
     hipLaunchKernelGGL((k_conv_ws<R, K0, K1, K2, YR, X3>), dim3(grid), dim3(WS_THREADS), t.lds_bytes + 2048, ctx->stream, a, total, resident,
