@@ -45,7 +45,7 @@ HBM_COPY_GBPS = 6300.0
 # CU), pure read 6.37, copy 4.6 - 5.3: what the write-dominated kernels (first conv: 94 % of its bytes are stores, transposed conv: 89 %)
 # can be priced against besides the 8 TB/s data-sheet figure
 HBM_WRITE_GBPS = 4700.0
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r05_pmc_fetch_write_512.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r06_pmc_fetch_write_512.json")
 
 
 def parse_args():

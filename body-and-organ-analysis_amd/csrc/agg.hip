@@ -263,8 +263,12 @@ extern "C" int boa_tissue_projections(boa_ctx* c, const uint8_t* dev_tissues, co
 // distinct (label, HU) keys of a contiguous voxel range of compact organs between flushes; LOG2 = 13 (two workgroups) is the default.
 #define HIST_EMPTY 0xFFFFFFFFu
 
-template <int LOG2>
-__global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
+// HT: threads per workgroup.  What bounds the pass on compact organs is the FLUSH: every workgroup sends each distinct (label, HU) key of
+// its voxel range to the global table with one device-scope atomic, and those serialise in the fabric (the reason for the LDS tables in the
+// first place) -- 2 048 workgroups of 256 threads re-send the same ~1 000 keys 2 048 times.  1 024-thread workgroups cover 4x the voxels
+// per table at the same waves per CU: a quarter of the workgroups, a little more than a quarter of the atomics.
+template <int LOG2, int HT>
+__global__ __launch_bounds__(HT) void k_label_hist(const short* __restrict__ ct, const unsigned char* __restrict__ labels,
                                                     const unsigned char* __restrict__ mask, size_t n_all, size_t head, int hu_min,
                                                     int nbins, unsigned int* __restrict__ hist, size_t groups_per_block) {
     constexpr int HIST_TAB = 1 << LOG2;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
     unsigned int* cnts = keys + HIST_TAB;            // [HIST_TAB]
     __shared__ int nkeys;
     const int tid = threadIdx.x;
-    for (int i = tid; i < HIST_TAB; i += 256) {
+    for (int i = tid; i < HIST_TAB; i += HT) {
         keys[i] = HIST_EMPTY;
         cnts[i] = 0u;
     }
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
         atomicAdd(&hist[(size_t)(key >> 16) * nbins + (key & 0xFFFFu)], c);   // a long probe chain: straight to the global table
     };
     auto flush = [&]() {  // whole workgroup
-        for (int i = tid; i < HIST_TAB; i += 256) {
+        for (int i = tid; i < HIST_TAB; i += HT) {
             const unsigned k = keys[i];
             if (k != HIST_EMPTY) {
                 atomicAdd(&hist[(size_t)(k >> 16) * nbins + (k & 0xFFFFu)], cnts[i]);
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
         if (tid == 0) nkeys = 0;
         __syncthreads();
     };
-    const size_t g_begin = (size_t)blockIdx.x * groups_per_block * 256;   // groups of 16 voxels, 256 per iteration
+    const size_t g_begin = (size_t)blockIdx.x * groups_per_block * HT;   // groups of 16 voxels, HT per iteration
     // the next iteration's 64 bytes per lane are fetched BEFORE this iteration's table work (round 6): with 32 - 128 KiB of LDS per
     // workgroup only 1 - 4 workgroups fit a CU, and a loop of load -> wait -> LDS work -> barrier left HBM idle most of the time
     union LabV {
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
     HuV nhb;
     nlb.u = nmb.u = nhb.u[0] = nhb.u[1] = make_uint4(0, 0, 0, 0);
     auto fetch = [&](size_t it) {
-        const size_t g = g_begin + it * 256 + tid;
+        const size_t g = g_begin + it * HT + tid;
         if (it < groups_per_block && g < n16) {
             nlb.u = *(const uint4*)(labels + g * 16);
             nhb.u[0] = *(const uint4*)(ct + g * 16);
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256) void k_label_hist(const short* __restrict__ ct
     };
     fetch(0);
     for (size_t it = 0; it < groups_per_block; ++it) {
-        const size_t g = g_begin + it * 256 + tid;
+        const size_t g = g_begin + it * HT + tid;
         const bool live = g < n16;
         unsigned key[16];   // 0 = not measured (label 0 / masked out)
         const LabV lb = nlb, mb = nmb;
@@ -467,24 +471,41 @@ extern "C" int boa_label_hu_histogram(boa_ctx* c, const int16_t* dev_ct, const u
     // table size / workgroups per CU, kernel time in us (tools/hist_sweep.sh, tools/hist_bench.sh; 512^3):   structured phantom | bench labels (noise-like)
     //   2^14, 4:  845 | 947      2^13, 8:  679 | 1 124      2^12, 8:  571 | 1 905      2^12, 16:  650 | 2 056
     // compact organs want occupancy, salt-and-pepper labels a table that merges more duplicates before it spills: 2^13 is the default
-    static const int hist_log2 = getenv("BOA_HIST_LOG2") ? atoi(getenv("BOA_HIST_LOG2")) : 13;
-    static const int hist_wg = getenv("BOA_HIST_WG") ? atoi(getenv("BOA_HIST_WG")) : (hist_log2 == 14 ? 4 : 8);   // workgroups per CU
-    const size_t iters = ((n - head) / 16 + 255) / 256;
-    const size_t gpb = std::max<size_t>(1, (iters + (size_t)c->cu_count * hist_wg - 1) / ((size_t)c->cu_count * hist_wg));
+    // round 6 (tools/r6_hist_sweep.sh, profiles/r06_hist_sweep.txt; kernel us on the structured phantom | on salt-and-pepper labels, 512^3):
+    //   2^13 x 256 threads x 8 per CU (round 5)  638 | 2 937      2^13 x 1 024 x 2   486 | 2 600      2^12 x 1 024 x 2   547 | 2 650
+    //   2^14 x 1 024 x 1  420 | 2 106  <- default: ONE 1 024-thread workgroup per CU with the largest table = the fewest flush atomics
+    // ($BOA_HIST_THREADS=256 restores the small workgroups)
+    static const int hist_log2 = getenv("BOA_HIST_LOG2") ? atoi(getenv("BOA_HIST_LOG2")) : 14;
+    static const int hist_threads = getenv("BOA_HIST_THREADS") ? atoi(getenv("BOA_HIST_THREADS")) : 1024;
+    const int HT = hist_threads == 256 ? 256 : (hist_threads == 512 ? 512 : 1024);
+    static const int hist_wg = getenv("BOA_HIST_WG") ? atoi(getenv("BOA_HIST_WG")) : 0;   // workgroups per CU (0: what fits next to each other)
+    const int wg = hist_wg > 0 ? hist_wg : (HT == 256 ? (hist_log2 == 14 ? 4 : 8) : std::max(1, std::min((160 * 1024) / (8 << hist_log2), 2048 / HT)));
+    const size_t iters = ((n - head) / 16 + HT - 1) / HT;
+    const size_t gpb = std::max<size_t>(1, (iters + (size_t)c->cu_count * wg - 1) / ((size_t)c->cu_count * wg));
     const int grid = (int)std::max<size_t>(1, (iters + gpb - 1) / gpb);
     KernelTimer t(c, BOA_K_AGG, 0, (double)n * (3.0 + (dev_mask ? 1 : 0)));
     if (together) {
-        static bool once = (hipFuncSetAttribute((const void*)k_label_hist<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024), true);
-        (void)once;
+#define BOA_HIST_LAUNCH(L, T)                                                                                                         \
+    do {                                                                                                                              \
+        static bool once = (hipFuncSetAttribute((const void*)k_label_hist<L, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024), true); \
+        (void)once;                                                                                                                   \
+        hipLaunchKernelGGL((k_label_hist<L, T>), dim3(grid), dim3(T), (size_t)8 << L, c->stream, dev_ct, dev_labels, dev_mask, n, head, hu_min, \
+                           nbins, dev_hist, gpb);                                                                                     \
+    } while (0)
+#define BOA_HIST_BY_T(L)                                  \
+    do {                                                  \
+        if (HT == 256) BOA_HIST_LAUNCH(L, 256);           \
+        else if (HT == 512) BOA_HIST_LAUNCH(L, 512);      \
+        else BOA_HIST_LAUNCH(L, 1024);                    \
+    } while (0)
         if (hist_log2 == 14)
-            hipLaunchKernelGGL(k_label_hist<14>, dim3(grid), dim3(256), (size_t)8 << 14, c->stream, dev_ct, dev_labels, dev_mask, n,
-                               head, hu_min, nbins, dev_hist, gpb);
+            BOA_HIST_BY_T(14);
         else if (hist_log2 == 13)
-            hipLaunchKernelGGL(k_label_hist<13>, dim3(grid), dim3(256), (size_t)8 << 13, c->stream, dev_ct, dev_labels, dev_mask, n,
-                               head, hu_min, nbins, dev_hist, gpb);
+            BOA_HIST_BY_T(13);
         else
-            hipLaunchKernelGGL(k_label_hist<12>, dim3(grid), dim3(256), (size_t)8 << 12, c->stream, dev_ct, dev_labels, dev_mask, n,
-                               head, hu_min, nbins, dev_hist, gpb);
+            BOA_HIST_BY_T(12);
+#undef BOA_HIST_BY_T
+#undef BOA_HIST_LAUNCH
     } else {
         hipLaunchKernelGGL(k_label_hist_scalar, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->cu_count * 32)), dim3(256), 0,
                            c->stream, dev_ct, dev_labels, dev_mask, n, hu_min, nbins, dev_hist);
