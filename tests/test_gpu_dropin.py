@@ -256,3 +256,39 @@ def test_compute_all_models_with_legacy_plans_and_upstream_checkpoint_keys(tmp_p
     torch.save(ck, pth)
     with pytest.raises(ValueError, match="unexpected checkpoint key"):
         compute_all_models(tmp_path / "ct.nii.gz", tmp_path / "bad", ["total"], params)
+
+
+def test_dicom_folder_input_gives_the_labels_of_the_nifti_input(tmp_path, monkeypatch):
+    """`analyze_ct` (BOA/commands.py:121-129) hands a DICOM folder to `get_image_info` and the resulting image.nii.gz to
+    `compute_all_models`: the folder path of the drop-in.  A CT phantom written as an axial series (explicit VR, stored = HU + 1024,
+    shuffled file order) must come out as the SAME label volume as the phantom saved directly as NIfTI with the series' geometry
+    (DICOM reader unpinned vs GDCM / SimpleITK: tests/dicom_writer.py is the only writer it has met)."""
+    from boa_hip import nifti
+    from boa_hip.compute.inference import compute_all_models
+    from boa_hip.compute.io import get_image_info
+    from boa_hip.synthetic import ct_phantom
+    from dicom_writer import write_series
+    root = tmp_path / "results"
+    _write_models(str(root), (1.5, 1.5, 1.5), (5.0, 1.5, 1.5))
+    monkeypatch.setenv("nnUNet_results", str(root))
+    ct = ct_phantom((48, 40, 36), seed=9)                        # file order (x, y, z), int16 HU in [-1024, 3071]
+    stored = (ct.astype(np.int32) + 1024).astype(np.uint16).transpose(2, 1, 0)      # [z][rows = y][cols = x]
+    rng = np.random.default_rng(0)
+    order = list(rng.permutation(stored.shape[0]))
+    write_series(tmp_path / "dcm", stored, origin=(-30.0, -40.0, 100.0), spacing=(1.5, 1.5), dz=1.5, order=order, bits_stored=12)
+    ct_path, ct_info = get_image_info(tmp_path / "dcm", tmp_path / "proc")
+    data, aff, _ = nifti.load(ct_path)
+    np.testing.assert_array_equal(data, ct)
+    want_aff = np.diag([-1.5, -1.5, 1.5, 1.0])
+    want_aff[:3, 3] = [30.0, 40.0, 100.0]
+    np.testing.assert_allclose(aff, want_aff, atol=1e-5)
+    assert {e["name"]: e["value"] for e in ct_info}["Modality"] == "CT"
+    params = {"preview": False, "fast": False, "ml": True, "nr_thr_resamp": 1, "nr_thr_saving": 1, "quiet": True,
+              "verbose": False, "device": "gpu", "license_number": None}
+    compute_all_models(ct_path, tmp_path / "from_dicom", ["total"], params)
+    ref_path = tmp_path / "ct.nii.gz"
+    nifti.save(ref_path, ct, want_aff)
+    compute_all_models(ref_path, tmp_path / "from_nifti", ["total"], params)
+    a, _, _ = nifti.load(tmp_path / "from_dicom" / "total.nii.gz")
+    b, _, _ = nifti.load(tmp_path / "from_nifti" / "total.nii.gz")
+    assert a.shape == ct.shape and (a == b).all() and a.max() > 0
