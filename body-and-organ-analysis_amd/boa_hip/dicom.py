@@ -152,7 +152,8 @@ def _read_element(cur: _Cursor, explicit: bool, want) -> Optional[Tuple[Tuple[in
     if length == 0xFFFFFFFF:
         if (g, e) == (0x7FE0, 0x0010):
             raise NotImplementedError("encapsulated (compressed) PixelData: only uncompressed transfer syntaxes are read")
-        _skip_sequence(cur, explicit)
+        # (PS3.5 6.2.2: an UN element of undefined length holds a sequence encoded in IMPLICIT VR, whatever the file's syntax)
+        _skip_sequence(cur, explicit and vr != "UN")
         return (g, e), "SQ", b""
     if want is not None and (g, e) not in want:
         cur.take(length) if (g, e) != (0x7FE0, 0x0010) else cur.take(min(length, len(cur.buf) - cur.pos))
