@@ -340,14 +340,14 @@ def load_series(folder) -> Tuple[np.ndarray, Dict[str, Any], List[str]]:
             raise ValueError("two slices of the series share a position (duplicated instances)")
         mean = float(np.linalg.norm(pos[-1] - pos[0])) / (n - 1)
         tol = max(0.01 * mean, 0.01)
+        # in-plane drift of the slice origins (a sheared stack): ITK would silently ignore it
+        drift = (pos - pos[0]) - np.outer(proj - proj[0], normal)
+        if np.abs(drift).max() > tol:
+            raise ValueError("slice origins are not aligned along the slice normal (sheared series)")
         if (np.abs(steps - mean) > tol).any():
             k = int(np.argmax(np.abs(steps - mean)))
             raise ValueError(f"non-uniform slice distances (missing slice?): {steps[k]:.4f} mm between {files[k]} and {files[k + 1]}, "
                              f"{mean:.4f} mm on average")
-        # in-plane drift of the slice origins (a sheared stack): ITK would silently ignore it
-        drift = (pos - pos[0]) - np.outer(proj - proj[0], normal)
-        if np.abs(drift).max() > max(0.01 * mean, 0.01):
-            raise ValueError("slice origins are not aligned along the slice normal (sheared series)")
         dz = mean
     else:
         dz = float(first.get("SliceThickness") or 1.0)

@@ -135,3 +135,41 @@ def test_reader_skips_unknown_and_nested_elements(tmp_path):
         f.write(b"\0" * 200)
     with pytest.raises(dicom.DicomError):
         dicom.read_file(tmp_path / "bad.dcm")
+
+
+def test_more_refusals_and_geometry_checks(tmp_path):
+    vol = _volume()
+    # explicit VR big endian
+    write_series(tmp_path / "be", vol, transfer_syntax="1.2.840.10008.1.2.2")
+    with pytest.raises(NotImplementedError, match="transfer syntax"):
+        dicom.load_series(tmp_path / "be")
+    # multi-frame object
+    write_series(tmp_path / "mf", vol, extra=[((0x0028, 0x0008), "IS", 4)])
+    with pytest.raises(NotImplementedError, match="multi-frame"):
+        dicom.load_series(tmp_path / "mf")
+    # a slice without ImagePositionPatient cannot be ordered
+    write_series(tmp_path / "noipp", vol)
+    write_slice(tmp_path / "noipp" / "extra.dcm", vol[0], ipp=None, instance=99)
+    with pytest.raises(ValueError, match="ImagePositionPatient"):
+        dicom.series_file_names(tmp_path / "noipp")
+    # a duplicated instance (same position twice)
+    write_series(tmp_path / "dup", vol)
+    write_slice(tmp_path / "dup" / "again.dcm", vol[3], ipp=(-100.0, -120.0, 50.0 + 3 * 1.5), instance=77)
+    with pytest.raises(ValueError, match="share a position"):
+        dicom.load_series(tmp_path / "dup")
+    # a sheared stack: slice origins drift in-plane
+    import os
+    os.makedirs(tmp_path / "shear")
+    for z in range(len(vol)):
+        write_slice(tmp_path / "shear" / f"s{z:03d}.dcm", vol[z], ipp=(-100.0 + 0.4 * z, -120.0, 50.0 + 1.5 * z), instance=z + 1)
+    with pytest.raises(ValueError, match="sheared"):
+        dicom.load_series(tmp_path / "shear")
+    # slices of different size
+    write_series(tmp_path / "size", vol)
+    write_slice(tmp_path / "size" / "big.dcm", np.zeros((10, 7), np.uint16), ipp=(-100.0, -120.0, 50.0 + 12 * 1.5), instance=13)
+    with pytest.raises(ValueError, match="slice size differs"):
+        dicom.load_series(tmp_path / "size")
+    # a single slice: z spacing falls back to SliceThickness
+    write_series(tmp_path / "one", vol[:1])
+    data, geom, files = dicom.load_series(tmp_path / "one")
+    assert data.shape == (7, 9, 1) and geom["spacing"][2] == 1.5 and len(files) == 1
